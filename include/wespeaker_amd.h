@@ -1,0 +1,140 @@
+/*
+ * wespeaker_amd.h -- C-ABI of the MI355X-native speaker-embedding + PLDA engine.
+ *
+ * This is the drop-in boundary for the hot path of wenet-e2e/wespeaker
+ * (fbank -> ECAPA-TDNN / ResNet / CAM++ forward -> two-covariance PLDA LLR).
+ * The reference has no FFI of its own for this path (it is torch.nn.Modules + numpy); each entry
+ * point below names the reference interface it replaces (file:line relative to the reference
+ * repo).  INTEGRATION.md shows the ctypes / C++ bindings a reference maintainer would add.
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes only; no C++ or torch types cross the boundary.
+ *   - every call returns int: 0 = ok, negative = error (never aborts);
+ *     ws_last_error() returns a thread-local human-readable message for the last failure.
+ *   - the caller owns every input/output buffer; the handle owns weights + workspace.
+ *   - pointers marked DEVICE are HIP device pointers on the handle's device; HOST are host pointers.
+ *   - all GPU work is enqueued on the caller's stream (a hipStream_t passed as void*; NULL = the
+ *     default stream); no call synchronises the device unless documented.
+ *   - one handle per (process, GPU); handles are not thread-safe.
+ */
+#ifndef WESPEAKER_AMD_H_
+#define WESPEAKER_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_OK 0
+#define WS_ERR_INVALID_ARG (-1)
+#define WS_ERR_UNKNOWN_MODEL (-2)
+#define WS_ERR_MISSING_TENSOR (-3)
+#define WS_ERR_SHAPE (-4)
+#define WS_ERR_HIP (-5)
+#define WS_ERR_STATE (-6)
+#define WS_ERR_CAPACITY (-7)
+
+#define WS_WINDOW_HAMMING 0 /* Speaker default, cli/speaker.py:50 */
+#define WS_WINDOW_POVEY 1   /* Speaker.set_window_type('povey'), cli/speaker.py:66-67 */
+
+#define WS_WAV_INT16 0 /* PCM16 samples (torchaudio.load(normalize=False), cli/speaker.py:126) */
+#define WS_WAV_FLOAT32 1
+
+typedef struct ws_engine ws_engine;     /* one speaker-embedding model on one GPU */
+typedef struct ws_frontend ws_frontend; /* Kaldi fbank + CMN frontend on one GPU  */
+typedef struct ws_plda ws_plda;         /* two-covariance PLDA scorer on one GPU  */
+typedef void* ws_stream;                /* hipStream_t */
+
+/* ------------------------------------------------------------------------------------ misc */
+int ws_version(void);
+const char* ws_last_error(void);
+/* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):
+ * 1 + (N - 400) / 160 at 16 kHz; 0 if N < frame length. */
+int ws_num_frames(int num_samples, int sample_rate);
+
+/* -------------------------------------------------------------------------------- frontend */
+/* Replaces torchaudio.compliance.kaldi.fbank as called at cli/speaker.py:92-97 and
+ * dataset/processor.py:518-525 (+ CMN cli/speaker.py:98-99, dataset_utils.py:19-26); native twin
+ * runtime/core/frontend/fbank.h:33-97 (constructor: mel banks, window).  dither is always 0. */
+int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out);
+void ws_frontend_destroy(ws_frontend* fe);
+/* wav: DEVICE (B, wav_stride) samples, the first num_samples of each row are used.
+ * scale multiplies samples on load (1.0 for int16-range input; 32768.0 reproduces
+ * processor.py:516 `waveform * (1 << 15)` for [-1,1] floats).
+ * feats: DEVICE (B, T, num_mel_bins) float32, T = ws_num_frames(num_samples).
+ * cmn != 0 subtracts the per-utterance mean over T from every mel bin. */
+int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num_samples,
+             int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
+             ws_stream stream);
+
+/* ---------------------------------------------------------------------------------- engine */
+/* Replaces get_speaker_model(name)(**model_args) + load_checkpoint (models/speaker_model.py:31-62,
+ * utils/checkpoint.py:20-85, cli/speaker.py:306-335).  model_name is the reference constructor
+ * name ("ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c1024", ...).  Tensors are supplied under the
+ * reference's state_dict key names (e.g. "layer2.se_res2block.1.convs.3.weight"); unknown keys
+ * ("projection.*", "*.num_batches_tracked") are ignored like strict=False does.  Returns the
+ * native twin of runtime/core/speaker/speaker_model.h:25-32 (SpeakerModel). */
+int ws_engine_create(const char* model_name, int feat_dim, int embed_dim, int device_id,
+                     ws_engine** out);
+/* data: HOST float32, C-contiguous, ndim <= 4.  Returns 1 if the key was consumed, 0 if ignored. */
+int ws_engine_set_tensor(ws_engine* eng, const char* key, const float* data, int ndim,
+                         const int64_t* shape);
+/* Checks that every required tensor arrived (WS_ERR_MISSING_TENSOR names the first missing key),
+ * folds/re-lays-out the weights, uploads them and allocates workspace for max_batch utterances
+ * of max_frames frames per forward chunk (larger batches are processed in chunks). */
+int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames);
+void ws_engine_destroy(ws_engine* eng);
+int ws_engine_embed_dim(const ws_engine* eng);
+int ws_engine_feat_dim(const ws_engine* eng);
+/* Replaces model(feats)[-1] (cli/speaker.py:163-166; bin/extract.py:133-135):
+ * feats DEVICE (B, T, feat_dim) float32 (already CMN'd) -> emb DEVICE (B, embed_dim) float32. */
+int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, float* emb,
+               ws_stream stream);
+/* Fused Speaker.extract_embedding_from_pcm (cli/speaker.py:156-166): wav -> fbank -> CMN ->
+ * forward, feature tensor kept inside the engine's workspace. */
+int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
+               int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
+               ws_stream stream);
+/* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
+double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
+
+/* ------------------------------------------------------------------------------------ PLDA */
+/* Replaces TwoCovPLDA.load_model's in-memory state (utils/plda/two_cov_plda.py:341-363):
+ * mu, psi, offset HOST float64[dim]; transform HOST float64[dim*dim] row-major. */
+int ws_plda_create(int dim, const double* mu, const double* transform, const double* psi,
+                   const double* offset, int normalize_length, int device_id, ws_plda** out);
+void ws_plda_destroy(ws_plda* plda);
+/* eval_sv pre-processing for enrollment models (two_cov_plda.py:216-235): rows of emb are grouped
+ * contiguously, group g = rows [group_offsets[g], group_offsets[g+1]).  Per group: subtract
+ * mean_vec (HOST float64[dim] or NULL), mean over rows, length-norm of the mean if
+ * normalize_length, transform_embedding.  emb DEVICE float32 (n_rows, dim); group_offsets DEVICE
+ * int32[n_groups+1]; out DEVICE float64 (n_groups, dim). */
+int ws_plda_prepare_enroll(ws_plda* plda, const float* emb, const int32_t* group_offsets,
+                           int n_groups, const double* mean_vec, double* out, ws_stream stream);
+/* eval_sv pre-processing for test utterances (two_cov_plda.py:237-244) == transform_embedding
+ * (:156-163) after optional mean subtraction / length-norm.  emb DEVICE float32 (n, dim);
+ * out DEVICE float64 (n, dim). */
+int ws_plda_prepare_test(ws_plda* plda, const float* emb, int n, const double* mean_vec,
+                         double* out, ws_stream stream);
+/* TwoCovPLDA.transform_embedding (two_cov_plda.py:156-163) verbatim: y = transform x + offset, then
+ * y *= sqrt(D)/|y| iff normalize_length.  x DEVICE float64 (n, dim); out DEVICE float64 (n, dim). */
+int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_stream stream);
+/* Dense LLR matrix: log_likelihood_ratio (two_cov_plda.py:165-184) for every (enroll i, test j).
+ * enroll DEVICE float64 (n_enroll, dim) transformed; n_sessions DEVICE int32[n_enroll] (the `n`
+ * argument: 1 if multisession_avg else #utts, :219-222); test DEVICE float64 (n_test, dim);
+ * out DEVICE float64 (n_enroll, n_test). */
+int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+                       int n_enroll, const double* test, int n_test, double* out,
+                       ws_stream stream);
+/* Explicit trial list (the eval_sv trial loop :246-256): out[p] = LLR(enroll[idx_e[p]],
+ * test[idx_t[p]], n_sessions[idx_e[p]]).  idx_* DEVICE int32[num_trials]; out DEVICE float64. */
+int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+                      int n_enroll, const double* test, int n_test, const int32_t* idx_e,
+                      const int32_t* idx_t, int64_t num_trials, double* out, ws_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WESPEAKER_AMD_H_ */

@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""ORACLE tooling (test infrastructure): generate tests/golden/*.npz by running the
+REFERENCE ITSELF in this container.
+
+  python oracle/make_golden.py          # needs /root/reference; writes tests/golden/
+
+What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerated from them):
+  * ecapa_ref.npz   -- embeddings of the reference's own nn.Modules
+                       (wespeaker/models/ecapa_tdnn.py, imported from /root/reference) for the four
+                       ECAPA constructors on synthetic utterances 0..1, weights = synth seed 42.
+  * plda_ref.npz    -- outputs of the reference's own TwoCovPLDA.transform_embedding /
+                       log_likelihood_ratio (wespeaker/utils/plda/two_cov_plda.py:156-184).
+  * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
+                       (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
+The GPU box has no /root/reference; tests there compare against these committed files.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from oracle.fbank import speaker_features  # noqa: E402
+from wespeaker_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_native_fbank(pcm_int16):
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_fbank.so"))
+    lib.ref_fbank.restype = ctypes.c_int
+    x = np.ascontiguousarray(pcm_int16, dtype=np.float32)
+    out = np.zeros((2000, 80), np.float32)
+    n = lib.ref_fbank(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]), 80, 16000,
+                      out.ctypes.data_as(ctypes.c_void_p), 2000)
+    return out[:n].copy()
+
+
+def make_fbank():
+    idx = [0, 7]
+    feats = np.stack([ref_native_fbank(synth.synth_wav(i)) for i in idx])
+    short = ref_native_fbank(synth.synth_wav(3, 4000))     # 23 frames
+    np.savez_compressed(os.path.join(GOLD, "fbank_ref_native.npz"), utt_idx=np.array(idx),
+                        logmel=feats, short_idx=np.array(3), short_len=np.array(4000),
+                        short_logmel=short)
+    mine = np.stack([speaker_features(synth.synth_wav(i), cmn=False) for i in idx])
+    print("fbank: native-ref vs restatement max|d| = %.3e mean|d| = %.3e"
+          % (np.abs(mine - feats).max(), np.abs(mine - feats).mean()))
+
+
+def make_ecapa():
+    out = {}
+    feats = np.stack([speaker_features(synth.synth_wav(i)) for i in range(2)])
+    feats_short = feats[:, :57, :].copy()
+    for name in ("ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512", "ECAPA_TDNN_GLOB_c1024",
+                 "ECAPA_TDNN_c1024"):
+        sd = synth.synth_ecapa_state_dict(name, 80, 192, seed=42)
+        m = ref_shim.ref_model(name, feat_dim=80, embed_dim=192, pooling_func="ASTP")
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m.eval()
+        with torch.no_grad():
+            out4, emb = m(torch.from_numpy(feats))
+            _, emb_s = m(torch.from_numpy(feats_short))
+        out[name + "/emb"] = emb.numpy()
+        out[name + "/emb_T57"] = emb_s.numpy()
+        out[name + "/out4_absmean"] = np.array(out4.abs().mean().item())
+        print(name, "emb", emb.shape, float(emb.abs().mean()))
+    # emb_bn=True variant (bn2 path, ecapa_tdnn.py:202-206,232-233)
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_c512", 80, 256, emb_bn=True, seed=5)
+    m = ref_shim.ref_model("ECAPA_TDNN_c512", feat_dim=80, embed_dim=256, pooling_func="ASTP",
+                           emb_bn=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    with torch.no_grad():
+        out["ECAPA_TDNN_c512_embbn/emb"] = m(torch.from_numpy(feats))[-1].numpy()
+    np.savez_compressed(os.path.join(GOLD, "ecapa_ref.npz"), **out)
+
+
+def make_plda():
+    out = {}
+    emb, _ = synth.synth_embeddings(40, 192, seed=11)
+    for nl in (False, True):
+        p = synth.synth_plda(192, seed=7, normalize_length=nl)
+        ref = ref_shim.ref_plda(p)
+        tr = np.stack([ref.transform_embedding(e.astype(np.float64)) for e in emb])
+        tag = "nl%d" % int(nl)
+        out[tag + "/transformed"] = tr
+        for n in (1, 3):
+            llr = np.array([[ref.log_likelihood_ratio(tr[i], tr[20 + j], n) for j in range(20)]
+                            for i in range(20)])
+            out["%s/llr_n%d" % (tag, n)] = llr
+    np.savez_compressed(os.path.join(GOLD, "plda_ref.npz"), **out)
+    print("plda llr range", float(llr.min()), float(llr.max()))
+
+
+if __name__ == "__main__":
+    assert ref_shim.available(), "needs /root/reference"
+    os.makedirs(GOLD, exist_ok=True)
+    make_fbank()
+    make_ecapa()
+    make_plda()
+    print("golden fixtures written to", GOLD)

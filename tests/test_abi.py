@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/wespeaker_amd.h declares
+(no compute calls here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+from wespeaker_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "wespeaker_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ws_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(built_lib):
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(built_lib, n), "symbol %s missing from libwespeaker_amd.so" % n
+        assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
+    for n in _lib.SIGNATURES:
+        assert n in names, "ctypes binds %s which the header does not declare" % n
+
+
+def test_pure_host_entry_points(built_lib):
+    assert built_lib.ws_version() >= 100
+    # frame-count known answers from the reference: 2 s @ 16 kHz -> 198 frames
+    # (runtime/server/x86_gpu/README.md:35-53), num_frames + 2 == seg_length in 10 ms units
+    assert built_lib.ws_num_frames(32000, 16000) == 198
+    assert built_lib.ws_num_frames(400, 16000) == 1
+    assert built_lib.ws_num_frames(399, 16000) == 0
+    assert built_lib.ws_num_frames(0, 16000) == 0
+    assert built_lib.ws_num_frames(16000 * 3, 16000) == 298
+    assert isinstance(built_lib.ws_last_error(), bytes)
+
+
+def test_invalid_arguments_return_codes_not_aborts(built_lib):
+    h = ctypes.c_void_p()
+    assert built_lib.ws_engine_create(None, 80, 192, 0, ctypes.byref(h)) == -1
+    assert b"invalid" in built_lib.ws_last_error()
+    assert built_lib.ws_engine_create(b"ECAPA_TDNN_c512", 81, 192, 0, ctypes.byref(h)) == -1
+    assert built_lib.ws_forward(None, None, 1, 1, None, None) == -1
+    assert built_lib.ws_plda_create(0, None, None, None, None, 0, 0, ctypes.byref(h)) == -1
+    assert built_lib.ws_engine_embed_dim(None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.lib()
+    except _lib.NativeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("expected NativeError")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under wespeaker_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "wespeaker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

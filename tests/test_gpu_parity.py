@@ -1,0 +1,259 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same seeded
+inputs and against the committed golden vectors produced by the reference itself.
+
+Bars (BASELINE.json north_star): embeddings within 1e-4 cosine of the reference CPU path, PLDA
+LLRs within 1e-3.  The tests additionally hold tighter bounds (relative L2 error) so that a
+wrong-but-correlated embedding cannot pass."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as oecapa
+from oracle import fbank as ofbank
+from oracle import plda as oplda
+from wespeaker_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-4          # north_star: 1 - cosine <= 1e-4
+REL_TOL = 2e-4          # our own: ||e - e_ref|| / ||e_ref||   (fp32 contraction-order noise is ~1e-6)
+LLR_TOL = 1e-3          # north_star; float64 path is far inside (checked at 1e-8 below)
+
+
+def _cos_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return 1.0 - np.sum(a * b, -1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def _rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+@pytest.fixture(scope="module")
+def frontend():
+    from wespeaker_amd.engine import Frontend
+    return Frontend(16000, 80)
+
+
+# ------------------------------------------------------------------------------------- fbank
+@pytest.mark.parametrize("window", ["hamming", "povey"])
+def test_fbank_matches_oracle(frontend, window):
+    wav = synth.synth_wav_batch(0, 5)
+    got = frontend.fbank(torch.from_numpy(wav), window_type=window, cmn=False).cpu().numpy()
+    ref = np.stack([ofbank.kaldi_fbank(w.astype(np.float32), window_type=window) for w in wav])
+    assert got.shape == ref.shape == (5, 198, 80)
+    assert np.abs(got - ref).max() < 2e-3            # log-mel values span ~8..26
+    assert np.abs(got - ref).mean() < 2e-5
+    got_c = frontend.fbank(torch.from_numpy(wav), window_type=window, cmn=True).cpu().numpy()
+    ref_c = ref - ref.mean(1, keepdims=True)
+    assert np.abs(got_c - ref_c).max() < 2e-3
+
+
+def test_fbank_matches_reference_native_golden(frontend, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fbank_ref_native.npz"))
+    wav = np.stack([synth.synth_wav(int(i)) for i in g["utt_idx"]])
+    got = frontend.fbank(torch.from_numpy(wav), cmn=False).cpu().numpy()
+    assert np.abs(got - g["logmel"]).max() < 5e-4     # reference-owned native arithmetic
+
+
+def test_fbank_edge_cases(frontend):
+    # ragged / minimal lengths, float input, strided rows, silence
+    for n in (400, 559, 560, 4000, 16000 * 5):
+        wav = synth.synth_wav(11, n)
+        got = frontend.fbank(torch.from_numpy(wav)[None], cmn=False).cpu().numpy()[0]
+        ref = ofbank.kaldi_fbank(wav.astype(np.float32), window_type="hamming")
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 2e-3
+    assert frontend.fbank(torch.zeros(2, 399, dtype=torch.int16)).shape == (2, 0, 80)
+    z = frontend.fbank(torch.zeros(1, 1000, dtype=torch.int16), cmn=False).cpu().numpy()
+    assert np.allclose(z, np.log(np.float32(1.1920929e-07)))
+    wav = synth.synth_wav_batch(20, 3)
+    f32 = frontend.fbank(torch.from_numpy(wav.astype(np.float32)), cmn=False).cpu().numpy()
+    i16 = frontend.fbank(torch.from_numpy(wav), cmn=False).cpu().numpy()
+    assert np.array_equal(f32, i16)
+    # [-1, 1] floats with scale 32768 (processor.py:516)
+    sc = frontend.fbank(torch.from_numpy(wav.astype(np.float32) / 32768.0), cmn=False,
+                        scale=32768.0).cpu().numpy()
+    assert np.abs(sc - i16).max() < 1e-3
+    # max values: full-scale square wave must not overflow / NaN
+    sq = np.where(np.arange(32000) % 64 < 32, 32767, -32768).astype(np.int16)
+    out = frontend.fbank(torch.from_numpy(sq)[None], cmn=False).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out[0] - ofbank.kaldi_fbank(sq.astype(np.float32), window_type="hamming")).max() < 2e-3
+
+
+# ------------------------------------------------------------------------------------- ECAPA
+def _engine(name, embed_dim=192, seed=42, **kw):
+    from wespeaker_amd.engine import NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict(name, 80, embed_dim, seed=seed, **kw)
+    return sd, NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=embed_dim, max_batch=8,
+                                  max_frames=400)
+
+
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512",
+                                  "ECAPA_TDNN_GLOB_c1024", "ECAPA_TDNN_c1024"])
+def test_ecapa_forward_matches_oracle_and_golden(name, golden_dir):
+    sd, model = _engine(name)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(3)])
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    ref = oecapa.ecapa_forward(sd, feats).numpy()
+    assert got.shape == ref.shape == (3, 192)
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < REL_TOL
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))       # reference nn.Module outputs
+    assert _cos_err(got[:2], g[name + "/emb"]).max() < COS_TOL
+    assert _rel_err(got[:2], g[name + "/emb"]).max() < REL_TOL
+    got_s = model(torch.from_numpy(feats[:2, :57].copy()))[-1].cpu().numpy()
+    assert _rel_err(got_s, g[name + "/emb_T57"]).max() < REL_TOL
+
+
+def test_ecapa_emb_bn_and_shapes(golden_dir):
+    sd, model = _engine("ECAPA_TDNN_c512", embed_dim=256, seed=5, emb_bn=True)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))
+    assert _rel_err(got, g["ECAPA_TDNN_c512_embbn/emb"]).max() < REL_TOL
+
+
+def test_ecapa_batch_invariance_chunking_and_ragged_lengths():
+    """Utterances are independent: any batch split / chunking gives the same rows; odd lengths
+    (T not a multiple of any tile) work; B larger than the engine's chunk is processed in chunks."""
+    sd, model = _engine("ECAPA_TDNN_GLOB_c512")
+    wav = synth.synth_wav_batch(30, 19)
+    feats = np.stack([ofbank.speaker_features(w) for w in wav])
+    full = model(torch.from_numpy(feats))[-1].cpu().numpy()            # 19 > max_batch 8 -> 3 chunks
+    one = np.concatenate([model(torch.from_numpy(feats[i:i + 1]))[-1].cpu().numpy()
+                          for i in range(19)])
+    assert _rel_err(full, one).max() < 1e-5
+    ref = oecapa.ecapa_forward(sd, feats).numpy()
+    assert _rel_err(full, ref).max() < REL_TOL
+    for T in (5, 33, 129, 201, 399):
+        f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
+        got = model(torch.from_numpy(f))[-1].cpu().numpy()
+        assert _rel_err(got, oecapa.ecapa_forward(sd, f).numpy()).max() < REL_TOL
+    with pytest.raises(Exception):
+        model(torch.zeros(1, 401, 80))                                    # over capacity: loud
+    assert model(torch.zeros(0, 100, 80))[-1].shape == (0, 192)           # empty batch
+
+
+# ---------------------------------------------------------------------- Speaker API end-to-end
+def test_speaker_api_end_to_end(tmp_path):
+    import wespeaker_amd as wespeaker
+    mdir = str(tmp_path / "model")
+    sd = synth.write_model_dir(mdir, "ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    with pytest.raises(FileNotFoundError):
+        wespeaker.load_model_pt(str(tmp_path))
+    spk = wespeaker.load_model(mdir)
+    assert spk.model.frontend_type == "fbank"
+    scp = tmp_path / "wav.scp"
+    lines = []
+    lengths = [32000, 32000, 24000, 32000, 16000]
+    for i, n in enumerate(lengths):
+        p = str(tmp_path / ("u%d.wav" % i))
+        synth.write_wav(p, synth.synth_wav(100 + i, n))
+        lines.append("utt%d %s" % (i, p))
+    scp.write_text("\n".join(lines) + "\n")
+    names, embs = spk.extract_embedding_list(str(scp))
+    assert names == ["utt%d" % i for i in range(5)]
+    ref = [oecapa.ecapa_forward(sd, ofbank.speaker_features(synth.synth_wav(100 + i, n))[None]).numpy()[0]
+           for i, n in enumerate(lengths)]
+    for e, r in zip(embs, ref):
+        assert isinstance(e, np.ndarray) and e.shape == (192,)
+        assert _cos_err(e, r) < COS_TOL and _rel_err(e, r) < 5e-4
+    e0 = spk.extract_embedding(str(tmp_path / "u0.wav"))
+    assert isinstance(e0, torch.Tensor) and e0.device.type == "cpu"
+    assert _rel_err(e0.numpy(), embs[0]) < 1e-5
+    s = spk.compute_similarity(str(tmp_path / "u0.wav"), str(tmp_path / "u0.wav"))
+    assert abs(s - 1.0) < 1e-5
+    spk.set_window_type("povey")
+    ep = spk.extract_embedding(str(tmp_path / "u0.wav")).numpy()
+    rp = oecapa.ecapa_forward(sd, ofbank.speaker_features(synth.synth_wav(100), window_type="povey")[None]).numpy()[0]
+    assert _rel_err(ep, rp) < 5e-4
+    spk.set_window_type("hamming")
+    fb = [ofbank.speaker_features(synth.synth_wav(100 + i, 24000 + 400), cmn=False)[:150] for i in range(3)]
+    ef = spk.extract_embedding_from_feats(fb, batch_size=2, subseg_cmn=True)
+    rf = oecapa.ecapa_forward(sd, np.stack(fb) - np.stack(fb).mean(1, keepdims=True)).numpy()
+    assert _rel_err(ef, rf).max() < REL_TOL
+
+
+# -------------------------------------------------------------------------------------- PLDA
+@pytest.mark.parametrize("normalize_length", [False, True])
+def test_plda_matches_oracle_and_reference_golden(normalize_length, golden_dir):
+    from wespeaker_amd import TwoCovPLDA
+    p = synth.synth_plda(192, seed=7, normalize_length=normalize_length)
+    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    emb, _ = synth.synth_embeddings(40, 192, seed=11)
+    g = np.load(os.path.join(golden_dir, "plda_ref.npz"))
+    tag = "nl%d" % int(normalize_length)
+    tr = plda.transform(emb.astype(np.float64)).cpu().numpy()
+    assert np.abs(tr - g[tag + "/transformed"]).max() < 1e-10
+    one = plda.transform_embedding(emb[3].astype(np.float64))
+    assert np.abs(one - g[tag + "/transformed"][3]).max() < 1e-10
+    for n in (1, 3):
+        ref = g["%s/llr_n%d" % (tag, n)]
+        mat = plda.llr_matrix(tr[:20], np.full(20, n, np.int32), tr[20:]).cpu().numpy()
+        assert np.abs(mat - ref).max() < 1e-8 < LLR_TOL
+        s = plda.log_likelihood_ratio(tr[2], tr[25], n)
+        assert abs(s - ref[2, 5]) < 1e-8
+    # mixed n per enrollment row, odd sizes, explicit pairs
+    E, T = tr[:17], tr[17:40]
+    nn = (np.arange(17) % 4 + 1).astype(np.int32)
+    mat = plda.llr_matrix(E, nn, T).cpu().numpy()
+    ref = np.array([[oplda.log_likelihood_ratio(p, E[i], T[j], nn[i]) for j in range(23)] for i in range(17)])
+    assert np.abs(mat - ref).max() < 1e-8
+    ie, it = synth.synth_trial_pairs(1000, 17, 23)
+    pr = plda.llr_pairs(E, nn, T, ie, it).cpu().numpy()
+    assert np.abs(pr - ref[ie, it]).max() < 1e-8
+    assert plda.llr_pairs(E, nn, T, ie[:0], it[:0]).shape == (0,)
+
+
+@pytest.mark.parametrize("normalize_length,multisession_avg", [(False, True), (True, False)])
+def test_score_plda_and_eval_sv_files(tmp_path, normalize_length, multisession_avg):
+    from wespeaker_amd import TwoCovPLDA, kaldi_io, score_plda
+    p = synth.synth_plda(64, seed=3, normalize_length=normalize_length)
+    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    emb, spk = synth.synth_embeddings(60, 64, seed=5, num_speakers=6)
+    enroll = {}
+    for i in range(30):
+        enroll.setdefault("spk%d" % spk[i], []).append(emb[i])
+    test = {"t%d" % i: emb[30 + i] for i in range(30)}
+    trials = [(m, t, "target") for m in enroll for t in list(test)[::3]]
+    indomain = emb.mean(0).astype(np.float64)
+    got = score_plda(plda, enroll, test, trials, multisession_avg=multisession_avg,
+                     indomain_mean=indomain)
+    e_t, n_e = {}, {}
+    for k, v in enroll.items():
+        e_t[k], n_e[k] = oplda.prepare_enroll(p, v, indomain, multisession_avg)
+    t_t = {k: oplda.prepare_test(p, v, indomain) for k, v in test.items()}
+    ref = np.array([oplda.log_likelihood_ratio(p, e_t[m], t_t[t], n_e[m]) for m, t, _ in trials])
+    assert np.abs(got - ref).max() < 1e-8
+    # file-level eval_sv with Kaldi ark/scp I/O
+    with kaldi_io.VectorWriter(str(tmp_path / "e.ark"), str(tmp_path / "e.scp")) as w:
+        utt2spk = []
+        for k, vs in enroll.items():
+            for j, v in enumerate(vs):
+                w("%s_u%d" % (k, j), v)
+                utt2spk.append("%s_u%d %s" % (k, j, k))
+    (tmp_path / "utt2spk").write_text("\n".join(utt2spk) + "\n")
+    with kaldi_io.VectorWriter(str(tmp_path / "t.ark"), str(tmp_path / "t.scp")) as w:
+        for k, v in test.items():
+            w(k, v)
+    (tmp_path / "trials").write_text("".join("%s %s %s\n" % t for t in trials))
+    plda.save_model(str(tmp_path / "plda.npz"))
+    plda2 = TwoCovPLDA.load_model(str(tmp_path / "plda.npz"))
+    assert plda2.normalize_length == normalize_length
+    with kaldi_io.VectorWriter(str(tmp_path / "i.ark"), str(tmp_path / "i.scp")) as w:
+        for i in range(60):
+            w("i%d" % i, emb[i])
+    plda2.eval_sv(str(tmp_path / "e.scp"), str(tmp_path / "utt2spk"), str(tmp_path / "t.scp"),
+                  str(tmp_path / "trials"), str(tmp_path / "scores"),
+                  multisession_avg=multisession_avg, indomain_scp=str(tmp_path / "i.scp"))
+    lines = (tmp_path / "scores").read_text().strip().split("\n")
+    assert len(lines) == len(trials)
+    for ln, (m, t, lab), r in zip(lines, trials, ref):
+        a = ln.split()
+        assert a[0] == m and a[1] == t and a[3] == lab
+        assert abs(float(a[2]) - r) < 1e-3          # printed with %.5f; indomain mean in f32 ark

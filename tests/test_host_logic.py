@@ -1,0 +1,96 @@
+"""CPU: host-side logic that needs no GPU -- I/O formats, synthetic generators, sharding rule,
+and the world_size-2 gather path on the gloo backend."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wespeaker_amd import audio, kaldi_io, parallel, synth
+
+
+def test_synth_is_deterministic():
+    a, b = synth.synth_wav(3), synth.synth_wav(3)
+    assert a.dtype == np.int16 and a.shape == (32000,) and np.array_equal(a, b)
+    assert not np.array_equal(a, synth.synth_wav(4))
+    s1 = synth.synth_ecapa_state_dict("ECAPA_TDNN_c512", seed=1)
+    s2 = synth.synth_ecapa_state_dict("ECAPA_TDNN_c512", seed=1)
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+    n_params = sum(v.size for k, v in s1.items() if v.dtype == np.float32 and "running" not in k)
+    assert abs(n_params - 5.80e6) < 0.05e6        # 5.80 M (runtime/onnxruntime/README.md:77-88 scale)
+    g = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512")
+    n_glob = sum(v.size for k, v in g.items() if v.dtype == np.float32 and "running" not in k)
+    assert abs(n_glob - 6.19e6) < 0.05e6
+
+
+def test_wav_roundtrip(tmp_path):
+    pcm = synth.synth_wav(2, 8000)
+    p = str(tmp_path / "a.wav")
+    synth.write_wav(p, pcm)
+    x, sr = audio.load_wav(p, normalize=False)
+    assert sr == 16000 and x.dtype == torch.int16 and x.shape == (1, 8000)
+    assert np.array_equal(x[0].numpy(), pcm)
+    y, _ = audio.load_wav(p, normalize=True)
+    assert y.dtype == torch.float32 and torch.allclose(y[0], torch.from_numpy(pcm / 32768.0).float())
+
+
+def test_kaldi_vector_ark_scp_roundtrip(tmp_path):
+    ark, scp = str(tmp_path / "x.ark"), str(tmp_path / "x.scp")
+    vecs = {"utt%d" % i: np.random.RandomState(i).randn(192).astype(np.float32) for i in range(5)}
+    with kaldi_io.VectorWriter(ark, scp) as w:
+        for k, v in vecs.items():
+            w(k, v)
+    back = kaldi_io.read_vec_scp(scp)
+    assert list(back) == list(vecs)
+    assert all(np.array_equal(back[k], vecs[k]) for k in vecs)
+    seq = kaldi_io.read_vec_ark(ark)
+    assert all(np.array_equal(seq[k], vecs[k]) for k in vecs)
+    # byte layout: key ' ' \0 B F V ' ' \4 int32 dim payload   (utils/plda/kaldi_utils.py:58-79)
+    raw = open(ark, "rb").read()
+    assert raw.startswith(b"utt0 \x00BFV \x04\xc0\x00\x00\x00")
+
+
+def test_shard_rule_matches_reference_split():
+    # tools/extract_embedding.sh:40-42: split -l ceil(N/nj) -> contiguous chunks, last one short
+    for n, g in [(100, 8), (4874, 8), (7, 8), (0, 4), (10000, 4), (5, 1)]:
+        ranges = [parallel.shard_range(n, r, g) for r in range(g)]
+        covered = [i for lo, hi in ranges for i in range(lo, hi)]
+        assert covered == list(range(n))
+        per = parallel.shard_size(n, g)
+        assert all(hi - lo <= per for lo, hi in ranges)
+
+
+def _gloo_worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    wavs = torch.arange(n_total * 4, dtype=torch.float32).reshape(n_total, 4)
+
+    def fake_extract(block):            # "embedding" = row sums, width 3
+        s = block.sum(1, keepdim=True)
+        return torch.cat([s, s * 2, s * 3], 1)
+
+    out = parallel.extract_sharded(fake_extract, wavs, batch_size=3)
+    expect = fake_extract(wavs)
+    q.put((rank, bool(torch.equal(out, expect)), tuple(out.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [11, 2, 1])
+def test_world_size_2_gather_on_gloo(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() + n_total) % 300
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok and shape == (n_total, 3), (rank, ok, shape)

@@ -1,0 +1,121 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors produced by the REFERENCE ITSELF
+(oracle/make_golden.py ran the reference's nn.Modules / TwoCovPLDA / native fbank in the build
+container).  If /root/reference is present, also re-check against the live reference."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as oecapa
+from oracle import fbank as ofbank
+from oracle import plda as oplda
+from oracle import ref_shim
+from wespeaker_amd import synth
+
+
+def test_fbank_restatement_vs_reference_native(golden_dir):
+    g = np.load(os.path.join(golden_dir, "fbank_ref_native.npz"))
+    for k, idx in enumerate(g["utt_idx"]):
+        mine = ofbank.speaker_features(synth.synth_wav(int(idx)), cmn=False)
+        ref = g["logmel"][k]
+        assert mine.shape == ref.shape == (198, 80)        # 2 s @ 16 kHz -> 198 frames
+        # the reference's native code uses a hand-rolled float FFT / logf: agreement to ~2e-4
+        assert np.abs(mine - ref).max() < 5e-4
+        assert np.abs(mine - ref).mean() < 2e-5
+    short = ofbank.speaker_features(synth.synth_wav(int(g["short_idx"]), int(g["short_len"])), cmn=False)
+    assert short.shape == g["short_logmel"].shape == (23, 80)
+    assert np.abs(short - g["short_logmel"]).max() < 5e-4
+
+
+def test_fbank_edge_cases():
+    assert ofbank.kaldi_fbank(np.zeros(399, np.float32), window_type="hamming").shape == (0, 80)
+    assert ofbank.kaldi_fbank(np.zeros(400, np.float32), window_type="hamming").shape == (1, 80)
+    z = ofbank.kaldi_fbank(np.zeros(1000, np.float32), window_type="hamming")
+    assert np.allclose(z, np.log(np.float32(1.1920929e-07)))          # floor at eps
+    x = synth.synth_wav(1).astype(np.float32)
+    a = ofbank.kaldi_fbank(x, window_type="hamming")
+    b = ofbank.kaldi_fbank(np.stack([x, -x]), window_type="hamming")   # channel 0 only
+    assert np.array_equal(a, b)
+    c = ofbank.kaldi_fbank(x, window_type="hamming", cmn=True)
+    assert np.abs(c.mean(0)).max() < 1e-4
+    p = ofbank.kaldi_fbank(x, window_type="povey")
+    assert np.abs(p - a).max() > 1e-3                                 # the window matters
+    # [-1,1] floats scaled by 1<<15 (processor.py:516) == int16-range input
+    d = ofbank.kaldi_fbank((x / 32768.0) * np.float32(32768.0), window_type="hamming")
+    assert np.abs(d - a).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512",
+                                  "ECAPA_TDNN_GLOB_c1024", "ECAPA_TDNN_c1024"])
+def test_ecapa_restatement_vs_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))
+    sd = synth.synth_ecapa_state_dict(name, 80, 192, seed=42)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    emb = oecapa.ecapa_forward(sd, feats).numpy()
+    ref = g[name + "/emb"]
+    assert emb.shape == ref.shape == (2, 192)
+    assert np.abs(emb - ref).max() <= 2e-4 * np.abs(ref).max()
+    emb_s = oecapa.ecapa_forward(sd, feats[:, :57]).numpy()
+    assert np.abs(emb_s - g[name + "/emb_T57"]).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_ecapa_emb_bn_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_c512", 80, 256, emb_bn=True, seed=5)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    emb = oecapa.ecapa_forward(sd, feats).numpy()
+    ref = g["ECAPA_TDNN_c512_embbn/emb"]
+    assert np.abs(emb - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_plda_restatement_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "plda_ref.npz"))
+    emb, _ = synth.synth_embeddings(40, 192, seed=11)
+    for nl in (False, True):
+        p = synth.synth_plda(192, seed=7, normalize_length=nl)
+        tag = "nl%d" % int(nl)
+        tr = np.stack([oplda.transform_embedding(p, e) for e in emb])
+        assert np.abs(tr - g[tag + "/transformed"]).max() < 1e-12
+        for n in (1, 3):
+            ref = g["%s/llr_n%d" % (tag, n)]
+            loop = np.array([[oplda.log_likelihood_ratio(p, tr[i], tr[20 + j], n) for j in range(20)]
+                             for i in range(20)])
+            assert np.abs(loop - ref).max() < 1e-10
+            mat = oplda.llr_matrix_vectorised(p, tr[:20], np.full(20, n), tr[20:])
+            assert np.abs(mat - ref).max() < 1e-9
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference checkout not present (GPU box)")
+def test_live_reference_agrees_with_oracle():
+    """In the build container the reference is importable: bit-compare the restatement."""
+    name = "ECAPA_TDNN_GLOB_c512"
+    sd = synth.synth_ecapa_state_dict(name, 80, 192, seed=3)
+    m = ref_shim.ref_model(name, feat_dim=80, embed_dim=192, pooling_func="ASTP")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    feats = torch.from_numpy(np.stack([ofbank.speaker_features(synth.synth_wav(5, 16000))]))
+    with torch.no_grad():
+        ref = m(feats)[-1]
+    mine = oecapa.ecapa_forward(sd, feats)
+    assert torch.equal(ref, mine)
+    p = synth.synth_plda(64, seed=1, normalize_length=True)
+    rp = ref_shim.ref_plda(p)
+    x = np.random.RandomState(0).randn(64)
+    assert np.allclose(rp.transform_embedding(x), oplda.transform_embedding(p, x), atol=1e-13)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref",
+                                                    "libref_fbank.so")),
+                    reason="oracle/_ref not built")
+def test_reference_native_fbank_library_runs():
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libref_fbank.so"))
+    lib.ref_fbank.restype = ctypes.c_int
+    x = synth.synth_wav(7).astype(np.float32)
+    out = np.zeros((300, 80), np.float32)
+    n = lib.ref_fbank(x.ctypes.data_as(ctypes.c_void_p), x.shape[0], 80, 16000,
+                      out.ctypes.data_as(ctypes.c_void_p), 300)
+    assert n == 198
+    mine = ofbank.speaker_features(synth.synth_wav(7), cmn=False)
+    assert np.abs(mine - out[:n]).max() < 5e-4

@@ -1,0 +1,93 @@
+"""ctypes binding of the C-ABI in include/wespeaker_amd.h (no torch C++ extension machinery:
+raw device pointers + the caller's hipStream_t cross the boundary).
+
+The library is the product: if it is missing or fails to load, everything here raises -- there
+is no CPU / eager fallback."""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwespeaker_amd.so")
+
+_lib = None
+
+# name -> (restype, argtypes); also used by the ABI test to check every header symbol is exported
+SIGNATURES = {
+    "ws_version": (c_int, []),
+    "ws_last_error": (c_char_p, []),
+    "ws_num_frames": (c_int, [c_int, c_int]),
+    "ws_frontend_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ws_frontend_destroy": (None, [c_void_p]),
+    "ws_fbank": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_int, c_int,
+                         c_void_p, c_void_p]),
+    "ws_engine_create": (c_int, [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ws_engine_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, POINTER(c_int64)]),
+    "ws_engine_finalize": (c_int, [c_void_p, c_int, c_int]),
+    "ws_engine_destroy": (None, [c_void_p]),
+    "ws_engine_embed_dim": (c_int, [c_void_p]),
+    "ws_engine_feat_dim": (c_int, [c_void_p]),
+    "ws_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ws_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float,
+                           c_int, c_void_p, c_void_p]),
+    "ws_engine_flops": (c_double, [c_void_p, c_int, c_int]),
+    "ws_plda_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               POINTER(c_void_p)]),
+    "ws_plda_destroy": (None, [c_void_p]),
+    "ws_plda_prepare_enroll": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p]),
+    "ws_plda_prepare_test": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "ws_plda_transform": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ws_plda_llr_matrix": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                   c_void_p]),
+    "ws_plda_llr_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_int64, c_void_p, c_void_p]),
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libwespeaker_amd.so."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "%s not found: build it with `python -m wespeaker_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc < 0:
+        msg = lib().ws_last_error()
+        raise NativeError("%s failed (code %d): %s" % (what or "wespeaker_amd call", rc,
+                                                       msg.decode() if msg else ""))
+    return rc
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise NativeError("no MI355X / ROCm device visible: the wespeaker_amd hot path runs only on "
+                          "the GPU (there is no CPU fallback)")
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array as c_void_p."""
+    if hasattr(t, "data_ptr"):
+        return c_void_p(t.data_ptr())
+    return c_void_p(t.ctypes.data)

@@ -1,0 +1,398 @@
+// C-ABI entry points (include/wespeaker_amd.h): error plumbing, the fbank frontend tables,
+// engine lifecycle and the PLDA scorer.  Host code only; kernels live in the other .hip files.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace wsamd {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+}  // namespace wsamd
+
+using namespace wsamd;
+
+// ===================================================================================== frontend
+struct ws_frontend {
+  int sample_rate = 16000, num_bins = 80, device = 0;
+  int frame_len = 400, frame_shift = 160, fft_n = 512;
+  DevBuf window_h, window_p, twiddle, mel_start, mel_len, mel_off, mel_w;
+  FbankTables tables;
+};
+
+struct ws_plda {
+  int dim = 0, device = 0, normalize_length = 0;
+  DevBuf mu, transform, psi, offset, mean_vec;
+  DevBuf EA, rowc, TT;            // GEMM operand scratch (grown on demand)
+  size_t cap_e = 0, cap_t = 0;
+};
+
+extern "C" {
+
+int ws_version(void) { return 100; }
+const char* ws_last_error(void) { return get_error(); }
+
+int ws_num_frames(int num_samples, int sample_rate) {
+  const int flen = (int)(sample_rate * 25.0 * 0.001), fshift = (int)(sample_rate * 10.0 * 0.001);
+  if (fshift <= 0 || num_samples < flen) return 0;
+  return 1 + (num_samples - flen) / fshift;
+}
+
+// ------------------------------------------------------------------------------------ frontend
+static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out) {
+  if (!out || sample_rate <= 0 || num_mel_bins <= 0 || num_mel_bins > 128) {
+    set_error("ws_frontend_create: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(hipSetDevice(device_id));
+  ws_frontend* fe = new ws_frontend;
+  fe->sample_rate = sample_rate; fe->num_bins = num_mel_bins; fe->device = device_id;
+  fe->frame_len = (int)(sample_rate * 25.0 * 0.001);
+  fe->frame_shift = (int)(sample_rate * 10.0 * 0.001);
+  fe->fft_n = next_pow2(fe->frame_len);
+  if (fe->fft_n != 512) {
+    delete fe;
+    set_error("ws_frontend_create: only 25 ms windows that pad to 512 points are supported "
+              "(sample_rate 10241..20480 Hz), got %d Hz", sample_rate);
+    return WS_ERR_INVALID_ARG;
+  }
+  const int L = fe->frame_len, NF = fe->fft_n;
+  // windows (torch.hamming_window / hann_window(periodic=False)^0.85)
+  std::vector<float> wh(L), wp(L);
+  const double a = 2.0 * M_PI / (L - 1);
+  for (int j = 0; j < L; ++j) {
+    wh[j] = (float)(0.54 - 0.46 * std::cos(a * j));
+    wp[j] = (float)std::pow(0.5 - 0.5 * std::cos(a * j), 0.85);
+  }
+  // 512-th roots of unity exp(-2 pi i m / 512)
+  std::vector<float> tw(2 * NF);
+  for (int m = 0; m < NF; ++m) {
+    tw[2 * m] = (float)std::cos(2.0 * M_PI * m / NF);
+    tw[2 * m + 1] = (float)(-std::sin(2.0 * M_PI * m / NF));
+  }
+  // mel banks, float32 arithmetic as in torchaudio.compliance.kaldi.get_mel_banks
+  const int num_fft_bins = NF / 2;
+  const double nyquist = 0.5 * sample_rate, low = 20.0, high = nyquist;
+  const double fft_bin_width = (double)sample_rate / NF;
+  const double mel_low = 1127.0 * std::log(1.0 + low / 700.0);
+  const double mel_high = 1127.0 * std::log(1.0 + high / 700.0);
+  const double delta = (mel_high - mel_low) / (num_mel_bins + 1);
+  std::vector<int> st(num_mel_bins), ln(num_mel_bins), off(num_mel_bins);
+  std::vector<float> wts;
+  for (int b = 0; b < num_mel_bins; ++b) {
+    const float left = (float)mel_low + (float)b * (float)delta;
+    const float center = (float)mel_low + ((float)b + 1.0f) * (float)delta;
+    const float right = (float)mel_low + ((float)b + 2.0f) * (float)delta;
+    int first = -1, last = -1;
+    std::vector<float> row(num_fft_bins, 0.f);
+    for (int i = 0; i < num_fft_bins; ++i) {
+      const float freq = (float)fft_bin_width * (float)i;
+      const float mel = 1127.0f * std::log(1.0f + freq / 700.0f);
+      const float up = (mel - left) / (center - left);
+      const float down = (right - mel) / (right - center);
+      const float wv = std::fmax(0.f, std::fmin(up, down));
+      row[i] = wv;
+      if (wv > 0.f) { if (first < 0) first = i; last = i; }
+    }
+    if (first < 0) { first = 0; last = 0; }
+    st[b] = first; ln[b] = last - first + 1; off[b] = (int)wts.size();
+    for (int i = first; i <= last; ++i) wts.push_back(row[i]);
+  }
+  auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = d.alloc(bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.ptr, src, bytes, hipMemcpyHostToDevice);
+  };
+  hipError_t e = hipSuccess;
+  if ((e = up(fe->window_h, wh.data(), wh.size() * 4)) != hipSuccess ||
+      (e = up(fe->window_p, wp.data(), wp.size() * 4)) != hipSuccess ||
+      (e = up(fe->twiddle, tw.data(), tw.size() * 4)) != hipSuccess ||
+      (e = up(fe->mel_start, st.data(), st.size() * 4)) != hipSuccess ||
+      (e = up(fe->mel_len, ln.data(), ln.size() * 4)) != hipSuccess ||
+      (e = up(fe->mel_off, off.data(), off.size() * 4)) != hipSuccess ||
+      (e = up(fe->mel_w, wts.data(), wts.size() * 4)) != hipSuccess) {
+    delete fe;
+    set_error("ws_frontend_create: device upload failed: %s", hipGetErrorString(e));
+    return WS_ERR_HIP;
+  }
+  FbankTables& t = fe->tables;
+  t.window_hamming = fe->window_h.as<float>(); t.window_povey = fe->window_p.as<float>();
+  t.twiddle = fe->twiddle.as<float>();
+  t.mel_start = fe->mel_start.as<int>(); t.mel_len = fe->mel_len.as<int>();
+  t.mel_off = fe->mel_off.as<int>(); t.mel_w = fe->mel_w.as<float>();
+  t.frame_len = L; t.frame_shift = fe->frame_shift; t.fft_n = NF; t.num_bins = num_mel_bins;
+  *out = fe;
+  return WS_OK;
+}
+
+void ws_frontend_destroy(ws_frontend* fe) { delete fe; }
+
+int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num_samples,
+             int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
+             ws_stream stream) {
+  if (!fe || !wav || !feats || batch < 0 || (wav_dtype != WS_WAV_INT16 && wav_dtype != WS_WAV_FLOAT32) ||
+      (window_type != WS_WINDOW_HAMMING && window_type != WS_WINDOW_POVEY) ||
+      wav_stride < num_samples) {
+    set_error("ws_fbank: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  const int T = ws_num_frames(num_samples, fe->sample_rate);
+  if (T == 0 || batch == 0) return WS_OK;          // shorter than one frame: empty output
+  hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, num_samples, wav_stride, scale,
+                            window_type, T, feats, st));
+  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st));
+  return WS_OK;
+}
+
+// -------------------------------------------------------------------------------------- engine
+int ws_engine_create(const char* model_name, int feat_dim, int embed_dim, int device_id,
+                     ws_engine** out) {
+  if (!model_name || !out || feat_dim <= 0 || embed_dim <= 0 || (feat_dim & 3)) {
+    set_error("ws_engine_create: invalid argument (feat_dim must be a positive multiple of 4)");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(hipSetDevice(device_id));
+  Model* m = make_ecapa(model_name, feat_dim, embed_dim);
+  if (!m) {
+    set_error("ws_engine_create: unknown model '%s'", model_name);
+    return WS_ERR_UNKNOWN_MODEL;
+  }
+  ws_engine* e = new ws_engine;
+  e->model_name = model_name; e->feat_dim = feat_dim; e->embed_dim = embed_dim;
+  e->device = device_id; e->model = m;
+  *out = e;
+  return WS_OK;
+}
+
+int ws_engine_set_tensor(ws_engine* eng, const char* key, const float* data, int ndim,
+                         const int64_t* shape) {
+  if (!eng || !key || !data || ndim < 0 || ndim > 4 || (ndim && !shape)) {
+    set_error("ws_engine_set_tensor: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (eng->finalized) {
+    set_error("ws_engine_set_tensor: engine already finalized");
+    return WS_ERR_STATE;
+  }
+  if (!eng->model->wants(key)) return 0;     // strict=False: unknown keys are ignored
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  eng->sd[key] = std::move(t);
+  return 1;
+}
+
+int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames) {
+  if (!eng || max_batch <= 0 || max_frames <= 0) {
+    set_error("ws_engine_finalize: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (eng->finalized) { set_error("ws_engine_finalize: already finalized"); return WS_ERR_STATE; }
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  int r = eng->model->finalize(eng->sd, max_batch, max_frames);
+  if (r) return r;
+  eng->sd.clear();
+  eng->finalized = true;
+  return WS_OK;
+}
+
+void ws_engine_destroy(ws_engine* eng) {
+  if (!eng) return;
+  delete eng->model;
+  delete eng;
+}
+
+int ws_engine_embed_dim(const ws_engine* eng) { return eng ? eng->embed_dim : WS_ERR_INVALID_ARG; }
+int ws_engine_feat_dim(const ws_engine* eng) { return eng ? eng->feat_dim : WS_ERR_INVALID_ARG; }
+
+int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, float* emb,
+               ws_stream stream) {
+  if (!eng || !feats || !emb || batch < 0 || num_frames <= 0) {
+    set_error("ws_forward: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_forward: engine not finalized"); return WS_ERR_STATE; }
+  if (batch == 0) return WS_OK;
+  return eng->model->forward(feats, batch, num_frames, emb, (hipStream_t)stream);
+}
+
+int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
+               int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
+               ws_stream stream) {
+  if (!eng || !fe || !wav || !emb || batch < 0) {
+    set_error("ws_extract: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_extract: engine not finalized"); return WS_ERR_STATE; }
+  if (fe->num_bins != eng->feat_dim) {
+    set_error("ws_extract: frontend has %d mel bins, model expects %d", fe->num_bins, eng->feat_dim);
+    return WS_ERR_SHAPE;
+  }
+  const int T = ws_num_frames(num_samples, fe->sample_rate);
+  if (T <= 0) { set_error("ws_extract: utterance shorter than one frame"); return WS_ERR_INVALID_ARG; }
+  if (T > eng->model->max_frames()) {
+    set_error("ws_extract: %d frames exceed the finalized capacity %d", T, eng->model->max_frames());
+    return WS_ERR_CAPACITY;
+  }
+  const int chunk = eng->model->max_batch();
+  const size_t esz = wav_dtype == WS_WAV_INT16 ? 2 : 4;
+  float* fw = eng->model->feats_workspace();
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+    const char* w = reinterpret_cast<const char*>(wav) + (size_t)b0 * wav_stride * esz;
+    int r = ws_fbank(fe, w, wav_dtype, nb, num_samples, wav_stride, scale, window_type, 1, fw, stream);
+    if (r) return r;
+    r = eng->model->forward(fw, nb, T, emb + (size_t)b0 * eng->embed_dim, (hipStream_t)stream);
+    if (r) return r;
+  }
+  return WS_OK;
+}
+
+double ws_engine_flops(const ws_engine* eng, int batch, int num_frames) {
+  return eng ? eng->model->flops(batch, num_frames) : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------- PLDA
+int ws_plda_create(int dim, const double* mu, const double* transform, const double* psi,
+                   const double* offset, int normalize_length, int device_id, ws_plda** out) {
+  if (!out || dim <= 0 || dim > 4096 || !mu || !transform || !psi || !offset) {
+    set_error("ws_plda_create: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(hipSetDevice(device_id));
+  ws_plda* p = new ws_plda;
+  p->dim = dim; p->device = device_id; p->normalize_length = normalize_length ? 1 : 0;
+  auto up = [&](DevBuf& d, const double* src, size_t n) -> hipError_t {
+    hipError_t e = d.alloc(n * sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(d.ptr, src, n * sizeof(double), hipMemcpyHostToDevice);
+  };
+  hipError_t e;
+  if ((e = up(p->mu, mu, dim)) != hipSuccess ||
+      (e = up(p->transform, transform, (size_t)dim * dim)) != hipSuccess ||
+      (e = up(p->psi, psi, dim)) != hipSuccess || (e = up(p->offset, offset, dim)) != hipSuccess ||
+      (e = p->mean_vec.alloc(dim * sizeof(double))) != hipSuccess) {
+    delete p;
+    set_error("ws_plda_create: device upload failed: %s", hipGetErrorString(e));
+    return WS_ERR_HIP;
+  }
+  *out = p;
+  return WS_OK;
+}
+
+void ws_plda_destroy(ws_plda* plda) { delete plda; }
+
+static int plda_prepare(ws_plda* p, const void* emb, int is_f64, const int32_t* groups, int n_out,
+                        const double* mean_vec, int pre_norm, double* out, hipStream_t st) {
+  const double* mv = nullptr;
+  if (mean_vec) {
+    WS_HIP_CHECK(hipMemcpyAsync(p->mean_vec.ptr, mean_vec, p->dim * sizeof(double),
+                                hipMemcpyHostToDevice, st));
+    mv = p->mean_vec.as<double>();
+  }
+  WS_HIP_CHECK(launch_plda_prepare(emb, is_f64, groups, n_out, p->dim, mv,
+                                   p->transform.as<double>(), p->offset.as<double>(), pre_norm,
+                                   p->normalize_length, out, st));
+  return WS_OK;
+}
+
+int ws_plda_prepare_enroll(ws_plda* plda, const float* emb, const int32_t* group_offsets,
+                           int n_groups, const double* mean_vec, double* out, ws_stream stream) {
+  if (!plda || !emb || !group_offsets || !out || n_groups < 0) {
+    set_error("ws_plda_prepare_enroll: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  return plda_prepare(plda, emb, 0, group_offsets, n_groups, mean_vec, plda->normalize_length, out,
+                      (hipStream_t)stream);
+}
+
+int ws_plda_prepare_test(ws_plda* plda, const float* emb, int n, const double* mean_vec,
+                         double* out, ws_stream stream) {
+  if (!plda || !emb || !out || n < 0) {
+    set_error("ws_plda_prepare_test: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  return plda_prepare(plda, emb, 0, nullptr, n, mean_vec, plda->normalize_length, out,
+                      (hipStream_t)stream);
+}
+
+int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_stream stream) {
+  if (!plda || !x || !out || n < 0) {
+    set_error("ws_plda_transform: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  return plda_prepare(plda, x, 1, nullptr, n, nullptr, 0, out, (hipStream_t)stream);
+}
+
+static int plda_terms(ws_plda* p, const double* enroll, const int32_t* n_sessions, int n_enroll,
+                      const double* test, int n_test, hipStream_t st) {
+  const size_t D2 = 2 * (size_t)p->dim;
+  if ((size_t)n_enroll > p->cap_e) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));
+    WS_HIP_CHECK(p->EA.alloc((size_t)n_enroll * D2 * sizeof(double)));
+    WS_HIP_CHECK(p->rowc.alloc((size_t)n_enroll * sizeof(double)));
+    p->cap_e = n_enroll;
+  }
+  if ((size_t)n_test > p->cap_t) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));
+    WS_HIP_CHECK(p->TT.alloc((size_t)n_test * D2 * sizeof(double)));
+    p->cap_t = n_test;
+  }
+  WS_HIP_CHECK(launch_plda_enroll_terms(enroll, n_sessions, n_enroll, p->dim, p->psi.as<double>(),
+                                        p->EA.as<double>(), p->rowc.as<double>(), st));
+  WS_HIP_CHECK(launch_plda_test_terms(test, n_test, p->dim, p->TT.as<double>(), st));
+  return WS_OK;
+}
+
+int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+                       int n_enroll, const double* test, int n_test, double* out,
+                       ws_stream stream) {
+  if (!plda || !enroll || !n_sessions || !test || !out || n_enroll < 0 || n_test < 0) {
+    set_error("ws_plda_llr_matrix: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (n_enroll == 0 || n_test == 0) return WS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int r = plda_terms(plda, enroll, n_sessions, n_enroll, test, n_test, st);
+  if (r) return r;
+  WS_HIP_CHECK(launch_plda_llr_gemm(plda->EA.as<double>(), plda->rowc.as<double>(), n_enroll,
+                                    plda->TT.as<double>(), n_test, 2 * plda->dim, out, st));
+  return WS_OK;
+}
+
+int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+                      int n_enroll, const double* test, int n_test, const int32_t* idx_e,
+                      const int32_t* idx_t, int64_t num_trials, double* out, ws_stream stream) {
+  if (!plda || !enroll || !n_sessions || !test || !out || !idx_e || !idx_t || n_enroll < 0 ||
+      n_test < 0 || num_trials < 0) {
+    set_error("ws_plda_llr_pairs: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (num_trials == 0) return WS_OK;
+  if (n_enroll == 0 || n_test == 0) {
+    set_error("ws_plda_llr_pairs: trials given but an embedding table is empty");
+    return WS_ERR_INVALID_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int r = plda_terms(plda, enroll, n_sessions, n_enroll, test, n_test, st);
+  if (r) return r;
+  WS_HIP_CHECK(launch_plda_llr_pairs(plda->EA.as<double>(), plda->rowc.as<double>(),
+                                     plda->TT.as<double>(), 2 * plda->dim, idx_e, idx_t,
+                                     num_trials, out, st));
+  return WS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Host-side helpers shared by the C-ABI implementation files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wespeaker_amd.h"
+
+namespace wsamd {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define WS_HIP_CHECK(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ::wsamd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                         __LINE__);                                                         \
+      return WS_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+// RAII device allocation
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+// Many small weight tensors packed into one device allocation (16-byte aligned slices).
+struct WeightArena {
+  std::vector<float> host;
+  DevBuf dev;
+  // returns the float offset of the slice
+  size_t add(const float* data, size_t n) {
+    size_t off = (host.size() + 3) & ~size_t(3);
+    host.resize(off + n);
+    if (data) std::copy(data, data + n, host.begin() + off);
+    return off;
+  }
+  size_t add(const std::vector<float>& v) { return add(v.data(), v.size()); }
+  hipError_t upload() {
+    hipError_t e = dev.alloc(host.size() * sizeof(float) + 64);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(dev.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+  const float* at(size_t off) const { return dev.as<float>() + off; }
+};
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+// Model-family interface behind ws_engine (native twin of runtime/core/speaker/speaker_model.h:25-32)
+struct Model {
+  virtual ~Model() {}
+  // returns true if `key` belongs to this architecture
+  virtual bool wants(const std::string& key) const = 0;
+  virtual int finalize(const std::map<std::string, HostTensor>& sd, int max_batch,
+                       int max_frames) = 0;
+  virtual int forward(const float* feats, int batch, int frames, float* emb,
+                      hipStream_t stream) = 0;
+  virtual double flops(int batch, int frames) const = 0;
+  virtual float* feats_workspace() = 0;      // (max_batch, max_frames, feat_dim) floats
+  virtual int max_batch() const = 0;
+  virtual int max_frames() const = 0;
+};
+
+Model* make_ecapa(const std::string& model_name, int feat_dim, int embed_dim);
+
+}  // namespace wsamd
+
+struct ws_engine {
+  std::string model_name;
+  int feat_dim = 0, embed_dim = 0, device = 0;
+  bool finalized = false;
+  std::map<std::string, wsamd::HostTensor> sd;
+  wsamd::Model* model = nullptr;
+};

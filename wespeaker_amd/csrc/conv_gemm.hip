@@ -1,0 +1,245 @@
+// Implicit-GEMM convolution on channels-last activations for gfx950 (MI355X), exact fp32.
+//
+// Replaces the conv1d / conv2d / linear ATen calls of the reference forward
+// (wespeaker/models/ecapa_tdnn.py:85-106 Conv1dReluBn, :58-78 Res2 convs, :196 cat conv;
+//  pooling_layers.py:108-117 ASTP 1x1 convs; resnet.py Conv2d 3x3/1x1; campplus.py TDNN convs).
+//
+// Design (MI355X-first, not a port of any CUDA tiling):
+//  * activations are [pixel][channel] (channels-last), weights [cout][tap*Cin + ci]: both GEMM
+//    operands are K-contiguous, so global loads are 16 B/lane along K and both LDS tiles are
+//    read with ds_read_b128 along K.
+//  * contraction on v_mfma_f32_32x32x2_f32: the exact-f32 matrix instruction (bit-identical to an
+//    fmaf chain, 157 TF peak).  A 64-lane wavefront owns TM x TN tiles of 32x32; lane l holds
+//    row/col (l & 31) and the k-half (l >> 5).  One ds_read_b128 feeds 4 MFMAs per tile (the four
+//    k values of a lane pair with the four of its partner lane: k order inside a tile is permuted,
+//    which a sum does not care about).
+//  * LDS row stride BK+4 floats makes every ds_read_b128 lane group hit 16 distinct 16-B slots
+//    (conflict-free).
+//  * im2col-free: a K-chunk of 4 floats lies inside one filter tap; the tap's pixel offset and the
+//    zero-padding predicate are evaluated per 16-B chunk while staging (masked chunks are read
+//    from a 16-B zero page, so the loads stay unconditional and pipelined).
+//  * register-prefetch double buffering: tile k+1's global loads are issued before tile k's
+//    MFMAs and written to the other LDS buffer after them -> one barrier per K-tile.
+//  * fused epilogue: bias (+ per-utterance bias), residual, ReLU/tanh, BN-after-activation affine,
+//    dual store (Res2 pass-through split), or raw split-K partials.
+#include "kernels.h"
+
+namespace wsamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int S = LDS_STRIDE;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_IT = BM / 32, W_IT = BN / 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---------------- staging roles: thread -> (16-B chunk kc of the K-tile, rows r0 + 32 i)
+  const int kc = tid & 7;
+  const int r0 = tid >> 3;
+  const int HW = p.Hout * p.Wout;
+  int a_pix[A_IT], a_iy[A_IT], a_ix[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + r0 + 32 * i;
+    bool ok = m < p.M;
+    int mm = ok ? m : 0;
+    int img = mm / HW;
+    int rem = mm - img * HW;
+    int oy = rem / p.Wout;
+    int ox = rem - oy * p.Wout;
+    int iy0 = oy * p.stride_h - p.pad_h;
+    int ix0 = ox * p.stride_w - p.pad_w;
+    a_pix[i] = (img * p.Hin + iy0) * p.Win + ix0;
+    a_iy[i] = ok ? iy0 : -(1 << 28);   // forces the bounds predicate false for rows >= M
+    a_ix[i] = ix0;
+  }
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.splitk > 1) {
+    kt_begin = (int)(((long long)nk_total * blockIdx.y) / p.splitk);
+    kt_end = (int)(((long long)nk_total * (blockIdx.y + 1)) / p.splitk);
+  }
+
+  f32x4 ra[A_IT], rw[W_IT];
+  auto load_tile = [&](int kt) {
+    const int kg = kt * BK + kc * 4;
+    const bool kok = kg < p.K;
+    const int tap = kg / p.Cin;
+    const int ci = kg - tap * p.Cin;
+    const int ty = tap / p.kw;
+    const int tx = tap - ty * p.kw;
+    const int dy = ty * p.dil_h, dx = tx * p.dil_w;
+    const int tapoff = dy * p.Win + dx;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+      const bool ok = kok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const long long pix = a_pix[i] + tapoff;
+      const float* src = ok ? p.A + pix * p.lda + p.a_off + ci : p.zeros;
+      ra[i] = *reinterpret_cast<const f32x4*>(src);
+      if (p.A2) {
+        const float* src2 = ok ? p.A2 + pix * p.lda2 + p.a2_off + ci : p.zeros;
+        ra[i] += *reinterpret_cast<const f32x4*>(src2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      const float* src = (n < p.N) ? p.W + (long long)n * p.ldw + kt * BK + kc * 4 : p.zeros;
+      rw[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = lds + buf * (BM + BN) * S;
+    float* Ws = As + BM * S;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * S + kc * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i)
+      *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * i) * S + kc * 4]) = rw[i];
+  };
+
+  // ---------------- compute roles
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool has_next = kt + 1 < kt_end;
+    if (has_next) load_tile(kt + 1);
+    const float* As = lds + buf * (BM + BN) * S + (wm * TM * 32 + li) * S + lh * 4;
+    const float* Ws = lds + buf * (BM + BN) * S + BM * S + (wn * TN * 32 + li) * S + lh * 4;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+        a[im] = *reinterpret_cast<const f32x4*>(&As[im * 32 * S + g * 8]);
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+        b[in] = *reinterpret_cast<const f32x4*>(&Ws[in * 32 * S + g * 8]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+    }
+    if (has_next) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---------------- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = n0 + (wn * TN + in) * 32 + li;
+    const bool nok = n < p.N;
+    float bias = 0.f, ps = 1.f, pb = 0.f;
+    if (p.splitk <= 1 && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.post_scale) { ps = p.post_scale[n]; pb = p.post_shift[n]; }
+    }
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + (wm * TM + im) * 32 + row;
+        if (m >= p.M || !nok) continue;
+        float v = acc[im][in][r];
+        if (p.splitk > 1) {
+          p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        if (p.bias_img) v += p.bias_img[(long long)(m / HW) * p.N + n];
+        if (p.residual) v += p.residual[(long long)m * p.ldr + p.r_off + n];
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_TANH) v = tanhf(v);
+        if (p.post_scale) v = v * ps + pb;
+        p.D[(long long)m * p.ldd + p.d_off + n] = v;
+        if (p.D2 && n >= p.d2_col0) p.D2[(long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
+  const size_t lds_bytes = 2ull * (BM + BN) * LDS_STRIDE * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if (p.N <= 64) return launch_variant<128, 64, 4, 1>(p, stream);
+  return launch_variant<128, 128, 2, 2>(p, stream);
+}
+
+// --------------------------------------------------------------------------- split-K reduce
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * p.N) return;
+  const int m = (int)(idx / p.N), n = (int)(idx - (long long)m * p.N);
+  float v = 0.f;
+  for (int z = 0; z < p.splitk; ++z) v += p.partial[((long long)z * p.M + m) * p.N + n];
+  if (p.bias) v += p.bias[n];
+  if (p.bias_img) v += p.bias_img[(long long)(m / (p.Hout * p.Wout)) * p.N + n];
+  if (p.residual) v += p.residual[(long long)m * p.ldr + p.r_off + n];
+  if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+  else if (p.act == ACT_TANH) v = tanhf(v);
+  if (p.post_scale) v = v * p.post_scale[n] + p.post_shift[n];
+  p.D[(long long)m * p.ldd + p.d_off + n] = v;
+}
+
+hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream) {
+  const long long total = (long long)p.M * p.N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace wsamd

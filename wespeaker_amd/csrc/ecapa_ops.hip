@@ -1,0 +1,242 @@
+// Reduction / element-wise kernels of the ECAPA-TDNN forward on channels-last activations
+// (rows = (utterance, frame), contiguous channels).  All HBM-bound: 16-B loads, lanes run along
+// the contiguous channel axis, reductions over time are per-lane serial sums (unrolled for memory
+// level parallelism) finished through LDS / wavefront shuffles.
+//
+// Reference semantics:
+//   SE_Connect           wespeaker/models/ecapa_tdnn.py:120-126
+//   SE_Res2Block add     wespeaker/models/ecapa_tdnn.py:156-157
+//   ASTP                 wespeaker/models/pooling_layers.py:119-144
+#include "kernels.h"
+
+namespace wsamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------- SE pooling + FCs
+// grid = B, block = 256.  C <= 1024 (C/4 float4 columns <= 256), bottleneck <= 256.
+__global__ __launch_bounds__(256) void se_pool_fc_kernel(const float* __restrict__ y, int ldy, int T,
+                                                         int C, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1,
+                                                         const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, int bott,
+                                                         float* __restrict__ s) {
+  __shared__ __attribute__((aligned(16))) float sm[1024 * 4 + 256];
+  float* part = sm;             // [groups][C]
+  float* hidden = sm + 1024 * 4;  // [bott]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cols4 = C >> 2;                 // float4 columns
+  const int groups = 256 / cols4;           // time groups (>=1)
+  const int col = tid % cols4, grp = tid / cols4;
+  const float* base = y + (long long)b * T * ldy + col * 4;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+  if (grp < groups) {
+    int t = grp;
+    const int step = groups;
+    for (; t + 3 * step < T; t += 4 * step) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)t * ldy);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(t + step) * ldy);
+      f32x4 v2 = *reinterpret_cast<const f32x4*>(base + (long long)(t + 2 * step) * ldy);
+      f32x4 v3 = *reinterpret_cast<const f32x4*>(base + (long long)(t + 3 * step) * ldy);
+      acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+    }
+    for (; t < T; t += step) acc0 += *reinterpret_cast<const f32x4*>(base + (long long)t * ldy);
+    f32x4 a = (acc0 + acc1) + (acc2 + acc3);
+    *reinterpret_cast<f32x4*>(&part[grp * C + col * 4]) = a;
+  }
+  __syncthreads();
+  // mean[c]
+  for (int c = tid; c < C; c += 256) {
+    float v = 0.f;
+    for (int g = 0; g < groups; ++g) v += part[g * C + c];
+    part[c] = v / (float)T;     // group 0 slot reused: safe, each thread touches only column c
+  }
+  __syncthreads();
+  // hidden = relu(W1 mean + b1): one wavefront per output row
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = wave; j < bott; j += 4) {
+    const float* wr = w1 + (long long)j * C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) v += wr[c] * part[c];
+    v = wave_sum(v);
+    if (lane == 0) hidden[j] = fmaxf(v + b1[j], 0.f);
+  }
+  __syncthreads();
+  // s = sigmoid(W2 hidden + b2): thread per output channel (rows of W2 are short: bott floats)
+  for (int c = tid; c < C; c += 256) {
+    const float* wr = w2 + (long long)c * bott;
+    float v = 0.f;
+    for (int j = 0; j < bott; j += 4) {
+      f32x4 w = *reinterpret_cast<const f32x4*>(wr + j);
+      v += w[0] * hidden[j] + w[1] * hidden[j + 1] + w[2] * hidden[j + 2] + w[3] * hidden[j + 3];
+    }
+    v += b2[c];
+    s[(long long)b * C + c] = 1.f / (1.f + expf(-v));
+  }
+}
+
+hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
+                             const float* b1, const float* w2, const float* b2, int bottleneck,
+                             float* s, hipStream_t stream) {
+  if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || 256 % (C >> 2) != 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(se_pool_fc_kernel, dim3(B), dim3(256), 0, stream, y, ldy, T, C, w1, b1, w2,
+                     b2, bottleneck, s);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------- SE scale + block residual
+__global__ __launch_bounds__(256) void se_scale_residual_kernel(
+    const float* __restrict__ x, int ldx, int x_off, const float* __restrict__ y, int ldy,
+    const float* __restrict__ s, float* __restrict__ out, int ldo, int o_off, int T, int C,
+    long long total4) {
+  const int cols4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * 256) {
+    const long long m = i / cols4;
+    const int c = (int)(i - m * cols4) * 4;
+    const int b = (int)(m / T);
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * ldx + x_off + c);
+    f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
+    f32x4 sv = *reinterpret_cast<const f32x4*>(s + (long long)b * C + c);
+    *reinterpret_cast<f32x4*>(out + m * ldo + o_off + c) = xv + yv * sv;
+  }
+}
+
+hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
+                                    const float* s, float* out, int ldo, int o_off, int B, int T,
+                                    int C, hipStream_t stream) {
+  const long long total4 = (long long)B * T * (C >> 2);
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx,
+                     x_off, y, ldy, s, out, ldo, o_off, T, C, total4);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ ASTP global-context statistics
+// grid = (B, C/256), block = 256: thread = 1 channel... channel-parallel, two passes over T
+// (mean, then centred sum of squares: same two-pass form torch.var uses, no E[x^2]-m^2 cancellation).
+__global__ __launch_bounds__(256) void astp_stats_kernel(const float* __restrict__ h, int ldh, int T,
+                                                         int C, float* __restrict__ stats) {
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* base = h + (long long)b * T * ldh + c;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int t = 0;
+  for (; t + 3 < T; t += 4) {
+    s0 += base[(long long)t * ldh];
+    s1 += base[(long long)(t + 1) * ldh];
+    s2 += base[(long long)(t + 2) * ldh];
+    s3 += base[(long long)(t + 3) * ldh];
+  }
+  for (; t < T; ++t) s0 += base[(long long)t * ldh];
+  const float mean = ((s0 + s1) + (s2 + s3)) / (float)T;
+  float q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  t = 0;
+  for (; t + 3 < T; t += 4) {
+    float d0 = base[(long long)t * ldh] - mean, d1 = base[(long long)(t + 1) * ldh] - mean;
+    float d2 = base[(long long)(t + 2) * ldh] - mean, d3 = base[(long long)(t + 3) * ldh] - mean;
+    q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+  }
+  for (; t < T; ++t) { float d = base[(long long)t * ldh] - mean; q0 += d * d; }
+  const float var = ((q0 + q1) + (q2 + q3)) / (float)(T - 1);      // unbiased (torch.var default)
+  stats[(long long)b * 2 * C + c] = mean;
+  stats[(long long)b * 2 * C + C + c] = sqrtf(var + 1e-7f);
+}
+
+// bias_img[b][j] = b1[j] + sum_c W1[j][C + c] * stats[b][c]   (c over the 2C mean|std entries)
+// grid = B, block = 256: wavefront per output row.
+__global__ __launch_bounds__(256) void astp_context_bias_kernel(const float* __restrict__ stats,
+                                                                int C2, const float* __restrict__ w1,
+                                                                int ldw1, int w_off,
+                                                                const float* __restrict__ b1,
+                                                                int bott, float* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* st = stats + (long long)b * C2;
+  for (int j = wave; j < bott; j += 4) {
+    const float* wr = w1 + (long long)j * ldw1 + w_off;
+    float v = 0.f;
+    for (int c = lane * 4; c < C2; c += 256) {
+      f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+      f32x4 x = *reinterpret_cast<const f32x4*>(st + c);
+      v += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
+    }
+    v = wave_sum(v);
+    if (lane == 0) out[(long long)b * bott + j] = v + b1[j];
+  }
+}
+
+hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
+                                    int ldw1, const float* b1, int bottleneck, float* stats,
+                                    float* bias_img, hipStream_t stream) {
+  hipLaunchKernelGGL(astp_stats_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, h, ldh, T,
+                     C, stats);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(astp_context_bias_kernel, dim3(B), dim3(256), 0, stream, stats, 2 * C, w1,
+                     ldw1, C, b1, bottleneck, bias_img);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------- ASTP pooling
+// Per (b, c): alpha = softmax_t(e), mean = sum alpha h, var = sum alpha h^2 - mean^2,
+// std = sqrt(max(var, 1e-7)).  Online softmax, one pass over e and h.
+// grid = (B, C/256), block = 256 (thread = channel; lanes contiguous in c -> coalesced rows).
+__global__ __launch_bounds__(256) void astp_pool_kernel(const float* __restrict__ e, int lde,
+                                                        const float* __restrict__ h, int ldh,
+                                                        int T, int C, float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* ep = e + (long long)b * T * lde + c;
+  const float* hp = h + (long long)b * T * ldh + c;
+  // pass 1: max (keeps exp arguments <= 0 exactly like torch.softmax's max-subtraction)
+  float mx = -INFINITY;
+  int t = 0;
+  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  for (; t + 3 < T; t += 4) {
+    m0 = fmaxf(m0, ep[(long long)t * lde]);
+    m1 = fmaxf(m1, ep[(long long)(t + 1) * lde]);
+    m2 = fmaxf(m2, ep[(long long)(t + 2) * lde]);
+    m3 = fmaxf(m3, ep[(long long)(t + 3) * lde]);
+  }
+  for (; t < T; ++t) m0 = fmaxf(m0, ep[(long long)t * lde]);
+  mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+  // pass 2: sums (e is re-read from L2)
+  float l0 = 0, l1 = 0, a0 = 0, a1 = 0, q0 = 0, q1 = 0;
+  t = 0;
+  for (; t + 1 < T; t += 2) {
+    float w0 = expf(ep[(long long)t * lde] - mx), w1 = expf(ep[(long long)(t + 1) * lde] - mx);
+    float x0 = hp[(long long)t * ldh], x1 = hp[(long long)(t + 1) * ldh];
+    l0 += w0; l1 += w1;
+    a0 += w0 * x0; a1 += w1 * x1;
+    q0 += w0 * x0 * x0; q1 += w1 * x1 * x1;
+  }
+  for (; t < T; ++t) {
+    float w0 = expf(ep[(long long)t * lde] - mx);
+    float x0 = hp[(long long)t * ldh];
+    l0 += w0; a0 += w0 * x0; q0 += w0 * x0 * x0;
+  }
+  const float inv = 1.f / (l0 + l1);
+  const float mean = (a0 + a1) * inv;
+  const float var = (q0 + q1) * inv - mean * mean;
+  pooled[(long long)b * 2 * C + c] = mean;
+  pooled[(long long)b * 2 * C + C + c] = sqrtf(fmaxf(var, 1e-7f));
+}
+
+hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
+                            float* pooled, hipStream_t stream) {
+  hipLaunchKernelGGL(astp_pool_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, e, lde, h,
+                     ldh, T, C, pooled);
+  return hipGetLastError();
+}
+
+}  // namespace wsamd

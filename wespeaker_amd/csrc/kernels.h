@@ -1,0 +1,93 @@
+// Internal launcher interface between the host engine (engine.cpp / plda.cpp) and the gfx950
+// kernels.  Everything here is HIP-only (no torch); all launchers enqueue on `stream` and
+// return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wsamd {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+// Implicit-GEMM convolution / linear layer on channels-last activations:
+//   D[m][n] = epilogue( sum_{tap, ci} A[pix(m, tap)][a_off + ci] * W[n][tap*Cin + ci] )
+// m enumerates output pixels (img, oy, ox) row-major; pix() applies stride/dilation/zero padding.
+// Conv1d over time is the H=1 case (time on the W axis); a Linear layer is 1x1 with Hout=Wout=1.
+struct ConvGemmParams {
+  const float* A;  int lda;  int a_off;       // input rows: lda floats per pixel
+  const float* A2; int lda2; int a2_off;      // optional second input, added element-wise to A
+  const float* W;  int ldw;                   // [N][ldw]; ldw >= taps*Cin, multiple of 32, zero padded
+  float* D;  int ldd;  int d_off;             // output rows
+  float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
+  int M, N, K;                                // M output pixels, N output channels, K = taps*Cin
+  int Cin;
+  int Hin, Win, Hout, Wout;
+  int stride_h, stride_w, kh, kw, dil_h, dil_w, pad_h, pad_w;
+  const float* bias;                          // [N] or null
+  const float* bias_img;                      // [num_images][N] or null (per-utterance bias)
+  const float* residual; int ldr; int r_off;  // optional, added before the activation
+  int act;
+  const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
+  float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
+  const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
+};
+hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
+
+// out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
+hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
+
+// SE_Connect (ecapa_tdnn.py:120-126): s[b][c] = sigmoid(W2 relu(W1 mean_t(y[b,t,:]) + b1) + b2)
+hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
+                             const float* b1, const float* w2, const float* b2, int bottleneck,
+                             float* s, hipStream_t stream);
+// out[m][o_off + c] = x[m][x_off + c] + y[m][c] * s[b][c]      (SE scale + residual)
+hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
+                                    const float* s, float* out, int ldo, int o_off, int B, int T,
+                                    int C, hipStream_t stream);
+// ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
+// over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
+hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
+                                    int ldw1, const float* b1, int bottleneck, float* stats,
+                                    float* bias_img, hipStream_t stream);
+// ASTP pooling (pooling_layers.py:138-144): softmax over T of logits e, weighted mean / std of h
+// -> pooled[b] = [mean(C) | std(C)]
+hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
+                            float* pooled, hipStream_t stream);
+
+// ---- frontend
+struct FbankTables {
+  const float* window_hamming;   // [frame_len]
+  const float* window_povey;     // [frame_len]
+  const float* twiddle;          // [fft_n/2] (cos, sin) pairs for the complex FFT of size fft_n/2 + unpack
+  const int* mel_start;          // [num_bins] first fft bin
+  const int* mel_len;            // [num_bins]
+  const int* mel_off;            // [num_bins] offset into mel_w
+  const float* mel_w;            // packed weights
+  int frame_len, frame_shift, fft_n, num_bins;
+};
+hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
+                        int64_t wav_stride, float scale, int window_type, int T, float* feats,
+                        hipStream_t stream);
+hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream);
+
+// ---- PLDA (float64)
+hipError_t launch_plda_prepare(const void* emb, int emb_is_f64, const int32_t* group_offsets,
+                               int n_out, int dim, const double* mean_vec, const double* transform,
+                               const double* offset, int pre_norm, int post_norm, double* out,
+                               hipStream_t stream);
+// builds the GEMM operands: EA[i] = [g(n_i) * e_i | -0.5 a(n_i)], rowc[i] = K(n_i) - 0.5 sum b e^2
+hipError_t launch_plda_enroll_terms(const double* enroll, const int32_t* n_sessions, int n_enroll,
+                                    int dim, const double* psi, double* EA, double* rowc,
+                                    hipStream_t stream);
+// TT[j] = [t_j | t_j^2]
+hipError_t launch_plda_test_terms(const double* test, int n_test, int dim, double* TT,
+                                  hipStream_t stream);
+// out[i][j] = rowc[i] + sum_k EA[i][k] TT[j][k]   (f64 MFMA)
+hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, int n_enroll,
+                                const double* TT, int n_test, int K, double* out,
+                                hipStream_t stream);
+hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* TT, int K,
+                                 const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials,
+                                 double* out, hipStream_t stream);
+
+}  // namespace wsamd

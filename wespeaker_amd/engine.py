@@ -1,0 +1,176 @@
+"""Host-side wrappers around the native frontend and model engine.
+
+`NativeSpeakerModel` stands where the reference has a torch.nn.Module
+(wespeaker/models/speaker_model.py:31-62 `get_speaker_model(name)(**args)` +
+wespeaker/utils/checkpoint.py:20-85 `load_checkpoint`): it is callable on a (B, T, F) float32
+feature tensor and returns a tuple whose last element is the (B, E) embedding, which is all the
+reference's callers use (`outputs[-1] if isinstance(outputs, tuple) else outputs`,
+cli/speaker.py:119-120,165; bin/extract.py:134).  PyTorch is used only to own device memory and
+streams; every FLOP of the forward runs in the HIP library.
+"""
+import ctypes
+from ctypes import c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+
+WINDOW_TYPES = {"hamming": 0, "povey": 1}
+
+SUPPORTED_MODELS = ("ECAPA_TDNN_c512", "ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c1024",
+                    "ECAPA_TDNN_GLOB_c1024")
+
+DEFAULT_EMBED_DIM = {"ECAPA": 192, "ResNe": 256, "CAMPP": 512}
+
+
+def default_device() -> torch.device:
+    import os
+    _lib.require_gpu()
+    idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    return torch.device("cuda", idx)
+
+
+class Frontend:
+    """Kaldi fbank (+CMN) on the GPU: replaces torchaudio.compliance.kaldi.fbank as called at
+    cli/speaker.py:92-99 and dataset/processor.py:516-525."""
+
+    def __init__(self, sample_rate=16000, num_mel_bins=80, device=None):
+        self.device = torch.device(device) if device is not None else default_device()
+        self.sample_rate = sample_rate
+        self.num_mel_bins = num_mel_bins
+        h = c_void_p()
+        _lib.check(_lib.lib().ws_frontend_create(sample_rate, num_mel_bins, self.device.index or 0,
+                                                 ctypes.byref(h)), "ws_frontend_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().ws_frontend_destroy(h)
+            self._h = None
+
+    def num_frames(self, num_samples: int) -> int:
+        return _lib.lib().ws_num_frames(int(num_samples), self.sample_rate)
+
+    def fbank(self, wav: torch.Tensor, window_type="hamming", cmn=True, scale=1.0) -> torch.Tensor:
+        """wav: (B, N) int16 or float32 (int16-range unless `scale` says otherwise), any device
+        -> (B, T, num_mel_bins) float32 on the GPU."""
+        if window_type not in WINDOW_TYPES:
+            raise ValueError("Invalid window type " + str(window_type))
+        if wav.dim() == 1:
+            wav = wav.unsqueeze(0)
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device).contiguous()
+        B, N = wav.shape
+        T = self.num_frames(N)
+        feats = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=self.device)
+        if B == 0 or T == 0:
+            return feats
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_fbank(self._h, _lib.ptr(wav), dt, B, N, wav.stride(0),
+                                           float(scale), WINDOW_TYPES[window_type], int(bool(cmn)),
+                                           _lib.ptr(feats), _lib.current_stream_ptr(self.device)),
+                       "ws_fbank")
+        return feats
+
+
+class NativeSpeakerModel:
+    """The engine behind `Speaker.model`."""
+
+    def __init__(self, model_name: str, state_dict, feat_dim=80, embed_dim=None, device=None,
+                 max_batch=64, max_frames=400, **unused_model_args):
+        self.device = torch.device(device) if device is not None else default_device()
+        self.model_name = model_name
+        self.feat_dim = int(feat_dim)
+        self.embed_dim = int(embed_dim or DEFAULT_EMBED_DIM.get(model_name[:5], 256))
+        self.frontend_type = "fbank"
+        self.max_batch = int(max_batch)
+        self.max_frames = int(max_frames)
+        L = _lib.lib()
+        h = c_void_p()
+        _lib.check(L.ws_engine_create(model_name.encode(), self.feat_dim, self.embed_dim,
+                                      self.device.index or 0, ctypes.byref(h)), "ws_engine_create")
+        self._h = h
+        self.ignored_keys = []
+        for key, val in state_dict.items():
+            arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+            if arr.dtype.kind != "f":
+                continue                       # num_batches_tracked etc.
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (c_int64 * max(1, arr.ndim))(*arr.shape)
+            used = _lib.check(L.ws_engine_set_tensor(h, key.encode(), _lib.ptr(arr), arr.ndim, shape),
+                              "ws_engine_set_tensor(%s)" % key)
+            if not used:
+                self.ignored_keys.append(key)
+        _lib.check(L.ws_engine_finalize(h, self.max_batch, self.max_frames), "ws_engine_finalize")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().ws_engine_destroy(h)
+            self._h = None
+
+    # nn.Module look-alikes so reference-style call sites keep working
+    def eval(self):
+        return self
+
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type == "cuda" and (dev.index is None or dev.index == self.device.index):
+            return self
+        if dev.type == "cpu":
+            return self          # outputs are returned wherever the caller asks; compute stays on the GPU
+        raise _lib.NativeError("engine was created on %s; create a new one for %s" % (self.device, dev))
+
+    def flops(self, batch, frames) -> float:
+        return float(_lib.lib().ws_engine_flops(self._h, int(batch), int(frames)))
+
+    def _ensure_capacity(self, frames):
+        if frames > self.max_frames:
+            raise _lib.NativeError("utterance has %d frames, engine capacity is %d (pass max_frames)"
+                                   % (frames, self.max_frames))
+
+    def embed(self, feats: torch.Tensor) -> torch.Tensor:
+        """(B, T, F) float32 -> (B, E) float32 on the GPU."""
+        if feats.dim() != 3 or feats.shape[2] != self.feat_dim:
+            raise ValueError("expected (B, T, %d) features, got %s" % (self.feat_dim, tuple(feats.shape)))
+        feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T, _ = feats.shape
+        self._ensure_capacity(T)
+        emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if B:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_forward(self._h, _lib.ptr(feats), B, T, _lib.ptr(emb),
+                                                 _lib.current_stream_ptr(self.device)), "ws_forward")
+        return emb
+
+    def __call__(self, feats: torch.Tensor):
+        # ECAPA returns (out4, embed) in the reference (ecapa_tdnn.py:227-234); callers take [-1].
+        # The frame-level tensor is not materialised on this path.
+        return None, self.embed(feats)
+
+    def extract(self, frontend: Frontend, wav: torch.Tensor, window_type="hamming", scale=1.0):
+        """Fused wav -> fbank -> CMN -> forward (ws_extract).  wav (B, N) int16/float32."""
+        if wav.dim() == 1:
+            wav = wav.unsqueeze(0)
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device).contiguous()
+        B, N = wav.shape
+        self._ensure_capacity(frontend.num_frames(N))
+        emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if B:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_extract(self._h, frontend._h, _lib.ptr(wav), dt, B, N,
+                                                 wav.stride(0), float(scale),
+                                                 WINDOW_TYPES[window_type], _lib.ptr(emb),
+                                                 _lib.current_stream_ptr(self.device)), "ws_extract")
+        return emb

@@ -1,0 +1,80 @@
+"""Multi-GPU extraction: one process per GPU, utterances sharded as independent contiguous
+blocks, ONE collective (all_gather over RCCL/xGMI) to collect the embeddings.
+
+The reference shards through the filesystem: tools/extract_embedding.sh:39-67 does
+`split -l ceil(N/nj)` into contiguous chunks, job k -> GPU k % num_gpus, then `cat xvector_*.scp`.
+Here rank r of G takes utterances [r*ceil(N/G), (r+1)*ceil(N/G)) -- the same contiguous rule, so
+concatenating the shards in rank order reproduces the list order -- and the `cat` becomes a single
+`all_gather_into_tensor` of equal-size padded (ceil(N/G), E) float32 blocks (payload: a few MB,
+latency-bound on xGMI; no other collective touches the data path).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world_size: int):
+    """Contiguous shard [lo, hi) of rank `rank` (last shards may be short or empty)."""
+    per = (n_total + world_size - 1) // world_size if world_size > 0 else n_total
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+def shard_size(n_total: int, world_size: int) -> int:
+    return (n_total + world_size - 1) // world_size
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).
+    backend 'nccl' is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Every rank passes its (n_local, E) shard (n_local = len of shard_range); every rank gets the
+    full (n_total, E) tensor in list order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local[:n_total]
+    world = dist.get_world_size(group)
+    per = shard_size(n_total, world)
+    width = local.shape[1:]
+    padded = torch.zeros((per,) + tuple(width), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return out[:n_total]
+
+
+def extract_sharded(extract_fn, wavs: torch.Tensor, batch_size: int = 256, group=None):
+    """wavs: (N, samples) on every rank (or at least this rank's shard valid).  extract_fn maps a
+    (b, samples) block to (b, E) embeddings on this rank's GPU.  Returns (N, E) on every rank."""
+    n = wavs.shape[0]
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_range(n, rank, world)
+    outs = []
+    for b0 in range(lo, hi, batch_size):
+        outs.append(extract_fn(wavs[b0:min(hi, b0 + batch_size)]))
+    if outs:
+        local = torch.cat(outs, 0)
+    else:
+        probe = extract_fn(wavs[:1])
+        local = probe[:0]
+    return gather_rows(local, n, group)

@@ -1,0 +1,276 @@
+"""Two-covariance PLDA scoring on the MI355X behind the reference's interface.
+
+Mirrors `wespeaker/utils/plda/two_cov_plda.py`:
+    TwoCovPLDA.load_model(path, from_kaldi=False)          :341-363
+    .transform_embedding(x) / .log_likelihood_ratio(e, t, n)   :156-184
+    .eval_sv(enroll_scp, enroll_utt2spk, test_scp, trials, score_file,
+             multisession_avg=True, indomain_scp=None)     :186-256
+plus the matrix / pair APIs and the new in-memory entry point `score_plda(...)` (semantics of
+`eval_sv`; the reference only has it as bin/eval_plda.py + local/score_plda.sh).
+All arithmetic runs in float64 in the HIP library (the reference computes in numpy float64);
+numpy/torch are used here only for plumbing (name -> row index maps, device buffers).
+EM training / adaptation (two_cov_plda.py:106-154,258-309) are not on this path.
+"""
+import ctypes
+import struct
+from collections import OrderedDict
+from ctypes import c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import default_device
+from .kaldi_io import read_vec_scp
+
+
+def _f64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+class TwoCovPLDA:
+
+    def __init__(self, mu=None, transform=None, psi=None, offset=None, normalize_length=False,
+                 subtract_train_set_mean=False, embed_dim=256, device=None):
+        self.normalize_length = bool(normalize_length)
+        self.subtract_train_set_mean = bool(subtract_train_set_mean)
+        self.dim = int(embed_dim if mu is None else np.asarray(mu).shape[0])
+        self.mu = _f64(np.zeros(self.dim) if mu is None else mu)
+        self.transform = _f64(np.zeros((self.dim, self.dim)) if transform is None else transform)
+        self.psi = _f64(np.zeros(self.dim) if psi is None else psi)
+        self.offset = _f64(-self.transform @ self.mu if offset is None else offset)
+        self._device = device
+        self._h = None
+
+    # ------------------------------------------------------------------------------ native handle
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = default_device()
+        return torch.device(self._device)
+
+    def _handle(self):
+        if self._h is None:
+            _lib.require_gpu()
+            h = c_void_p()
+            _lib.check(_lib.lib().ws_plda_create(
+                self.dim, _lib.ptr(self.mu), _lib.ptr(self.transform), _lib.ptr(self.psi),
+                _lib.ptr(self.offset), int(self.normalize_length), self.device.index or 0,
+                ctypes.byref(h)), "ws_plda_create")
+            self._h = h
+        return self._h
+
+    def _invalidate(self):
+        if self._h:
+            _lib.lib().ws_plda_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._invalidate()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------- I/O
+    @staticmethod
+    def load_model(model_name, from_kaldi=False, device=None):
+        if from_kaldi:
+            mu, tr, psi = read_kaldi_plda(model_name)
+            return TwoCovPLDA(mu, tr, psi, -1.0 * np.matmul(tr, mu), device=device)
+        if str(model_name).endswith(".npz"):
+            with np.load(model_name) as f:
+                return TwoCovPLDA(f["mu"], f["transform"], f["psi"], f["offset"],
+                                  bool(f["normalize_length"]), bool(f["subtract_train_set_mean"]),
+                                  device=device)
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError("reading the reference's HDF5 PLDA models needs h5py (not installed); "
+                              "use .npz or from_kaldi=True") from e
+        with h5py.File(model_name, "r") as f:
+            return TwoCovPLDA(f.get("mu")[()], f.get("transform")[()], f.get("psi")[()],
+                              f.get("offset")[()], bool(f.get("normalize_length")[()]),
+                              bool(f.get("subtract_train_set_mean")[()]), device=device)
+
+    def save_model(self, output_file_name):
+        np.savez(output_file_name, mu=self.mu, transform=self.transform, psi=self.psi,
+                 offset=self.offset, normalize_length=int(self.normalize_length),
+                 subtract_train_set_mean=int(self.subtract_train_set_mean))
+
+    # ------------------------------------------------------------------------- device primitives
+    def _dev(self, x, dtype):
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def prepare_test(self, emb, mean_vec=None) -> torch.Tensor:
+        """(N, D) float32 embeddings -> (N, D) float64 transformed (eval_sv :237-244)."""
+        emb = self._dev(emb, torch.float32)
+        n = emb.shape[0]
+        out = torch.empty((n, self.dim), dtype=torch.float64, device=self.device)
+        mv = _f64(mean_vec) if mean_vec is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_plda_prepare_test(
+                self._handle(), _lib.ptr(emb), n, _lib.ptr(mv) if mv is not None else None,
+                _lib.ptr(out), _lib.current_stream_ptr(self.device)), "ws_plda_prepare_test")
+        return out
+
+    def prepare_enroll(self, emb, group_offsets, mean_vec=None) -> torch.Tensor:
+        """Rows of emb grouped contiguously per enrollment model (eval_sv :216-235)."""
+        emb = self._dev(emb, torch.float32)
+        offs = self._dev(np.asarray(group_offsets, dtype=np.int32), torch.int32)
+        g = offs.shape[0] - 1
+        out = torch.empty((g, self.dim), dtype=torch.float64, device=self.device)
+        mv = _f64(mean_vec) if mean_vec is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_plda_prepare_enroll(
+                self._handle(), _lib.ptr(emb), _lib.ptr(offs), g,
+                _lib.ptr(mv) if mv is not None else None, _lib.ptr(out),
+                _lib.current_stream_ptr(self.device)), "ws_plda_prepare_enroll")
+        return out
+
+    def llr_matrix(self, enroll_t, n_sessions, test_t) -> torch.Tensor:
+        """(Ne, D), (Ne,), (Nt, D) transformed float64 -> (Ne, Nt) float64 LLRs on the GPU."""
+        e = self._dev(enroll_t, torch.float64)
+        t = self._dev(test_t, torch.float64)
+        n = self._dev(np.broadcast_to(np.asarray(n_sessions, dtype=np.int32), (e.shape[0],)).copy()
+                      if not isinstance(n_sessions, torch.Tensor) else n_sessions, torch.int32)
+        out = torch.empty((e.shape[0], t.shape[0]), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_plda_llr_matrix(
+                self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
+                _lib.ptr(out), _lib.current_stream_ptr(self.device)), "ws_plda_llr_matrix")
+        return out
+
+    def llr_pairs(self, enroll_t, n_sessions, test_t, idx_e, idx_t) -> torch.Tensor:
+        e = self._dev(enroll_t, torch.float64)
+        t = self._dev(test_t, torch.float64)
+        n = self._dev(np.broadcast_to(np.asarray(n_sessions, dtype=np.int32), (e.shape[0],)).copy()
+                      if not isinstance(n_sessions, torch.Tensor) else n_sessions, torch.int32)
+        ie = self._dev(idx_e, torch.int32)
+        it = self._dev(idx_t, torch.int32)
+        if ie.shape != it.shape:
+            raise ValueError("idx_e and idx_t differ in length")
+        out = torch.empty((ie.shape[0],), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_plda_llr_pairs(
+                self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
+                _lib.ptr(ie), _lib.ptr(it), ie.shape[0], _lib.ptr(out),
+                _lib.current_stream_ptr(self.device)), "ws_plda_llr_pairs")
+        return out
+
+    # ---------------------------------------------------------- reference per-vector methods
+    def transform(self, x) -> torch.Tensor:
+        """(N, D) float64 -> (N, D) float64: `transform_embedding` applied row-wise on the GPU."""
+        x = self._dev(x, torch.float64)
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ws_plda_transform(self._handle(), _lib.ptr(x), x.shape[0],
+                                                    _lib.ptr(out),
+                                                    _lib.current_stream_ptr(self.device)),
+                       "ws_plda_transform")
+        return out
+
+    def transform_embedding(self, embedding):
+        """(D,) -> (D,) float64 numpy (two_cov_plda.py:156-163)."""
+        x = np.asarray(embedding, dtype=np.float64)[None, :]
+        return self.transform(x).cpu().numpy()[0]
+
+    def log_likelihood_ratio(self, transformed_train_embedding, transformed_test_embedding, n):
+        out = self.llr_matrix(np.asarray(transformed_train_embedding, dtype=np.float64)[None, :],
+                              [int(n)],
+                              np.asarray(transformed_test_embedding, dtype=np.float64)[None, :])
+        return float(out.cpu().numpy()[0, 0])
+
+    # --------------------------------------------------------------------------------- eval_sv
+    def eval_sv(self, enroll_scp, enroll_utt2spk, test_scp, trials, score_file,
+                multisession_avg=True, indomain_scp=None):
+        enroll_vecs = read_vec_scp(enroll_scp)
+        labels = {}
+        with open(enroll_utt2spk, "r") as fin:
+            for line in fin:
+                tokens = line.strip().split()
+                labels[tokens[0]] = tokens[1]
+        enroll_dict = OrderedDict()
+        for key, vec in enroll_vecs.items():
+            if key in labels:
+                enroll_dict.setdefault(labels[key], []).append(vec)
+            else:
+                print("WARNING: {} not in utt2spk ({}), skipping it.".format(key, enroll_utt2spk))
+        test_dict = read_vec_scp(test_scp)
+        mean_vec = None
+        if indomain_scp is not None:
+            mean_vec = np.vstack(list(read_vec_scp(indomain_scp).values())).mean(0)
+        trial_list = []
+        with open(trials, "r") as read_trials:
+            for line in read_trials:
+                tokens = line.strip().split()
+                if tokens:
+                    trial_list.append(tokens)
+        scores = score_plda(self, enroll_dict, test_dict, [(t[0], t[1]) for t in trial_list],
+                            multisession_avg=multisession_avg, indomain_mean=mean_vec)
+        with open(score_file, "w") as write_score:
+            for segs, score in zip(trial_list, scores):
+                write_score.write("{} {} {:.5f} {}\n".format(segs[0], segs[1], score,
+                                                             segs[2] if len(segs) > 2 else ""))
+
+
+def score_plda(plda: TwoCovPLDA, enroll_embeddings, test_embeddings, trials,
+               multisession_avg=True, indomain_mean=None, return_tensor=False):
+    """In-memory `eval_sv` (two_cov_plda.py:186-256).
+
+    enroll_embeddings: dict model_id -> list/array of (D,) utterance embeddings
+    test_embeddings:   dict utt_id -> (D,) embedding
+    trials:            sequence of (model_id, utt_id[, ...])
+    Returns the LLR of every trial, in order (numpy float64, or a GPU tensor)."""
+    e_names = list(enroll_embeddings.keys())
+    rows, offs, counts = [], [0], []
+    for k in e_names:
+        v = np.vstack(enroll_embeddings[k]).astype(np.float32)
+        rows.append(v)
+        offs.append(offs[-1] + v.shape[0])
+        counts.append(1 if multisession_avg else v.shape[0])
+    t_names = list(test_embeddings.keys())
+    e_index = {k: i for i, k in enumerate(e_names)}
+    t_index = {k: i for i, k in enumerate(t_names)}
+    idx_e = np.fromiter((e_index[t[0]] for t in trials), dtype=np.int32, count=len(trials))
+    idx_t = np.fromiter((t_index[t[1]] for t in trials), dtype=np.int32, count=len(trials))
+    if not e_names or not t_names:
+        if len(trials):
+            raise KeyError("trials reference embeddings but a table is empty")
+        return np.zeros(0, dtype=np.float64)
+    enroll_t = plda.prepare_enroll(np.vstack(rows), offs, indomain_mean)
+    test_t = plda.prepare_test(np.vstack([np.asarray(test_embeddings[k], dtype=np.float32)
+                                          for k in t_names]), indomain_mean)
+    out = plda.llr_pairs(enroll_t, np.asarray(counts, dtype=np.int32), test_t, idx_e, idx_t)
+    return out if return_tensor else out.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------- Kaldi <Plda>
+def read_kaldi_plda(path):
+    """Binary Kaldi `<Plda>` (mean vector, transform matrix, psi vector; float or double) as read
+    by utils/plda/kaldi_utils.py:24-55."""
+    with open(path, "rb") as fd:
+        if fd.read(2) != b"\0B":
+            raise NotImplementedError("text-format Kaldi PLDA is not supported; convert to binary")
+        if fd.read(7) != b"<Plda> ":
+            raise ValueError("not a Kaldi <Plda> file: " + str(path))
+
+        def vec():
+            tag = fd.read(3)
+            size = {b"FV ": 4, b"DV ": 8}[tag]
+            assert fd.read(1) == b"\x04"
+            n = struct.unpack("<i", fd.read(4))[0]
+            return np.frombuffer(fd.read(n * size), dtype="<f4" if size == 4 else "<f8").astype(np.float64)
+
+        def mat():
+            tag = fd.read(3)
+            size = {b"FM ": 4, b"DM ": 8}[tag]
+            assert fd.read(1) == b"\x04"
+            r = struct.unpack("<i", fd.read(4))[0]
+            assert fd.read(1) == b"\x04"
+            c = struct.unpack("<i", fd.read(4))[0]
+            return np.frombuffer(fd.read(r * c * size),
+                                 dtype="<f4" if size == 4 else "<f8").astype(np.float64).reshape(r, c)
+
+        mu, tr, psi = vec(), mat(), vec()
+    return mu, tr, psi

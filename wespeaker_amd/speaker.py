@@ -1,0 +1,232 @@
+"""Drop-in for the reference's Python API surface on the extraction path:
+
+    wespeaker.load_model(dir) -> Speaker            (wespeaker/cli/speaker.py:300-301)
+    wespeaker.load_model_pt(dir) -> model           (:306-335)
+    Speaker.extract_embedding / _from_pcm / _list / _from_feats, setters, cosine helpers (:60-211)
+
+Same names, argument meaning, return types and error behaviour; the arithmetic (fbank, CMN, model
+forward) runs in the HIP library on an MI355X.  Out-of-scope methods (VAD, diarization, model-hub
+download -- SURVEY.md section 2 rows 1/17) raise NotImplementedError instead of silently doing
+something else.
+"""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib
+from .audio import load_wav
+from .engine import Frontend, NativeSpeakerModel, default_device
+
+
+def _load_state_dict(path: str):
+    """utils/checkpoint.py:20-33: torch.load, unwrap {'state_dict': ...}."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(ckpt, dict) and "state_dict" in ckpt:
+        ckpt = ckpt["state_dict"]
+    return ckpt
+
+
+def load_model_pt(model_name_or_path: str, device=None, max_batch=64, max_frames=400):
+    """`config.yaml` + `avg_model.pt` -> native model (cli/speaker.py:306-335).  Raises
+    FileNotFoundError exactly like the reference when either file is missing (:312-315)."""
+    model_dir = model_name_or_path
+    for file in ("config.yaml", "avg_model.pt"):
+        if not os.path.exists(os.path.join(model_dir, file)):
+            raise FileNotFoundError(f"{file} not found in {model_dir}")
+    with open(os.path.join(model_dir, "config.yaml"), "r") as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    frontend_type = "fbank"
+    if "dataset_args" in config and "frontend" in config["dataset_args"]:
+        frontend_type = config["dataset_args"]["frontend"]
+    if frontend_type != "fbank":
+        raise NotImplementedError("only the 'fbank' frontend is on the MI355X hot path "
+                                  "(got %r; SSL frontends are out of scope)" % frontend_type)
+    model_args = dict(config.get("model_args") or {})
+    pooling = model_args.pop("pooling_func", None)
+    if config["model"].startswith("ECAPA") and pooling not in (None, "ASTP"):
+        raise NotImplementedError("ECAPA-TDNN with pooling_func=%r (only ASTP)" % pooling)
+    sd = _load_state_dict(os.path.join(model_dir, "avg_model.pt"))
+    if model_args.pop("emb_bn", False) and "bn2.running_mean" not in sd:
+        raise KeyError("emb_bn=True but bn2.* is missing from the checkpoint")
+    model = NativeSpeakerModel(config["model"], sd, device=device, max_batch=max_batch,
+                               max_frames=max_frames, **model_args)
+    model.frontend_type = frontend_type
+    model.config = config
+    return model
+
+
+class Speaker:
+
+    def __init__(self, model_dir: str, device=None, max_batch=64, max_frames=400):
+        _lib.require_gpu()
+        self.device = torch.device(device) if device is not None else default_device()
+        self.model = load_model_pt(model_dir, device=self.device, max_batch=max_batch,
+                                   max_frames=max_frames)
+        self.vad = None
+        self.table = {}
+        self.resample_rate = 16000
+        self.apply_vad = False
+        self.output_device = torch.device("cpu")
+        self.wavform_norm = False
+        self.window_type = "hamming"
+        self._frontends = {}
+        # diarization params kept for API compatibility
+        self.diar_min_duration = 0.255
+        self.diar_window_secs = 1.5
+        self.diar_period_secs = 0.75
+        self.diar_frame_shift = 10
+        self.diar_batch_size = 32
+        self.diar_subseg_cmn = True
+
+    # ------------------------------------------------------------------ setters (speaker.py:60-88)
+    def set_wavform_norm(self, wavform_norm: bool):
+        self.wavform_norm = wavform_norm
+
+    def set_window_type(self, window_type: str):
+        self.window_type = window_type
+
+    def set_resample_rate(self, resample_rate: int):
+        self.resample_rate = resample_rate
+
+    def set_vad(self, apply_vad: bool):
+        if apply_vad:
+            raise NotImplementedError("silero VAD is outside the MI355X hot path (SURVEY.md s.2 row 1)")
+        self.apply_vad = False
+
+    def set_device(self, device: str):
+        """The engine always computes on its MI355X; 'cpu' is accepted and only means "hand results
+        back on the CPU" (what extract_embedding does anyway, speaker.py:166)."""
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            idx = self.device.index if dev.index is None else dev.index
+            if idx != self.device.index:
+                raise _lib.NativeError("Speaker was built on %s; build a new one for cuda:%d"
+                                       % (self.device, idx))
+        self.model = self.model.to(dev)
+
+    def set_diarization_params(self, min_duration=0.255, window_secs=1.5, period_secs=0.75,
+                               frame_shift=10, batch_size=32, subseg_cmn=True):
+        self.diar_min_duration = min_duration
+        self.diar_window_secs = window_secs
+        self.diar_period_secs = period_secs
+        self.diar_frame_shift = frame_shift
+        self.diar_batch_size = batch_size
+        self.diar_subseg_cmn = subseg_cmn
+
+    # ------------------------------------------------------------------------------- features
+    def _frontend(self, sample_rate):
+        fe = self._frontends.get(sample_rate)
+        if fe is None:
+            fe = Frontend(sample_rate, self.model.feat_dim, device=self.device)
+            self._frontends[sample_rate] = fe
+        return fe
+
+    def compute_features(self, wavform, sample_rate=16000, cmn=True):
+        """(C, N) waveform -> (1, T, F) features on the GPU (speaker.py:90-106; channel 0)."""
+        wav = wavform[0:1] if wavform.dim() == 2 else wavform.unsqueeze(0)
+        return self._frontend(sample_rate).fbank(wav, window_type=self.window_type, cmn=cmn)
+
+    def extract_embedding_from_feats(self, fbanks, batch_size, subseg_cmn):
+        """list of (T, F) arrays -> (N, E) numpy (speaker.py:108-123)."""
+        arr = np.stack(fbanks)
+        if subseg_cmn:
+            arr = arr - np.mean(arr, axis=1, keepdims=True)
+        arr_t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+        out = []
+        for i in range(0, arr_t.shape[0], batch_size):
+            emb = self.model(arr_t[i:i + batch_size])
+            emb = emb[-1] if isinstance(emb, tuple) else emb
+            out.append(emb.detach().cpu().numpy())
+        return np.vstack(out)
+
+    # ------------------------------------------------------------------------------ extraction
+    def extract_embedding(self, audio_path: str):
+        pcm, sample_rate = load_wav(audio_path, normalize=self.wavform_norm)
+        return self.extract_embedding_from_pcm(pcm, sample_rate)
+
+    def extract_embedding_from_pcm(self, pcm: torch.Tensor, sample_rate: int):
+        if self.apply_vad:
+            raise NotImplementedError("VAD is outside the MI355X hot path")
+        if sample_rate != self.resample_rate:
+            raise NotImplementedError("resampling (%d -> %d Hz) is not on the MI355X hot path yet"
+                                      % (sample_rate, self.resample_rate))
+        wav = pcm[0:1] if pcm.dim() == 2 else pcm.unsqueeze(0)
+        fe = self._frontend(self.resample_rate)
+        emb = self.model.extract(fe, wav, window_type=self.window_type)
+        return emb[0].to(torch.device("cpu"))
+
+    def extract_embedding_batch(self, wavs: torch.Tensor, sample_rate: int = 16000):
+        """(B, N) equal-length utterances -> (B, E) on the GPU (the batched form of
+        extract_embedding_from_pcm; results are identical to B single calls)."""
+        if sample_rate != self.resample_rate:
+            raise NotImplementedError("resampling is not on the MI355X hot path yet")
+        return self.model.extract(self._frontend(self.resample_rate), wavs,
+                                  window_type=self.window_type)
+
+    def extract_embedding_list(self, scp_path: str):
+        """scp of `name wav_path` lines -> (names, [np.ndarray(E)]) (speaker.py:169-178).
+        Utterances are independent, so equal-length ones are batched; the order of the output
+        follows the scp like the reference's batch-1 loop."""
+        names, wavs = [], []
+        with open(scp_path, "r") as read_scp:
+            for line in read_scp:
+                name, wav_path = line.strip().split()
+                names.append(name)
+                pcm, sr = load_wav(wav_path, normalize=self.wavform_norm)
+                if sr != self.resample_rate:
+                    raise NotImplementedError("resampling is not on the MI355X hot path yet")
+                wavs.append(pcm[0])
+        embeddings = [None] * len(names)
+        by_len = {}
+        for i, w in enumerate(wavs):
+            by_len.setdefault((w.shape[0], w.dtype), []).append(i)
+        fe = self._frontend(self.resample_rate)
+        for (_, _), idxs in by_len.items():
+            batch = torch.stack([wavs[i] for i in idxs])
+            emb = self.model.extract(fe, batch, window_type=self.window_type).cpu().numpy()
+            for k, i in enumerate(idxs):
+                embeddings[i] = emb[k]
+        return names, embeddings
+
+    # ------------------------------------------------------------------- similarity (:180-211)
+    def compute_similarity(self, audio_path1: str, audio_path2: str) -> float:
+        e1 = self.extract_embedding(audio_path1)
+        e2 = self.extract_embedding(audio_path2)
+        if e1 is None or e2 is None:
+            return 0.0
+        return self.cosine_similarity(e1, e2)
+
+    def cosine_similarity(self, e1, e2):
+        cosine_score = torch.dot(e1, e2) / (torch.norm(e1) * torch.norm(e2))
+        return (cosine_score.item() + 1.0) / 2      # [-1, 1] => [0, 1]  (speaker.py:188-191)
+
+    def register(self, name: str, audio_path: str):
+        if name in self.table:
+            print("Speaker {} already registered, ignore".format(name))
+        else:
+            self.table[name] = self.extract_embedding(audio_path)
+
+    def recognize(self, audio_path: str):
+        q = self.extract_embedding(audio_path)
+        best_score, best_name = 0.0, ""
+        for name, e in self.table.items():
+            score = self.cosine_similarity(q, e)
+            if best_score < score:
+                best_score, best_name = score, name
+        return {"name": best_name, "confidence": best_score}
+
+    def diarize(self, audio_path: str, utt: str = "unk"):
+        raise NotImplementedError("diarization is outside the MI355X hot path (SURVEY.md s.2 row 17)")
+
+    def diarize_list(self, scp_path: str):
+        raise NotImplementedError("diarization is outside the MI355X hot path")
+
+
+def load_model(model_name_or_path: str, **kw) -> Speaker:
+    """wespeaker.load_model: local model directory only (no network here for the model hub)."""
+    if not os.path.isdir(model_name_or_path):
+        raise FileNotFoundError("model directory %r not found (hub download is not available)"
+                                % model_name_or_path)
+    return Speaker(model_name_or_path, **kw)

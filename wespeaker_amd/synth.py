@@ -1,0 +1,180 @@
+"""Seeded synthetic inputs: wavs, model weights, PLDA parameters, trial lists.
+
+There is no network (no VoxCeleb, no pretrained checkpoints), so every test,
+fixture and benchmark in this repo runs on the generators below.  They follow
+SURVEY.md section 8(d).  Everything is driven by numpy's PCG64 so the same seed
+gives the same bytes on every machine (the GPU box cannot read fixtures that
+are too large to commit, e.g. 6 M-parameter weight sets).
+
+State-dict key names/shapes are the reference's parameter names
+(wespeaker/models/ecapa_tdnn.py:160-206, pooling_layers.py:97-117,
+resnet.py:110-169, campplus.py:333-407) because the weight ingestion path
+(`load_model` -> `avg_model.pt`) is keyed by them.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+SAMPLE_RATE = 16000
+
+
+# --------------------------------------------------------------------------- wavs
+def synth_wav(utt_idx: int, num_samples: int = 32000) -> np.ndarray:
+    """One PCM16 utterance: gaussian noise (sigma 3000) + an 8000-amplitude tone."""
+    rng = np.random.Generator(np.random.PCG64(1234 + int(utt_idx)))
+    f0 = rng.uniform(80.0, 400.0)
+    t = np.arange(num_samples, dtype=np.float64) / SAMPLE_RATE
+    x = 3000.0 * rng.standard_normal(num_samples) + 8000.0 * np.sin(2 * np.pi * f0 * t)
+    # a slow amplitude envelope so that frames differ in energy
+    x *= 0.6 + 0.4 * np.sin(2 * np.pi * (0.7 + 0.1 * (utt_idx % 5)) * t)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def synth_wav_batch(first_idx: int, batch: int, num_samples: int = 32000) -> np.ndarray:
+    return np.stack([synth_wav(first_idx + i, num_samples) for i in range(batch)])
+
+
+def write_wav(path: str, pcm: np.ndarray, sample_rate: int = SAMPLE_RATE) -> None:
+    """Minimal RIFF/WAVE PCM16 mono writer (stdlib only)."""
+    import wave
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sample_rate)
+        w.writeframes(np.ascontiguousarray(pcm, dtype="<i2").tobytes())
+
+
+# ------------------------------------------------------------------------ weights
+class _Init:
+    def __init__(self, seed):
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.sd = OrderedDict()
+
+    def conv(self, name, cout, cin, *k, bias=True, gain=2.0):
+        fan_in = cin * int(np.prod(k)) if k else cin
+        shape = (cout, cin) + tuple(k)
+        std = np.sqrt(gain / fan_in)
+        self.sd[name + ".weight"] = (std * self.rng.standard_normal(shape)).astype(np.float32)
+        if bias:
+            self.sd[name + ".bias"] = (0.1 * self.rng.standard_normal(cout)).astype(np.float32)
+
+    def linear(self, name, cout, cin, bias=True, gain=1.0):
+        self.conv(name, cout, cin, bias=bias, gain=gain)
+
+    def bn(self, name, c, affine=True):
+        """Randomised eval-mode BN (default init would make BN ~identity and hide bugs)."""
+        if affine:
+            self.sd[name + ".weight"] = self.rng.uniform(0.8, 1.2, c).astype(np.float32)
+            self.sd[name + ".bias"] = (0.1 * self.rng.standard_normal(c)).astype(np.float32)
+        self.sd[name + ".running_mean"] = (0.1 * self.rng.standard_normal(c)).astype(np.float32)
+        self.sd[name + ".running_var"] = self.rng.uniform(0.5, 1.5, c).astype(np.float32)
+        self.sd[name + ".num_batches_tracked"] = np.array(1000, dtype=np.int64)
+
+
+def ecapa_config(model_name: str):
+    """(channels, global_context_att) for the reference constructor names."""
+    table = {
+        "ECAPA_TDNN_c512": (512, False),
+        "ECAPA_TDNN_GLOB_c512": (512, True),
+        "ECAPA_TDNN_c1024": (1024, False),
+        "ECAPA_TDNN_GLOB_c1024": (1024, True),
+    }
+    if model_name not in table:
+        raise KeyError(model_name)
+    return table[model_name]
+
+
+def synth_ecapa_state_dict(model_name="ECAPA_TDNN_GLOB_c512", feat_dim=80, embed_dim=192,
+                           emb_bn=False, seed=42):
+    C, glob = ecapa_config(model_name)
+    w = C // 8
+    g = _Init(seed)
+    g.conv("layer1.conv", C, feat_dim, 5)
+    g.bn("layer1.bn", C)
+    for L in (2, 3, 4):
+        p = "layer%d.se_res2block" % L
+        g.conv(p + ".0.conv", C, C, 1)
+        g.bn(p + ".0.bn", C)
+        for i in range(7):
+            g.conv(p + ".1.convs.%d" % i, w, w, 3)
+            g.bn(p + ".1.bns.%d" % i, w)
+        g.conv(p + ".2.conv", C, C, 1, gain=0.7)
+        g.bn(p + ".2.bn", C)
+        g.linear(p + ".3.linear1", 128, C)
+        g.linear(p + ".3.linear2", C, 128, gain=4.0)
+    g.conv("conv", 1536, 3 * C, 1, gain=1.0)
+    g.conv("pool.linear1", 128, 1536 * (3 if glob else 1), 1, gain=1.0)
+    g.conv("pool.linear2", 1536, 128, 1, gain=8.0)   # wide logits -> non-trivial softmax
+    g.bn("bn", 3072)
+    g.linear("linear", embed_dim, 3072)
+    if emb_bn:
+        g.bn("bn2", embed_dim)
+    return g.sd
+
+
+def synth_state_dict(model_name, feat_dim=80, embed_dim=None, seed=42, **kw):
+    if model_name.startswith("ECAPA_TDNN"):
+        return synth_ecapa_state_dict(model_name, feat_dim, embed_dim or 192, seed=seed, **kw)
+    raise KeyError("no synthetic weights for model %r yet" % model_name)
+
+
+def write_model_dir(model_dir, model_name, feat_dim=80, embed_dim=192, seed=42, **model_kw):
+    """Write `config.yaml` + `avg_model.pt` exactly as wespeaker.load_model expects
+    (reference cli/speaker.py:306-335)."""
+    import os
+    import torch
+    import yaml
+    os.makedirs(model_dir, exist_ok=True)
+    sd = synth_state_dict(model_name, feat_dim, embed_dim, seed=seed, **model_kw)
+    torch.save(OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in sd.items()),
+               os.path.join(model_dir, "avg_model.pt"))
+    model_args = dict(feat_dim=feat_dim, embed_dim=embed_dim)
+    if model_name.startswith("ECAPA"):
+        model_args["pooling_func"] = "ASTP"
+    model_args.update(model_kw)
+    cfg = {
+        "model": model_name,
+        "model_args": model_args,
+        "dataset_args": {
+            "resample_rate": 16000,
+            "frontend": "fbank",
+            "fbank_args": {"num_mel_bins": feat_dim, "frame_shift": 10,
+                           "frame_length": 25, "dither": 0.0},
+        },
+    }
+    with open(os.path.join(model_dir, "config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    return sd
+
+
+# --------------------------------------------------------------------------- PLDA
+def synth_plda(dim=192, seed=7, normalize_length=False):
+    """transform = Q diag(s) (Q Haar), psi sorted-descending Gamma(2,1)+0.01,
+    mu ~ N(0, 0.1), offset = -T mu.  All float64 like the reference's HDF5 models."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.standard_normal((dim, dim))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    s = rng.uniform(0.5, 2.0, dim)
+    transform = q * s[None, :]
+    psi = np.sort(rng.gamma(2.0, 1.0, dim) + 0.01)[::-1].copy()
+    mu = 0.1 * rng.standard_normal(dim)
+    offset = -transform @ mu
+    return {"mu": mu, "transform": transform, "psi": psi, "offset": offset,
+            "normalize_length": bool(normalize_length), "subtract_train_set_mean": False}
+
+
+def synth_embeddings(n, dim=192, seed=11, num_speakers=None):
+    """float32 embeddings with speaker structure (so LLRs span target/non-target ranges)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    num_speakers = num_speakers or max(1, n // 8)
+    centers = rng.standard_normal((num_speakers, dim))
+    spk = rng.integers(0, num_speakers, n)
+    x = centers[spk] + 0.6 * rng.standard_normal((n, dim))
+    return x.astype(np.float32), spk
+
+
+def synth_trial_pairs(num_trials, n_enroll, n_test, seed=99):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (rng.integers(0, n_enroll, num_trials).astype(np.int32),
+            rng.integers(0, n_test, num_trials).astype(np.int32))
