@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: embeddings/sec on 2 s @ 16 kHz synthetic utterances through
+ECAPA-TDNN-512 (wav -> Kaldi fbank -> CMN -> forward, all in the HIP library) + PLDA trials/sec.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of `--batch` utterances per GPU whose PCM16
+samples are already resident in HBM.  Utterances are sharded over ranks as independent blocks
+(weak scaling: per-GPU batch fixed); the only collective is the all_gather of the (B, 192)
+embeddings, which is inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- dominant kernel (fp32-MFMA conv-GEMM, 128x128 tile): algorithmic FLOPs of its
+                  launches / their summed HIP-event durations measured live in the timed region.
+  cpu_baseline -- the oracle (CPU restatement of the reference: fbank + torch fp32 ECAPA forward,
+                  batch 1 per utterance like Speaker.extract_embedding_list) timed on this box's
+                  host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from wespeaker_amd import Frontend, NativeSpeakerModel, TwoCovPLDA, parallel, synth  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+
+
+def device_wavs(batch, num_samples, device, seed_base):
+    """Synthetic PCM16 batch generated on the device (same recipe family as synth.synth_wav:
+    gaussian noise sigma 3000 + 8000-amplitude tone with per-utterance f0 in [80, 400] Hz)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + seed_base)
+    t = torch.arange(num_samples, device=device, dtype=torch.float32) / 16000.0
+    f0 = 80.0 + 320.0 * torch.rand(batch, 1, device=device, generator=g)
+    x = 3000.0 * torch.randn(batch, num_samples, device=device, generator=g)
+    x = x + 8000.0 * torch.sin(2 * np.pi * f0 * t[None, :])
+    return x.round().clamp(-32768, 32767).to(torch.int16).contiguous()
+
+
+def cpu_baseline(model_name, sample_utts):
+    """Oracle on the host cores: the Speaker.extract_embedding_list loop (fbank -> CMN -> model,
+    batch 1) over `sample_utts` synthetic utterances."""
+    from oracle import ecapa as oecapa
+    from oracle import fbank as ofbank
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in
+          synth.synth_ecapa_state_dict(model_name, 80, 192, seed=42).items()}
+    wavs = [synth.synth_wav(i) for i in range(sample_utts)]
+    oecapa.ecapa_forward(sd, ofbank.speaker_features(wavs[0])[None])      # warm-up
+    t0 = time.perf_counter()
+    for w in wavs:
+        oecapa.ecapa_forward(sd, ofbank.speaker_features(w)[None])
+    dt = time.perf_counter() - t0
+    return {"value": sample_utts / dt, "unit": "embeddings/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d synthetic 2 s utts, batch 1, numpy fbank + torch-fp32 ECAPA oracle, %.1f s"
+                      % (sample_utts, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--chunk", type=int, default=64, help="engine forward chunk (utterances)")
+    ap.add_argument("--model", default="ECAPA_TDNN_GLOB_c512")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--trials", type=int, default=1000000)
+    ap.add_argument("--cpu-utts", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank = parallel.init_distributed()
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    num_samples = int(args.seconds * 16000)
+    sd = synth.synth_ecapa_state_dict(args.model, 80, 192, seed=42)
+    fe = Frontend(16000, 80, device=device)
+    T = fe.num_frames(num_samples)
+    model = NativeSpeakerModel(args.model, sd, feat_dim=80, embed_dim=192, device=device,
+                               max_batch=args.chunk, max_frames=T)
+    wav = device_wavs(args.batch, num_samples, device, seed_base=rank)
+    n_total = args.batch * world
+
+    def step():
+        emb = model.extract(fe, wav)                              # (B, 192) on this GPU
+        return parallel.gather_rows(emb, n_total) if world > 1 else emb
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    model.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_emb = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = model.profile_read()
+    model.profile(False)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+
+    # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
+    plda_info = None
+    if rank == 0:
+        p = synth.synth_plda(192, seed=7)
+        plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
+        n_emb = 10000
+        emb_tab, _ = synth.synth_embeddings(2 * n_emb, 192, seed=11)
+        emb_tab = torch.from_numpy(emb_tab).to(device)
+        ie, it = synth.synth_trial_pairs(args.trials, n_emb, n_emb, seed=99)
+        ie_d, it_d = torch.from_numpy(ie).to(device), torch.from_numpy(it).to(device)
+        nn = torch.ones(n_emb, dtype=torch.int32, device=device)
+
+        def plda_step():
+            e_t = plda.prepare_test(emb_tab[:n_emb])
+            t_t = plda.prepare_test(emb_tab[n_emb:])
+            return plda.llr_pairs(e_t, nn, t_t, ie_d, it_d)
+
+        for _ in range(2):
+            plda_step()
+        torch.cuda.synchronize(device)
+        k = max(3, min(args.steps, 20))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            plda_step()
+        torch.cuda.synchronize(device)
+        pdt = (time.perf_counter() - t1) / k
+        e_t = plda.prepare_test(emb_tab[:1000])
+        t_t = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
+        for _ in range(2):
+            plda.llr_matrix(e_t, nn[:1000], t_t)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        for _ in range(k):
+            plda.llr_matrix(e_t, nn[:1000], t_t)
+        torch.cuda.synchronize(device)
+        mdt = (time.perf_counter() - t2) / k
+        plda_info = {"pairs_trials_per_s": args.trials / pdt, "pairs_ms": pdt * 1e3,
+                     "pairs_workload": "%d index pairs over 2x%d embeddings D=192 incl. transform"
+                                       % (args.trials, n_emb),
+                     "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
+                     "matrix_workload": "dense 1000x1000 LLR matrix D=192", "dtype": "f64"}
+
+    if rank == 0:
+        g = prof["conv_gemm_f32_128x128"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        gemm_ms = sum(prof[c]["ms"] for c in prof if c.startswith("conv_gemm"))
+        total_ms = sum(prof[c]["ms"] for c in prof)
+        line = {
+            "metric": "embeddings/sec (2 s utts, ECAPA-512) + PLDA trials/sec at 1/2/4/8 MI355X",
+            "value": n_total * args.steps / dt,
+            "unit": "embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s fbank80 E=192, %d x %.0f s @16 kHz PCM16 utts per GPU per step "
+                                   "(wav resident in HBM -> fbank -> CMN -> forward -> all_gather)"
+                                   % (args.model, args.batch, args.seconds),
+                       "per_gpu_batch": args.batch, "global_batch": n_total, "frames": T,
+                       "engine_chunk": args.chunk, "parallelism": "utterance-sharded x%d" % world},
+            "plda_trials_per_s": plda_info["pairs_trials_per_s"],
+            "plda": plda_info,
+            "roofline": {
+                "kernel": "conv_gemm_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": g["launches"], "avg_launch_ms": g["ms"] / max(1, g["launches"]),
+                "kernel_time_share": g["ms"] / total_ms if total_ms else None,
+                "all_gemm_time_share": gemm_ms / total_ms if total_ms else None,
+                "forward_flops_per_utt": model.flops(1, T),
+                "event_ms_by_class": {c: round(prof[c]["ms"] / args.steps, 4) for c in prof},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, args.cpu_utts)
+        assert all_emb.shape == (n_total, 192) and bool(torch.isfinite(all_emb).all())
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,16 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 
+/* Measurement hooks (bench.py roofline leg; no reference counterpart -- the reference only has the
+ * wall-clock Timer of runtime/core/utils/timer.h:22-36).  While enabled, every kernel launch of
+ * ws_forward/ws_extract is bracketed by HIP events on the launch stream.  ws_engine_profile_read
+ * synchronises them and fills 4-element arrays indexed by kernel class
+ * (0 = fp32-MFMA conv-GEMM 128x128 tile, 1 = 128x64 tile, 2 = reductions/element-wise,
+ * 3 = split-K GEMM): summed milliseconds, algorithmic FLOPs, algorithmic bytes, launch counts.
+ * Returns the number of classes. */
+int ws_engine_profile_enable(ws_engine* eng, int on);
+int ws_engine_profile_read(ws_engine* eng, double* ms, double* flops, double* bytes, int* launches);
+
 /* ------------------------------------------------------------------------------------ PLDA */
 /* Replaces TwoCovPLDA.load_model's in-memory state (utils/plda/two_cov_plda.py:341-363):
  * mu, psi, offset HOST float64[dim]; transform HOST float64[dim*dim] row-major. */

@@ -188,7 +188,7 @@ def test_plda_matches_oracle_and_reference_golden(normalize_length, golden_dir):
     emb, _ = synth.synth_embeddings(40, 192, seed=11)
     g = np.load(os.path.join(golden_dir, "plda_ref.npz"))
     tag = "nl%d" % int(normalize_length)
-    tr = plda.transform(emb.astype(np.float64)).cpu().numpy()
+    tr = plda.transform_rows(emb.astype(np.float64)).cpu().numpy()
     assert np.abs(tr - g[tag + "/transformed"]).max() < 1e-10
     one = plda.transform_embedding(emb[3].astype(np.float64))
     assert np.abs(one - g[tag + "/transformed"][3]).max() < 1e-10

@@ -261,6 +261,21 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
   return WS_OK;
 }
 
+int ws_engine_profile_enable(ws_engine* eng, int on) {
+  if (!eng) { set_error("ws_engine_profile_enable: invalid argument"); return WS_ERR_INVALID_ARG; }
+  eng->model->prof.enabled = on != 0;
+  return WS_OK;
+}
+
+int ws_engine_profile_read(ws_engine* eng, double* ms, double* flops, double* bytes, int* launches) {
+  if (!eng || !ms || !flops || !bytes || !launches) {
+    set_error("ws_engine_profile_read: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  eng->model->prof.read(ms, flops, bytes, launches);
+  return KernelProfiler::kClasses;
+}
+
 double ws_engine_flops(const ws_engine* eng, int batch, int num_frames) {
   return eng ? eng->model->flops(batch, num_frames) : 0.0;
 }

@@ -80,8 +80,54 @@ struct HostTensor {
   }
 };
 
+// Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg:
+// achieved FLOP/s of the dominant kernel = sum of algorithmic flops / sum of event-to-event ms).
+struct KernelProfiler {
+  enum { kClasses = 4 };      // 0: conv_gemm 128x128 tile, 1: conv_gemm 128x64 tile, 2: other, 3: split-K path
+  bool enabled = false;
+  struct Rec { int cls; double flops, bytes; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  ~KernelProfiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+  hipEvent_t take() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  // call before / after a launch
+  void begin(int cls, double flops, double bytes, hipStream_t st) {
+    if (!enabled) return;
+    Rec r{cls, flops, bytes, take(), take()};
+    if (!r.a || !r.b) return;
+    (void)hipEventRecord(r.a, st);
+    recs.push_back(r);
+  }
+  void end(hipStream_t st) {
+    if (!enabled || recs.empty()) return;
+    (void)hipEventRecord(recs.back().b, st);
+  }
+  // synchronises; sums per class; clears
+  void read(double* ms, double* flops, double* bytes, int* launches) {
+    for (int c = 0; c < kClasses; ++c) { ms[c] = 0; flops[c] = 0; bytes[c] = 0; launches[c] = 0; }
+    for (auto& r : recs) {
+      (void)hipEventSynchronize(r.b);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+        ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+      }
+    }
+    recs.clear();
+    used = 0;
+  }
+};
+
 // Model-family interface behind ws_engine (native twin of runtime/core/speaker/speaker_model.h:25-32)
 struct Model {
+  KernelProfiler prof;
   virtual ~Model() {}
   // returns true if `key` belongs to this architecture
   virtual bool wants(const std::string& key) const = 0;

@@ -256,9 +256,29 @@ struct EcapaModel : Model {
     }                                                                                 \
   } while (0)
 
+  // conv-GEMM launch with optional event timing (class 0/1 = MFMA tile variant, 3 = split-K)
+  hipError_t gemm(const ConvGemmParams& p, hipStream_t st) {
+    if (prof.enabled) {
+      const double flops = 2.0 * p.M * (double)p.N * p.K;
+      const double bytes = 4.0 * ((double)p.M * p.Cin * (p.A2 ? 2 : 1) + (double)p.N * p.K +
+                                  (double)p.M * p.N);
+      prof.begin(p.splitk > 1 ? 3 : (p.N <= 64 ? 1 : 0), flops, bytes, st);
+    }
+    hipError_t e = launch_conv_gemm(p, st);
+    prof.end(st);
+    return e;
+  }
+  template <typename F>
+  hipError_t other(double bytes, hipStream_t st, F&& f) {
+    prof.begin(2, 0.0, bytes, st);
+    hipError_t e = f();
+    prof.end(st);
+    return e;
+  }
+
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
     // layer1: Conv1d(F -> C, k5, p2) -> ReLU -> BN
-    WS_LAUNCH(launch_conv_gemm(conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU), st));
+    WS_LAUNCH(gemm(conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU), st));
     for (int L = 0; L < 3; ++L) {
       const int d = L + 2;
       const float* x = L == 0 ? out1 : cat;
@@ -267,37 +287,46 @@ struct EcapaModel : Model {
       // 1x1 conv -> ReLU -> BN; the last Res2 split is passed through untouched: dual store
       ConvGemmParams p = conv1d(blk0[L], x, ldx, x_off, y1, C, 0, B, T, 1, ACT_RELU);
       p.D2 = y2; p.ldd2 = C; p.d2_off = 7 * w; p.d2_col0 = 7 * w;
-      WS_LAUNCH(launch_conv_gemm(p, st));
+      WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
       for (int i = 0; i < 7; ++i) {
         ConvGemmParams q = conv1d(res2[L][i], y1, C, i * w, y2, C, i * w, B, T, d, ACT_RELU);
         if (i >= 1) { q.A2 = y2; q.lda2 = C; q.a2_off = (i - 1) * w; }
-        WS_LAUNCH(launch_conv_gemm(q, st));
+        WS_LAUNCH(gemm(q, st));
       }
-      WS_LAUNCH(launch_conv_gemm(conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU), st));
-      WS_LAUNCH(launch_se_pool_fc(y3, C, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                  arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st));
-      WS_LAUNCH(launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st));
+      WS_LAUNCH(gemm(conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU), st));
+      const double mc = 4.0 * B * (double)T * C;
+      WS_LAUNCH(other(mc, st, [&] {
+        return launch_se_pool_fc(y3, C, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
+                                 arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
+      }));
+      WS_LAUNCH(other(3 * mc, st, [&] {
+        return launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st);
+      }));
     }
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
-    WS_LAUNCH(launch_conv_gemm(conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU), st));
+    WS_LAUNCH(gemm(conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU), st));
     // ASTP
     ConvGemmParams a1 = conv1d(pool1, h, 1536, 0, att, 128, 0, B, T, 1, ACT_TANH);
     a1.K = 1536; a1.Cin = 1536;                      // GLOB: only the first 1536 columns multiply h
     if (glob) {
-      WS_LAUNCH(launch_astp_context_bias(h, 1536, B, T, 1536, arena.at(pool1.w), pool1.ldw,
-                                         arena.at(pool1.b), 128, stats, bias_img, st));
+      WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
+        return launch_astp_context_bias(h, 1536, B, T, 1536, arena.at(pool1.w), pool1.ldw,
+                                        arena.at(pool1.b), 128, stats, bias_img, st);
+      }));
       a1.bias = nullptr;
       a1.bias_img = bias_img;
     }
-    WS_LAUNCH(launch_conv_gemm(a1, st));
-    WS_LAUNCH(launch_conv_gemm(conv1d(pool2, att, 128, 0, e, 1536, 0, B, T, 1, ACT_NONE), st));
-    WS_LAUNCH(launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st));
+    WS_LAUNCH(gemm(a1, st));
+    WS_LAUNCH(gemm(conv1d(pool2, att, 128, 0, e, 1536, 0, B, T, 1, ACT_NONE), st));
+    WS_LAUNCH(other(8.0 * B * (double)T * 1536, st, [&] {
+      return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st);
+    }));
     // BN + Linear (+bn2), folded: split-K GEMM over K = 3072
     ConvGemmParams f = conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE);
     f.splitk = kSplitK;
     f.partial = partial;
-    WS_LAUNCH(launch_conv_gemm(f, st));
+    WS_LAUNCH(gemm(f, st));
     WS_LAUNCH(launch_splitk_reduce(f, st));
     return 0;
   }

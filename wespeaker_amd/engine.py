@@ -130,6 +130,22 @@ class NativeSpeakerModel:
     def flops(self, batch, frames) -> float:
         return float(_lib.lib().ws_engine_flops(self._h, int(batch), int(frames)))
 
+    PROFILE_CLASSES = ("conv_gemm_f32_128x128", "conv_gemm_f32_128x64", "reduce_elementwise",
+                       "conv_gemm_f32_splitk")
+
+    def profile(self, on: bool):
+        _lib.check(_lib.lib().ws_engine_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """-> {class: dict(ms, flops, bytes, launches)}; synchronises the recorded events."""
+        ms = (ctypes.c_double * 4)()
+        fl = (ctypes.c_double * 4)()
+        by = (ctypes.c_double * 4)()
+        ln = (ctypes.c_int * 4)()
+        _lib.check(_lib.lib().ws_engine_profile_read(self._h, ms, fl, by, ln))
+        return {n: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i])
+                for i, n in enumerate(self.PROFILE_CLASSES)}
+
     def _ensure_capacity(self, frames):
         if frames > self.max_frames:
             raise _lib.NativeError("utterance has %d frames, engine capacity is %d (pass max_frames)"

@@ -159,7 +159,7 @@ class TwoCovPLDA:
         return out
 
     # ---------------------------------------------------------- reference per-vector methods
-    def transform(self, x) -> torch.Tensor:
+    def transform_rows(self, x) -> torch.Tensor:
         """(N, D) float64 -> (N, D) float64: `transform_embedding` applied row-wise on the GPU."""
         x = self._dev(x, torch.float64)
         out = torch.empty_like(x)
@@ -173,7 +173,7 @@ class TwoCovPLDA:
     def transform_embedding(self, embedding):
         """(D,) -> (D,) float64 numpy (two_cov_plda.py:156-163)."""
         x = np.asarray(embedding, dtype=np.float64)[None, :]
-        return self.transform(x).cpu().numpy()[0]
+        return self.transform_rows(x).cpu().numpy()[0]
 
     def log_likelihood_ratio(self, transformed_train_embedding, transformed_test_embedding, n):
         out = self.llr_matrix(np.asarray(transformed_train_embedding, dtype=np.float64)[None, :],
