@@ -57,15 +57,28 @@ def cpu_baseline(model_name, sample_utts):
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in
           synth.synth_ecapa_state_dict(model_name, 80, 192, seed=42).items()}
     wavs = [synth.synth_wav(i) for i in range(sample_utts)]
-    oecapa.ecapa_forward(sd, ofbank.speaker_features(wavs[0])[None])      # warm-up
-    t0 = time.perf_counter()
-    for w in wavs:
-        oecapa.ecapa_forward(sd, ofbank.speaker_features(w)[None])
-    dt = time.perf_counter() - t0
-    return {"value": sample_utts / dt, "unit": "embeddings/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d synthetic 2 s utts, batch 1, numpy fbank + torch-fp32 ECAPA oracle, %.1f s"
-                      % (sample_utts, dt)}
+    avail = os.cpu_count() or 1
+    best = None
+    # batch-1 torch ops do not scale to every core of a large host: try a few thread counts on a
+    # bounded sample each and report the best one (the threads actually used are stated)
+    for threads in sorted({1, min(8, avail), min(32, avail)}):
+        torch.set_num_threads(threads)
+        oecapa.ecapa_forward(sd, ofbank.speaker_features(wavs[0])[None])      # warm-up
+        n = 0
+        t0 = time.perf_counter()
+        for w in wavs:
+            oecapa.ecapa_forward(sd, ofbank.speaker_features(w)[None])
+            n += 1
+            if time.perf_counter() - t0 > 8.0:
+                break
+        dt = time.perf_counter() - t0
+        if best is None or n / dt > best[0]:
+            best = (n / dt, threads, n, dt)
+    return {"value": best[0], "unit": "embeddings/s", "cores": best[1], "kind": "port",
+            "host_cores": avail,
+            "sample": "%d synthetic 2 s utts in %.1f s, batch 1 (the Speaker.extract_embedding_list "
+                      "loop): numpy fbank + torch-fp32 ECAPA oracle; best of 1/8/32 threads"
+                      % (best[2], best[3])}
 
 
 def main():
@@ -74,7 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--chunk", type=int, default=64, help="engine forward chunk (utterances)")
+    ap.add_argument("--chunk", type=int, default=256, help="engine forward chunk (utterances)")
     ap.add_argument("--model", default="ECAPA_TDNN_GLOB_c512")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--trials", type=int, default=1000000)

@@ -1,0 +1,47 @@
+// Stand-alone timing probe for the conv-GEMM kernel (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip wespeaker_amd/csrc/conv_gemm.hip -o /tmp/gemm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../wespeaker_amd/csrc/kernels.h"
+using namespace wsamd;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+int main(int argc, char** argv) {
+  struct Shape { int M, N, K, taps; const char* name; };
+  std::vector<Shape> shapes = {{50688, 512, 512, 1, "1x1 512"}, {50688, 1536, 1536, 1, "cat 1536"},
+                               {50688, 128, 1536, 1, "astp1"}, {50688, 1536, 128, 1, "astp2"},
+                               {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"}};
+  float *A, *W, *D, *Z, *bias;
+  size_t maxA = 50688ull * 1536, maxW = 1536ull * 1536, maxD = 50688ull * 1536;
+  CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&W, maxW * 4)); CK(hipMalloc(&D, maxD * 4));
+  CK(hipMalloc(&Z, 256)); CK(hipMemset(Z, 0, 256)); CK(hipMalloc(&bias, 1536 * 4));
+  std::vector<float> h(maxA);
+  for (size_t i = 0; i < maxA; ++i) h[i] = (float)((rand() % 2001) - 1000) / 1000.f;
+  CK(hipMemcpy(A, h.data(), maxA * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, h.data(), maxW * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, h.data(), 1536 * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto& s : shapes) {
+    ConvGemmParams p; memset(&p, 0, sizeof(p));
+    int Cin = s.K / s.taps;
+    p.A = A; p.lda = Cin; p.W = W; p.ldw = (s.K + 31) / 32 * 32; p.D = D; p.ldd = s.N;
+    p.M = s.M; p.N = s.N; p.K = s.K; p.Cin = Cin;
+    p.Hin = p.Hout = 1; p.Win = p.Wout = 198; p.stride_h = p.stride_w = 1; p.kh = 1; p.kw = s.taps;
+    p.dil_h = 1; p.dil_w = s.taps == 3 ? 2 : 1; p.pad_w = p.dil_w * (s.taps / 2);
+    p.bias = bias; p.act = ACT_RELU; p.post_scale = bias; p.post_shift = bias; p.splitk = 1; p.zeros = Z;
+    for (int i = 0; i < 3; ++i) CK(launch_conv_gemm(p, 0));
+    CK(hipDeviceSynchronize());
+    const int iters = 20;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) CK(launch_conv_gemm(p, 0));
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
+    printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF\n", s.name, s.M, s.N, s.K, s.taps, us, tf);
+  }
+  return 0;
+}

@@ -391,12 +391,12 @@ int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_ses
 int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
                       int n_enroll, const double* test, int n_test, const int32_t* idx_e,
                       const int32_t* idx_t, int64_t num_trials, double* out, ws_stream stream) {
+  if (plda && num_trials == 0) return WS_OK;        // empty trial list: nothing to do
   if (!plda || !enroll || !n_sessions || !test || !out || !idx_e || !idx_t || n_enroll < 0 ||
       n_test < 0 || num_trials < 0) {
     set_error("ws_plda_llr_pairs: invalid argument");
     return WS_ERR_INVALID_ARG;
   }
-  if (num_trials == 0) return WS_OK;
   if (n_enroll == 0 || n_test == 0) {
     set_error("ws_plda_llr_pairs: trials given but an embedding table is empty");
     return WS_ERR_INVALID_ARG;

@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool HAS_A2>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int S = LDS_STRIDE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -42,8 +42,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 
   const int tid = threadIdx.x;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  // XCD-aware tile order: the dispatcher places block b on XCD b % 8, each XCD has a private L2.
+  // Give every XCD one CONTIGUOUS range of the (tile_m major, tile_n minor) work order, so the
+  // blocks that run concurrently on an XCD share their A row-panel (all n-tiles of an m-tile) and
+  // the weight panels; placement only affects speed, the map is a bijection for any grid size.
+  int work;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    work = xcd * q + (xcd < r ? xcd : r) + local;
+  }
+  const int tile_m = work / tiles_n;
+  const int tile_n = work - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---------------- staging roles: thread -> (16-B chunk kc of the K-tile, rows r0 + 32 i)
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       const long long pix = a_pix[i] + tapoff;
       const float* src = ok ? p.A + pix * p.lda + p.a_off + ci : p.zeros;
       ra[i] = *reinterpret_cast<const f32x4*>(src);
-      if (p.A2) {
+      if (HAS_A2) {
         const float* src2 = ok ? p.A2 + pix * p.lda2 + p.a2_off + ci : p.zeros;
         ra[i] += *reinterpret_cast<const f32x4*>(src2);
       }
@@ -135,7 +145,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   int buf = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool has_next = kt + 1 < kt_end;
+#if !defined(WS_ABLATE) || WS_ABLATE < 1
     if (has_next) load_tile(kt + 1);
+#endif
     const float* As = lds + buf * (BM + BN) * S + (wm * TM * 32 + li) * S + lh * 4;
     const float* Ws = lds + buf * (BM + BN) * S + BM * S + (wn * TN * 32 + li) * S + lh * 4;
 #pragma unroll
@@ -155,52 +167,87 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
           for (int in = 0; in < TN; ++in)
             acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
     }
+#if !defined(WS_ABLATE) || WS_ABLATE < 2
     if (has_next) store_tile(buf ^ 1);
     __syncthreads();
+#endif
     buf ^= 1;
   }
 
   // ---------------- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  if (p.splitk > 1) {
 #pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int n = n0 + (wn * TN + in) * 32 + li;
-    const bool nok = n < p.N;
-    float bias = 0.f, ps = 1.f, pb = 0.f;
-    if (p.splitk <= 1 && nok) {
-      if (p.bias) bias = p.bias[n];
-      if (p.post_scale) { ps = p.post_scale[n]; pb = p.post_shift[n]; }
-    }
+    for (int in = 0; in < TN; ++in) {
+      const int n = n0 + (wn * TN + in) * 32 + li;
 #pragma unroll
-    for (int im = 0; im < TM; ++im) {
+      for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + (wm * TM + im) * 32 + row;
-        if (m >= p.M || !nok) continue;
-        float v = acc[im][in][r];
-        if (p.splitk > 1) {
-          p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = v;
-          continue;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = acc[im][in][r];
         }
-        v += bias;
-        if (p.bias_img) v += p.bias_img[(long long)(m / HW) * p.N + n];
-        if (p.residual) v += p.residual[(long long)m * p.ldr + p.r_off + n];
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_TANH) v = tanhf(v);
+    }
+    return;
+  }
+  // Transpose the accumulators through LDS (the staging buffers are free now) so that every lane
+  // finishes 4 consecutive output channels of one row: 16-B global stores, 512 B contiguous per
+  // output row, instead of 4-B stores (which are ~6x slower per byte on gfx950).
+  constexpr int ES = BN + 4;
+  {
+    float* Es = lds;
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          Es[row * ES + (wn * TN + in) * 32 + li] = acc[im][in][r];
+        }
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = BN / 4;                 // float4 columns per tile row
+    constexpr int RPP = 256 / C4;              // rows per pass
+    const int c4 = tid % C4, rr = tid / C4;
+    const int n = n0 + c4 * 4;
+    if (n < p.N) {                             // N % 4 == 0 (checked on the host)
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.post_scale) {
+        ps = *reinterpret_cast<const f32x4*>(p.post_scale + n);
+        pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
+      }
+      const bool to_d2 = p.D2 && n >= p.d2_col0;
+#pragma unroll 4
+      for (int row = rr; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
+        if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
+        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
+        if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        } else if (p.act == ACT_TANH) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+        }
         if (p.post_scale) v = v * ps + pb;
-        p.D[(long long)m * p.ldd + p.d_off + n] = v;
-        if (p.D2 && n >= p.d2_col0) p.D2[(long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)] = v;
+        *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
+        if (to_d2)
+          *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool HAS_A2>
 static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
   const size_t lds_bytes = 2ull * (BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -215,8 +262,16 @@ static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
 
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.N <= 64) return launch_variant<128, 64, 4, 1>(p, stream);
-  return launch_variant<128, 128, 2, 2>(p, stream);
+  // 16-byte paths: channel counts / offsets / row strides must be multiples of 4 floats
+  if ((p.N | p.Cin | p.lda | p.a_off | p.ldw | p.ldd | p.d_off) & 3) return hipErrorInvalidValue;
+  if (p.A2 && ((p.lda2 | p.a2_off) & 3)) return hipErrorInvalidValue;
+  if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
+  if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
+  if (p.N <= 64)
+    return p.A2 ? launch_variant<128, 64, 4, 1, true>(p, stream)
+                : launch_variant<128, 64, 4, 1, false>(p, stream);
+  return p.A2 ? launch_variant<128, 128, 2, 2, true>(p, stream)
+              : launch_variant<128, 128, 2, 2, false>(p, stream);
 }
 
 // --------------------------------------------------------------------------- split-K reduce

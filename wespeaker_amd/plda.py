@@ -135,6 +135,8 @@ class TwoCovPLDA:
         n = self._dev(np.broadcast_to(np.asarray(n_sessions, dtype=np.int32), (e.shape[0],)).copy()
                       if not isinstance(n_sessions, torch.Tensor) else n_sessions, torch.int32)
         out = torch.empty((e.shape[0], t.shape[0]), dtype=torch.float64, device=self.device)
+        if out.numel() == 0:
+            return out
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ws_plda_llr_matrix(
                 self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
@@ -151,6 +153,8 @@ class TwoCovPLDA:
         if ie.shape != it.shape:
             raise ValueError("idx_e and idx_t differ in length")
         out = torch.empty((ie.shape[0],), dtype=torch.float64, device=self.device)
+        if ie.shape[0] == 0:
+            return out
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ws_plda_llr_pairs(
                 self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
