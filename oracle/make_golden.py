@@ -8,6 +8,8 @@ What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerat
   * ecapa_ref.npz   -- embeddings of the reference's own nn.Modules
                        (wespeaker/models/ecapa_tdnn.py, imported from /root/reference) for the four
                        ECAPA constructors on synthetic utterances 0..1, weights = synth seed 42.
+  * resnet_ref.npz / campplus_ref.npz -- the same for the reference's ResNet18/34/50/221 and
+                       CAMPPlus modules (wespeaker/models/resnet.py, campplus.py).
   * plda_ref.npz    -- outputs of the reference's own TwoCovPLDA.transform_embedding /
                        log_likelihood_ratio (wespeaker/utils/plda/two_cov_plda.py:156-184).
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
@@ -81,6 +83,39 @@ def make_ecapa():
     np.savez_compressed(os.path.join(GOLD, "ecapa_ref.npz"), **out)
 
 
+def _ref_forward(name, sd, feats, **model_args):
+    m = ref_shim.ref_model(name, **model_args)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(feats))
+    return (out[-1] if isinstance(out, tuple) else out).numpy()
+
+
+def make_resnet_campplus():
+    feats = np.stack([speaker_features(synth.synth_wav(i)) for i in range(2)])
+    long_feats = np.stack([speaker_features(synth.synth_wav(i, 52800)) for i in range(2)])   # 328 frames
+    out = {}
+    for name, kw in (("ResNet18", {}), ("ResNet34", {}), ("ResNet34", {"two_emb_layer": True}),
+                     ("ResNet50", {}), ("ResNet221", {})):
+        sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42, **kw)
+        tag = name + ("_2emb" if kw else "")
+        out[tag + "/emb"] = _ref_forward(name, sd, feats, feat_dim=80, embed_dim=256,
+                                         pooling_func="TSTP", **kw)
+        out[tag + "/emb_T57"] = _ref_forward(name, sd, feats[:, :57].copy(), feat_dim=80,
+                                             embed_dim=256, pooling_func="TSTP", **kw)
+        print(tag, float(np.abs(out[tag + "/emb"]).mean()))
+    np.savez_compressed(os.path.join(GOLD, "resnet_ref.npz"), **out)
+    sd = synth.synth_campplus_state_dict(80, 512, seed=42)
+    cam = {"emb": _ref_forward("CAMPPlus", sd, feats, feat_dim=80, embed_dim=512, pooling_func="TSTP"),
+           "emb_T328": _ref_forward("CAMPPlus", sd, long_feats, feat_dim=80, embed_dim=512,
+                                    pooling_func="TSTP"),
+           "emb_T57": _ref_forward("CAMPPlus", sd, feats[:, :57].copy(), feat_dim=80, embed_dim=512,
+                                   pooling_func="TSTP")}
+    np.savez_compressed(os.path.join(GOLD, "campplus_ref.npz"), **cam)
+    print("CAMPPlus", float(np.abs(cam["emb"]).mean()))
+
+
 def make_plda():
     out = {}
     emb, _ = synth.synth_embeddings(40, 192, seed=11)
@@ -103,5 +138,6 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     make_fbank()
     make_ecapa()
+    make_resnet_campplus()
     make_plda()
     print("golden fixtures written to", GOLD)

@@ -257,3 +257,80 @@ def test_score_plda_and_eval_sv_files(tmp_path, normalize_length, multisession_a
         a = ln.split()
         assert a[0] == m and a[1] == t and a[3] == lab
         assert abs(float(a[2]) - r) < 1e-3          # printed with %.5f; indomain mean in f32 ark
+
+
+# -------------------------------------------------------------------------- ResNet / CAM++
+def _native(name, sd, embed_dim, max_batch=4, max_frames=400):
+    from wespeaker_amd.engine import NativeSpeakerModel
+    return NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=embed_dim, max_batch=max_batch,
+                              max_frames=max_frames)
+
+
+@pytest.mark.parametrize("name,kw", [("ResNet18", {}), ("ResNet34", {}),
+                                     ("ResNet34", {"two_emb_layer": True}), ("ResNet50", {}),
+                                     ("ResNet221", {})])
+def test_resnet_forward_matches_oracle_and_golden(name, kw, golden_dir):
+    from oracle import resnet as oresnet
+    sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42, **kw)
+    model = _native(name, sd, 256)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(3)])
+    out = model(torch.from_numpy(feats))
+    assert isinstance(out, tuple)
+    got = out[-1].cpu().numpy()
+    ref = oresnet.resnet_forward(sd, feats, name).numpy()
+    assert got.shape == ref.shape == (3, 256)
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < REL_TOL
+    g = np.load(os.path.join(golden_dir, "resnet_ref.npz"))
+    tag = name + ("_2emb" if kw else "")
+    assert _rel_err(got[:2], g[tag + "/emb"]).max() < REL_TOL
+    got_s = model(torch.from_numpy(feats[:2, :57].copy()))[-1].cpu().numpy()
+    assert _rel_err(got_s, g[tag + "/emb_T57"]).max() < REL_TOL
+    for T in (9, 64, 131, 200):              # odd sizes through the three stride-2 stages
+        f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
+        e = model(torch.from_numpy(f))[-1].cpu().numpy()
+        assert _rel_err(e, oresnet.resnet_forward(sd, f, name).numpy()).max() < REL_TOL
+
+
+def test_campplus_forward_matches_oracle_and_golden(golden_dir):
+    from oracle import campplus as ocam
+    sd = synth.synth_campplus_state_dict(80, 512, seed=42)
+    model = _native("CAMPPlus", sd, 512, max_batch=4, max_frames=700)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(3)])
+    got = model(torch.from_numpy(feats))
+    assert isinstance(got, torch.Tensor)                 # CAM++ returns a bare tensor
+    got = got.cpu().numpy()
+    ref = ocam.campplus_forward(sd, feats).numpy()
+    assert got.shape == ref.shape == (3, 512)
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < REL_TOL
+    g = np.load(os.path.join(golden_dir, "campplus_ref.npz"))
+    assert _rel_err(got[:2], g["emb"]).max() < REL_TOL
+    long_feats = np.stack([ofbank.speaker_features(synth.synth_wav(i, 52800)) for i in range(2)])
+    got_l = model(torch.from_numpy(long_feats)).cpu().numpy()
+    assert _rel_err(got_l, g["emb_T328"]).max() < REL_TOL        # two context segments
+    got_s = model(torch.from_numpy(feats[:2, :57].copy())).cpu().numpy()
+    assert _rel_err(got_s, g["emb_T57"]).max() < REL_TOL
+    for T in (7, 201, 399, 603):             # 603 -> T' = 302 -> 4 segments, last one 2 frames
+        f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
+        e = model(torch.from_numpy(f)).cpu().numpy()
+        assert _rel_err(e, ocam.campplus_forward(sd, f).numpy()).max() < REL_TOL
+
+
+def test_speaker_api_resnet_and_campplus_model_dirs(tmp_path):
+    import wespeaker_amd as wespeaker
+    from oracle import campplus as ocam
+    from oracle import resnet as oresnet
+    wav = synth.synth_wav(200)
+    p = str(tmp_path / "a.wav")
+    synth.write_wav(p, wav)
+    feats = ofbank.speaker_features(wav)[None]
+    for name, ed, fwd in (("ResNet34", 256, lambda sd, f: oresnet.resnet_forward(sd, f, "ResNet34")),
+                          ("CAMPPlus", 512, ocam.campplus_forward)):
+        mdir = str(tmp_path / name)
+        sd = synth.write_model_dir(mdir, name, 80, ed, seed=9)
+        spk = wespeaker.load_model(mdir)
+        e = spk.extract_embedding(p).numpy()
+        r = fwd(sd, feats).numpy()[0]
+        assert e.shape == (ed,)
+        assert _cos_err(e, r) < COS_TOL and _rel_err(e, r) < 5e-4

@@ -119,3 +119,36 @@ def test_reference_native_fbank_library_runs():
     assert n == 198
     mine = ofbank.speaker_features(synth.synth_wav(7), cmn=False)
     assert np.abs(mine - out[:n]).max() < 5e-4
+
+
+@pytest.mark.parametrize("name,kw", [("ResNet18", {}), ("ResNet34", {}),
+                                     ("ResNet34", {"two_emb_layer": True}), ("ResNet50", {}),
+                                     ("ResNet221", {})])
+def test_resnet_restatement_vs_reference_golden(golden_dir, name, kw):
+    from oracle import resnet as oresnet
+    g = np.load(os.path.join(golden_dir, "resnet_ref.npz"))
+    tag = name + ("_2emb" if kw else "")
+    sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42, **kw)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    emb = oresnet.resnet_forward(sd, feats, name).numpy()
+    ref = g[tag + "/emb"]
+    assert emb.shape == ref.shape == (2, 256)
+    assert np.abs(emb - ref).max() <= 2e-4 * np.abs(ref).max()
+    emb_s = oresnet.resnet_forward(sd, feats[:, :57], name).numpy()
+    assert np.abs(emb_s - g[tag + "/emb_T57"]).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_campplus_restatement_vs_reference_golden(golden_dir):
+    from oracle import campplus as ocam
+    g = np.load(os.path.join(golden_dir, "campplus_ref.npz"))
+    sd = synth.synth_campplus_state_dict(80, 512, seed=42)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    emb = ocam.campplus_forward(sd, feats).numpy()
+    assert emb.shape == (2, 512)
+    assert np.abs(emb - g["emb"]).max() <= 2e-4 * np.abs(g["emb"]).max()
+    # 328 frames -> T' = 164 -> two context segments (100 + 64, ceil_mode)
+    long_feats = np.stack([ofbank.speaker_features(synth.synth_wav(i, 52800)) for i in range(2)])
+    emb_l = ocam.campplus_forward(sd, long_feats).numpy()
+    assert np.abs(emb_l - g["emb_T328"]).max() <= 2e-4 * np.abs(g["emb_T328"]).max()
+    emb_s = ocam.campplus_forward(sd, feats[:, :57]).numpy()
+    assert np.abs(emb_s - g["emb_T57"]).max() <= 2e-4 * np.abs(g["emb_T57"]).max()

@@ -166,6 +166,8 @@ int ws_engine_create(const char* model_name, int feat_dim, int embed_dim, int de
   }
   WS_HIP_CHECK(hipSetDevice(device_id));
   Model* m = make_ecapa(model_name, feat_dim, embed_dim);
+  if (!m) m = make_resnet(model_name, feat_dim, embed_dim);
+  if (!m) m = make_campplus(model_name, feat_dim, embed_dim);
   if (!m) {
     set_error("ws_engine_create: unknown model '%s'", model_name);
     return WS_ERR_UNKNOWN_MODEL;

@@ -1,0 +1,280 @@
+// CAM++ (CAMPPlus) forward scheduled onto the gfx950 kernels.
+//
+// Reference (file:line in wenet-e2e/wespeaker):
+//   wespeaker/models/campplus.py:333-413  CAMPPlus (FCM head -> TDNN k5 s2 -> 3 dense blocks
+//                                         (12/24/16 layers, dilation 1/2/2) + transit -> BN-ReLU ->
+//                                         TSTP -> dense 1x1 + BN(affine=False))
+//   wespeaker/models/campplus.py:282-330  FCM;  :245-279 BasicResBlock (freq-only stride (2,1))
+//   wespeaker/models/campplus.py:138-170  CAMDenseTDNNLayer;  :86-135 CAMLayer
+//
+// Layout: channels-last everywhere.  FCM activations are [b][f][t][c]; its (B, C*F', T) reshape
+// is never materialised: the TDNN layer is run as a (kh = F', kw = 5) convolution over the
+// (F' x T) image with the weight re-indexed on the host.  A dense block owns ONE [B*T'][Cmax] buffer
+// and every layer appends its 32 channels at a channel offset (concat-free).  Pre-activation
+// BN-ReLU (CAM++ is BN -> ReLU -> conv) is applied while the GEMM stages its A operand; BN that
+// directly follows a conv is folded into the weights; the context mask multiplies in the epilogue.
+#include "model_common.h"
+
+namespace wsamd {
+
+namespace {
+
+struct ResBlk { ConvW c1, c2, sc; bool has_sc = false; int stride = 1; };
+struct DenseLayerW {
+  size_t pre_s = 0, pre_b = 0;        // nonlinear1 BN (on the layer input)
+  ConvW lin1;                         // 1x1 Cin -> 128, nonlinear2 BN folded, ReLU
+  ConvW local;                        // k3 dilated 128 -> 32
+  size_t cw1 = 0, cb1 = 0, cw2 = 0, cb2 = 0;   // context FCs 128 -> 64 -> 32
+  int cin = 0;
+};
+struct Transit { size_t pre_s = 0, pre_b = 0; ConvW lin; int cin = 0; };
+
+struct CamppModel : ModelBase {
+  size_t stem_w = 0, stem_b = 0;
+  ResBlk res[4];
+  ConvW head_conv2, tdnn, dense;
+  std::vector<DenseLayerW> layers[3];
+  Transit transit[3];
+  size_t out_s = 0, out_b = 0;
+  int fprime = 10;
+  static constexpr int kLayers[3] = {12, 24, 16};
+  static constexpr int kDil[3] = {1, 2, 2};
+  static constexpr int kSplitK = 8;
+  float *fa = nullptr, *fb = nullptr, *fc = nullptr, *xbuf = nullptr, *xbuf2 = nullptr, *hbuf = nullptr,
+        *mask = nullptr, *pooled = nullptr, *partial = nullptr;
+  int max_segs = 1;
+
+  CamppModel(int fd, int ed) : ModelBase("CAMPPlus", fd, ed) {}
+
+  bool wants(const std::string& key) const override {
+    if (key.size() > 20 && key.compare(key.size() - 19, 19, "num_batches_tracked") == 0)
+      return false;
+    return key.compare(0, 5, "head.") == 0 || key.compare(0, 8, "xvector.") == 0;
+  }
+
+  int finalize(const SD& sd, int max_batch, int max_frames) override {
+    int err = 0;
+    if (feat_dim % 8) { set_error("CAMPPlus needs feat_dim %% 8 == 0"); return WS_ERR_INVALID_ARG; }
+    fprime = feat_dim / 8;
+    {
+      const HostTensor* wt = get(sd, "head.conv1.weight", {32, 1, 3, 3}, &err);
+      if (!wt) return err;
+      std::vector<double> sc, sh;
+      if ((err = bn_affine(sd, "head.bn1", 32, &sc, &sh))) return err;
+      std::vector<float> wf(32 * 9), bf(32);
+      for (int c = 0; c < 32; ++c) {
+        for (int k = 0; k < 9; ++k) wf[c * 9 + k] = (float)(wt->data[c * 9 + k] * sc[c]);
+        bf[c] = (float)sh[c];
+      }
+      stem_w = arena.add(wf);
+      stem_b = arena.add(bf);
+    }
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = std::string("head.layer") + (i < 2 ? "1." : "2.") + std::to_string(i & 1);
+      res[i].stride = (i & 1) ? 1 : 2;
+      if ((err = pack_conv2d(sd, p + ".conv1", 32, 32, 3, 3, p + ".bn1", &res[i].c1))) return err;
+      if ((err = pack_conv2d(sd, p + ".conv2", 32, 32, 3, 3, p + ".bn2", &res[i].c2))) return err;
+      if (!(i & 1)) {
+        res[i].has_sc = true;
+        if ((err = pack_conv2d(sd, p + ".shortcut.0", 32, 32, 1, 1, p + ".shortcut.1", &res[i].sc))) return err;
+      }
+    }
+    if ((err = pack_conv2d(sd, "head.conv2", 32, 32, 3, 3, "head.bn2", &head_conv2))) return err;
+    {   // TDNN: Conv1d(32*F' -> 128, k5, stride 2, pad 2), input channel index = c*F' + f.
+        // Run as a conv over the (F' x T) image: tap (ty = f, tx = j), Cin = 32.
+      const int Fp = fprime;
+      if ((err = pack_conv(sd, "xvector.tdnn.linear", {128, 32 * Fp, 5}, 128, 32, Fp, 5,
+                           [=](int n, int tp, int ci) {
+                             const int f = tp / 5, j = tp % 5;
+                             return ((size_t)n * 32 * Fp + (size_t)ci * Fp + f) * 5 + j;
+                           },
+                           false, "xvector.tdnn.nonlinear.batchnorm", "", &tdnn)))
+        return err;
+    }
+    int ch = 128;
+    for (int k = 0; k < 3; ++k) {
+      for (int j = 0; j < kLayers[k]; ++j) {
+        const std::string p = "xvector.block" + std::to_string(k + 1) + ".tdnnd" + std::to_string(j + 1);
+        DenseLayerW L;
+        L.cin = ch + 32 * j;
+        if ((err = add_bn_vectors(sd, p + ".nonlinear1.batchnorm", L.cin, &L.pre_s, &L.pre_b))) return err;
+        if ((err = pack_conv(sd, p + ".linear1", {128, L.cin, 1}, 128, L.cin, 1, 1,
+                             [=](int n, int, int ci) { return (size_t)n * L.cin + ci; }, false,
+                             p + ".nonlinear2.batchnorm", "", &L.lin1)))
+          return err;
+        if ((err = pack_conv1d(sd, p + ".cam_layer.linear_local", 32, 128, 3, false, "", "", &L.local))) return err;
+        const HostTensor* t;
+        if (!(t = get(sd, p + ".cam_layer.linear1.weight", {64, 128, 1}, &err))) return err;
+        L.cw1 = arena.add(t->data);
+        if ((err = add_vec(sd, p + ".cam_layer.linear1.bias", 64, &L.cb1))) return err;
+        if (!(t = get(sd, p + ".cam_layer.linear2.weight", {32, 64, 1}, &err))) return err;
+        L.cw2 = arena.add(t->data);
+        if ((err = add_vec(sd, p + ".cam_layer.linear2.bias", 32, &L.cb2))) return err;
+        layers[k].push_back(L);
+      }
+      ch += 32 * kLayers[k];
+      const std::string p = "xvector.transit" + std::to_string(k + 1);
+      transit[k].cin = ch;
+      if ((err = add_bn_vectors(sd, p + ".nonlinear.batchnorm", ch, &transit[k].pre_s, &transit[k].pre_b))) return err;
+      const int cin = ch;
+      if ((err = pack_conv(sd, p + ".linear", {ch / 2, ch, 1}, ch / 2, ch, 1, 1,
+                           [=](int n, int, int ci) { return (size_t)n * cin + ci; }, false, "", "",
+                           &transit[k].lin)))
+        return err;
+      ch /= 2;
+    }
+    if ((err = add_bn_vectors(sd, "xvector.out_nonlinear.batchnorm", ch, &out_s, &out_b))) return err;
+    {   // dense: Conv1d(2*ch -> E, k1, no bias) + BN(affine=False), folded
+      const int cin = 2 * ch;
+      if ((err = pack_conv(sd, "xvector.dense.linear", {embed_dim, cin, 1}, embed_dim, cin, 1, 1,
+                           [=](int n, int, int ci) { return (size_t)n * cin + ci; }, false,
+                           "xvector.dense.nonlinear.batchnorm", "", &dense, /*fold_affine=*/false)))
+        return err;
+    }
+
+    maxB = max_batch; maxT = max_frames;
+    const size_t img = (size_t)maxB * feat_dim * maxT * 32;        // FCM full-resolution activation
+    const int Tp = (maxT - 1) / 2 + 1;
+    const size_t Mp = (size_t)maxB * Tp;
+    max_segs = (Tp + 99) / 100;
+    size_t total = 0;
+    auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
+    size_t o_fa = take(img), o_fb = take(img / 2 + 64), o_fc = take(img / 2 + 64),
+           o_x = take(Mp * 1024), o_x2 = take(Mp * 1024), o_h = take(Mp * 128),
+           o_mask = take((size_t)maxB * max_segs * 32), o_pool = take((size_t)maxB * 1024),
+           o_part = take((size_t)kSplitK * maxB * embed_dim),
+           o_feats = take((size_t)maxB * maxT * feat_dim);
+    if ((err = upload_and_alloc(total))) return err;
+    float* base = ws.as<float>();
+    fa = base + o_fa; fb = base + o_fb; fc = base + o_fc; xbuf = base + o_x; xbuf2 = base + o_x2;
+    hbuf = base + o_h; mask = base + o_mask; pooled = base + o_pool; partial = base + o_part;
+    feats_ws = base + o_feats;
+    return 0;
+  }
+
+  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
+    // ---------------- FCM head (2-D, stride only along frequency)
+    int H = feat_dim;
+    WS_LAUNCH(other(4.0 * B * H * (double)T * 33, st, [&] {
+      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, fa, st);
+    }));
+    float* x = fa;          // block input
+    float* t1 = fb;
+    float* t2 = fc;
+    for (int i = 0; i < 4; ++i) {
+      const int s = res[i].stride, Ho = (H - 1) / s + 1;
+      const float* r = x;
+      if (res[i].has_sc) {
+        WS_LAUNCH(gemm(conv2d(res[i].sc, x, 32, 0, t2, 32, 0, B, H, T, s, 1, 1, 1, 0, 0, ACT_NONE), st));
+        r = t2;
+      }
+      WS_LAUNCH(gemm(conv2d(res[i].c1, x, 32, 0, t1, 32, 0, B, H, T, s, 1, 1, 1, 1, 1, ACT_RELU), st));
+      // conv2 writes over the block input buffer when that is no longer needed (shortcut case),
+      // otherwise into t2
+      float* out = res[i].has_sc ? x : t2;
+      ConvGemmParams p2 = conv2d(res[i].c2, t1, 32, 0, out, 32, 0, B, Ho, T, 1, 1, 1, 1, 1, 1, ACT_RELU);
+      p2.residual = r; p2.ldr = 32; p2.r_off = 0;
+      WS_LAUNCH(gemm(p2, st));
+      if (!res[i].has_sc) { float* tmp = x; x = t2; t2 = tmp; }
+      H = Ho;
+    }
+    {   // head.conv2: 3x3 stride (2,1) + BN + ReLU  -> [b][F'][T][32]
+      WS_LAUNCH(gemm(conv2d(head_conv2, x, 32, 0, t1, 32, 0, B, H, T, 2, 1, 1, 1, 1, 1, ACT_RELU), st));
+      H = (H - 1) / 2 + 1;
+    }
+    // ---------------- TDNN (k5, stride 2) over the (F' x T) image -> [B*T'][128] at channel 0 of xbuf
+    const int Tp = (T - 1) / 2 + 1;
+    float* X = xbuf;
+    float* Xn = xbuf2;
+    int ldx = 128 + 32 * kLayers[0];
+    WS_LAUNCH(gemm(conv2d(tdnn, t1, 32, 0, X, ldx, 0, B, H, T, 1, 2, 1, 1, 0, 2, ACT_RELU), st));
+    const int segs = (Tp + 99) / 100;
+    int ch = 128;
+    for (int k = 0; k < 3; ++k) {
+      for (size_t j = 0; j < layers[k].size(); ++j) {
+        const DenseLayerW& L = layers[k][j];
+        // BN-ReLU -> 1x1 (Cin -> 128) -> BN -> ReLU
+        ConvGemmParams p1 = conv1d(L.lin1, X, ldx, 0, hbuf, 128, 0, B, Tp, 1, ACT_RELU);
+        p1.pre_scale = arena.at(L.pre_s); p1.pre_shift = arena.at(L.pre_b);
+        WS_LAUNCH(gemm(p1, st));
+        // context mask m[b][seg][32]
+        WS_LAUNCH(other(4.0 * B * (double)Tp * 128, st, [&] {
+          return launch_cam_context(hbuf, 128, B, Tp, 128, 100, arena.at(L.cw1), arena.at(L.cb1), 64,
+                                    arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
+        }));
+        // local k3 dilated conv 128 -> 32, times the mask, appended at channel offset cin
+        ConvGemmParams p2 = conv1d(L.local, hbuf, 128, 0, X, ldx, L.cin, B, Tp, kDil[k], ACT_NONE);
+        p2.seg_scale = mask; p2.seg_len = 100; p2.segs_per_img = segs;
+        WS_LAUNCH(gemm(p2, st));
+      }
+      ch += 32 * kLayers[k];
+      // transit: BN-ReLU -> 1x1 (ch -> ch/2), written to channel 0 of the next block's buffer
+      const int ld_next = k < 2 ? ch / 2 + 32 * kLayers[k + 1] : ch / 2;
+      ConvGemmParams pt = conv1d(transit[k].lin, X, ldx, 0, Xn, ld_next, 0, B, Tp, 1, ACT_NONE);
+      pt.pre_scale = arena.at(transit[k].pre_s); pt.pre_shift = arena.at(transit[k].pre_b);
+      WS_LAUNCH(gemm(pt, st));
+      float* tmp = X; X = Xn; Xn = tmp;
+      ldx = ld_next;
+      ch /= 2;
+    }
+    // out_nonlinear BN-ReLU fused into TSTP, then dense 1x1 + BN(affine=False)
+    WS_LAUNCH(other(8.0 * B * (double)Tp * ch, st, [&] {
+      return launch_tstp(X, ldx, B, 1, Tp, ch, arena.at(out_s), arena.at(out_b), pooled, st);
+    }));
+    WS_LAUNCH(gemm_splitk(conv1d(dense, pooled, 2 * ch, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
+                          partial, kSplitK, st));
+    return 0;
+  }
+
+  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
+    if (frames > maxT || frames < 3) {
+      set_error("num_frames %d outside the finalized capacity [3, %d]", frames, maxT);
+      return WS_ERR_CAPACITY;
+    }
+    for (int b0 = 0; b0 < batch; b0 += maxB) {
+      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
+      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
+                            emb + (size_t)b0 * embed_dim, st);
+      if (r) return r;
+    }
+    return 0;
+  }
+
+  double flops(int batch, int T) const override {
+    double macs = 0;
+    int H = feat_dim;
+    macs += (double)H * T * 9 * 32;
+    for (int i = 0; i < 4; ++i) {
+      const int s = res[i].stride, Ho = (H - 1) / s + 1;
+      macs += (double)Ho * T * 9 * 32 * 32 * 2;
+      if (res[i].has_sc) macs += (double)Ho * T * 32 * 32;
+      H = Ho;
+    }
+    H = (H - 1) / 2 + 1;
+    macs += (double)H * T * 9 * 32 * 32;
+    const int Tp = (T - 1) / 2 + 1;
+    macs += (double)Tp * 128 * 32 * fprime * 5;
+    int ch = 128;
+    for (int k = 0; k < 3; ++k) {
+      for (int j = 0; j < kLayers[k]; ++j)
+        macs += (double)Tp * ((double)(ch + 32 * j) * 128 + 128.0 * 32 * 3) + 128.0 * 64 + 64.0 * 32;
+      ch += 32 * kLayers[k];
+      macs += (double)Tp * ch * (ch / 2);
+      ch /= 2;
+    }
+    macs += 2.0 * ch * embed_dim;
+    return 2.0 * macs * batch;
+  }
+};
+
+constexpr int CamppModel::kLayers[3];
+constexpr int CamppModel::kDil[3];
+
+}  // namespace
+
+Model* make_campplus(const std::string& model_name, int feat_dim, int embed_dim) {
+  if (model_name == "CAMPPlus") return new CamppModel(feat_dim, embed_dim);
+  return nullptr;
+}
+
+}  // namespace wsamd

@@ -1,0 +1,196 @@
+// Non-GEMM kernels of the ResNet and CAM++ forwards on channels-last activations.
+//
+// Reference semantics:
+//   stem conv       wespeaker/models/resnet.py:128-134,175 / campplus.py:286-292,325
+//   TSTP            wespeaker/models/pooling_layers.py:78-85 (unbiased var + 1e-7)
+//   CAM context     wespeaker/models/campplus.py:108-135 (global mean + 100-frame segment means,
+//                   ceil_mode, Linear -> ReLU -> Linear -> sigmoid)
+#include "kernels.h"
+
+namespace wsamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// -------------------------------------------------------------------------------------- stem
+// out[((b*F + f)*T + t)*C + c] = relu(b[c] + sum_{dy,dx} w[c][dy*3+dx] * img(f+dy-1, t+dx-1)),
+// img(f, t) = feats[(b*T + t)*F + f].  One thread per (pixel, 4 channels): 16-B coalesced stores.
+__global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ feats, int T,
+                                                           int F, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int C,
+                                                           float* __restrict__ out,
+                                                           long long total) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    const long long pix = i / c4n;
+    const int t = (int)(pix % T);
+    const long long bf = pix / T;
+    const int f = (int)(bf % F);
+    const long long b = bf / F;
+    const float* img = feats + b * T * F;
+    float in[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ff = f + dy - 1, tt = t + dx - 1;
+        in[dy * 3 + dx] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? img[(long long)tt * F + ff] : 0.f;
+      }
+    f32x4 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* wc = w + (c + q) * 9;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += wc[k] * in[k];
+      acc[q] = fmaxf(s + bias[c + q], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + pix * C + c) = acc;
+  }
+}
+
+hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
+                               const float* b, int C, float* out, hipStream_t stream) {
+  if (C & 3) return hipErrorInvalidValue;
+  const long long total = (long long)B * F * T * (C >> 2);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(stem_conv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feats, T, F,
+                     w, b, C, out, total);
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------- TSTP
+// grid = (B*F, ceil(C/64)); block = 256 = 4 time-groups x 64 channels.  Two passes over T
+// (mean, then centred squares) like torch.var; partial sums combined through LDS.
+__global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, int ldx, int F, int T,
+                                                   int C, const float* __restrict__ pre_scale,
+                                                   const float* __restrict__ pre_shift,
+                                                   float* __restrict__ pooled) {
+  __shared__ float red[4][64];
+  const int bf = blockIdx.x, b = bf / F, f = bf - b * F;
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const bool cok = c < C;
+  const float* base = x + (long long)bf * T * ldx + (cok ? c : 0);
+  float ps = 1.f, pb = 0.f;
+  const bool pre = pre_scale != nullptr;
+  if (pre && cok) { ps = pre_scale[c]; pb = pre_shift[c]; }
+  float s = 0.f;
+  for (int t = grp; t < T; t += 4) {
+    float v = base[(long long)t * ldx];
+    if (pre) v = fmaxf(v * ps + pb, 0.f);
+    s += v;
+  }
+  red[grp][cl] = s;
+  __syncthreads();
+  const float mean = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)T;
+  __syncthreads();
+  float q = 0.f;
+  for (int t = grp; t < T; t += 4) {
+    float v = base[(long long)t * ldx];
+    if (pre) v = fmaxf(v * ps + pb, 0.f);
+    const float d = v - mean;
+    q += d * d;
+  }
+  red[grp][cl] = q;
+  __syncthreads();
+  if (grp == 0 && cok) {
+    const float var = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)(T - 1);
+    const long long CF = (long long)C * F;
+    pooled[(long long)b * 2 * CF + (long long)c * F + f] = mean;
+    pooled[(long long)b * 2 * CF + CF + (long long)c * F + f] = sqrtf(var + 1e-7f);
+  }
+}
+
+hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
+                       const float* pre_shift, float* pooled, hipStream_t stream) {
+  hipLaunchKernelGGL(tstp_kernel, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x, ldx, F, T, C,
+                     pre_scale, pre_shift, pooled);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- CAM context mask
+// grid = B, block = 256.  C <= 256 channels, hidden <= 128, Cout <= 64, segs <= 32.
+// Segment sums over the T axis (lanes = channels, 256/C time groups), then the two small FCs
+// per segment.  mask[b][seg][Cout].
+__global__ __launch_bounds__(256) void cam_context_kernel(const float* __restrict__ h, int ldh, int T,
+                                                          int C, int seg_len, int segs,
+                                                          const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, int hidden,
+                                                          const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, int Cout,
+                                                          float* __restrict__ mask) {
+  extern __shared__ float sm[];
+  float* segsum = sm;                       // [groups][segs][C]
+  const int groups = 256 / C;
+  float* ctx = sm + groups * segs * C;      // [C]
+  float* hid = ctx + C;                     // [hidden]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid % C, grp = tid / C;
+  const float* base = h + (long long)b * T * ldh + c;
+  if (grp < groups) {
+    for (int s = 0; s < segs; ++s) {
+      const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
+      float acc = 0.f;
+      for (int t = t0 + grp; t < t1; t += groups) acc += base[(long long)t * ldh];
+      segsum[(grp * segs + s) * C + c] = acc;
+    }
+  }
+  __syncthreads();
+  // fold the time groups: segsum[0][s][c] <- sum_g
+  for (int i = tid; i < segs * C; i += 256) {
+    float v = 0.f;
+    for (int g = 0; g < groups; ++g) v += segsum[g * segs * C + i];
+    segsum[i] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int s = 0; s < segs; ++s) {
+    const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
+    if (tid < C) {
+      float tot = 0.f;
+      for (int k = 0; k < segs; ++k) tot += segsum[k * C + tid];
+      ctx[tid] = tot / (float)T + segsum[s * C + tid] / (float)(t1 - t0);
+    }
+    __syncthreads();
+    for (int j = wave; j < hidden; j += 4) {          // hid = relu(W1 ctx + b1)
+      const float* wr = w1 + (long long)j * C;
+      float v = 0.f;
+      for (int k = lane; k < C; k += 64) v += wr[k] * ctx[k];
+      v = wave_sum32(v);
+      if (lane == 0) hid[j] = fmaxf(v + b1[j], 0.f);
+    }
+    __syncthreads();
+    if (tid < Cout) {                                  // m = sigmoid(W2 hid + b2)
+      const float* wr = w2 + (long long)tid * hidden;
+      float v = 0.f;
+      for (int k = 0; k < hidden; ++k) v += wr[k] * hid[k];
+      v += b2[tid];
+      mask[((long long)b * segs + s) * Cout + tid] = 1.f / (1.f + expf(-v));
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
+                              const float* w1, const float* b1, int hidden, const float* w2,
+                              const float* b2, int Cout, float* mask, hipStream_t stream) {
+  if (C > 256 || 256 % C != 0 || hidden > 128 || Cout > 64) return hipErrorInvalidValue;
+  const int segs = (T + seg_len - 1) / seg_len;
+  const int groups = 256 / C;
+  const size_t lds = ((size_t)groups * segs * C + C + hidden) * sizeof(float);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cam_context_kernel, dim3(B), dim3(256), lds, stream, h, ldh, T, C, seg_len, segs,
+                     w1, b1, hidden, w2, b2, Cout, mask);
+  return hipGetLastError();
+}
+
+}  // namespace wsamd

@@ -142,6 +142,8 @@ struct Model {
 };
 
 Model* make_ecapa(const std::string& model_name, int feat_dim, int embed_dim);
+Model* make_resnet(const std::string& model_name, int feat_dim, int embed_dim);
+Model* make_campplus(const std::string& model_name, int feat_dim, int embed_dim);
 
 }  // namespace wsamd
 

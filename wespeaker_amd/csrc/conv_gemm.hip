@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2>
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int S = LDS_STRIDE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -104,6 +104,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       if (HAS_A2) {
         const float* src2 = ok ? p.A2 + pix * p.lda2 + p.a2_off + ci : p.zeros;
         ra[i] += *reinterpret_cast<const f32x4*>(src2);
+      }
+      if (HAS_PRE) {
+        // ci < Cin is guaranteed when kok; clamp keeps the (discarded) tail loads in range
+        const int cc = kok ? ci : 0;
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.pre_scale + cc);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.pre_shift + cc);
+        f32x4 v = ra[i] * s4 + t4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok ? fmaxf(v[q], 0.f) : 0.f;
+        ra[i] = v;
       }
     }
 #pragma unroll
@@ -235,6 +245,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
           for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
         }
         if (p.post_scale) v = v * ps + pb;
+        if (p.seg_scale) {
+          const int img = m / HW, ox = (m - img * HW) % p.Wout;
+          v *= *reinterpret_cast<const f32x4*>(
+              p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
+        }
         *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
         if (to_d2)
           *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
@@ -243,11 +258,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2>
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE>
 static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
   const size_t lds_bytes = 2ull * (BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2>;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -267,11 +282,15 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.A2 && ((p.lda2 | p.a2_off) & 3)) return hipErrorInvalidValue;
   if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
-  if (p.N <= 64)
-    return p.A2 ? launch_variant<128, 64, 4, 1, true>(p, stream)
-                : launch_variant<128, 64, 4, 1, false>(p, stream);
-  return p.A2 ? launch_variant<128, 128, 2, 2, true>(p, stream)
-              : launch_variant<128, 128, 2, 2, false>(p, stream);
+  if (p.pre_scale && p.A2) return hipErrorInvalidValue;
+  if (p.N <= 64) {
+    if (p.pre_scale) return launch_variant<128, 64, 4, 1, false, true>(p, stream);
+    return p.A2 ? launch_variant<128, 64, 4, 1, true, false>(p, stream)
+                : launch_variant<128, 64, 4, 1, false, false>(p, stream);
+  }
+  if (p.pre_scale) return launch_variant<128, 128, 2, 2, false, true>(p, stream);
+  return p.A2 ? launch_variant<128, 128, 2, 2, true, false>(p, stream)
+              : launch_variant<128, 128, 2, 2, false, false>(p, stream);
 }
 
 // --------------------------------------------------------------------------- split-K reduce
@@ -288,6 +307,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
   else if (p.act == ACT_TANH) v = tanhf(v);
   if (p.post_scale) v = v * p.post_scale[n] + p.post_shift[n];
   p.D[(long long)m * p.ldd + p.d_off + n] = v;
+  if (p.D2 && n >= p.d2_col0) p.D2[(long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)] = v;
 }
 
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream) {

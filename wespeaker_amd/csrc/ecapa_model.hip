@@ -11,43 +11,23 @@
 // split is dual-stored by the producing GEMM, eval-mode BN is an epilogue affine after the ReLU
 // (the reference order is conv -> ReLU -> BN, so it cannot be folded into the conv weights), the
 // last BN + Linear (+ bn2) are folded on the host in float64.
-#include <cmath>
-#include <cstring>
-
-#include "common.h"
-#include "kernels.h"
+#include "model_common.h"
 
 namespace wsamd {
 
 namespace {
 
-struct ConvW {        // conv/linear with optional bias and post-activation BN affine
-  size_t w = 0, b = 0, scale = 0, shift = 0;
-  bool has_b = false, has_bn = false;
-  int N = 0, Cin = 0, taps = 1, ldw = 0;
-};
-
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-struct EcapaModel : Model {
-  std::string name;
-  int feat_dim, embed_dim;
+struct EcapaModel : ModelBase {
   int C = 512, w = 64;
   bool glob = false;
-  int maxB = 0, maxT = 0;
-
-  WeightArena arena;
   ConvW layer1, blk0[3], res2[3][7], blk2[3], catconv, pool1, pool2, final_lin;
   size_t se_w1[3], se_b1[3], se_w2[3], se_b2[3];
-  size_t zeros_off = 0;
-
-  DevBuf ws;                         // activation workspace
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
-        *pooled = nullptr, *partial = nullptr, *feats_ws = nullptr;
+        *pooled = nullptr, *partial = nullptr;
   static constexpr int kSplitK = 16;
 
-  EcapaModel(const std::string& n, int fd, int ed) : name(n), feat_dim(fd), embed_dim(ed) {
+  EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
     glob = n.find("GLOB") != std::string::npos;
     C = n.find("c1024") != std::string::npos ? 1024 : 512;
     w = C / 8;
@@ -63,112 +43,29 @@ struct EcapaModel : Model {
     return false;
   }
 
-  // ------------------------------------------------------------------ weight ingestion helpers
-  const HostTensor* get(const std::map<std::string, HostTensor>& sd, const std::string& key,
-                        std::initializer_list<int64_t> shape, int* err) {
-    auto it = sd.find(key);
-    if (it == sd.end()) {
-      set_error("missing tensor '%s' for model %s", key.c_str(), name.c_str());
-      *err = WS_ERR_MISSING_TENSOR;
-      return nullptr;
-    }
-    std::vector<int64_t> want(shape);
-    if (it->second.shape != want) {
-      std::string got, exp;
-      for (auto s : it->second.shape) got += std::to_string(s) + ",";
-      for (auto s : want) exp += std::to_string(s) + ",";
-      set_error("tensor '%s' has shape (%s) but model %s expects (%s)", key.c_str(), got.c_str(),
-                name.c_str(), exp.c_str());
-      *err = WS_ERR_SHAPE;
-      return nullptr;
-    }
-    return &it->second;
-  }
-
-  // eval-mode BatchNorm -> y = x*scale + shift (float64 on the host)
-  int bn_affine(const std::map<std::string, HostTensor>& sd, const std::string& prefix, int n,
-                std::vector<double>* scale, std::vector<double>* shift, bool affine = true) {
+  int finalize(const SD& sd, int max_batch, int max_frames) override {
     int err = 0;
-    const HostTensor* mean = get(sd, prefix + ".running_mean", {n}, &err);
-    if (!mean) return err;
-    const HostTensor* var = get(sd, prefix + ".running_var", {n}, &err);
-    if (!var) return err;
-    const HostTensor *g = nullptr, *bt = nullptr;
-    if (affine) {
-      g = get(sd, prefix + ".weight", {n}, &err);
-      if (!g) return err;
-      bt = get(sd, prefix + ".bias", {n}, &err);
-      if (!bt) return err;
-    }
-    scale->resize(n);
-    shift->resize(n);
-    for (int i = 0; i < n; ++i) {
-      double inv = 1.0 / std::sqrt((double)var->data[i] + 1e-5);
-      double s = (g ? (double)g->data[i] : 1.0) * inv;
-      (*scale)[i] = s;
-      (*shift)[i] = (bt ? (double)bt->data[i] : 0.0) - (double)mean->data[i] * s;
-    }
-    return 0;
-  }
-
-  // conv weight (N, Cin, taps) [or (N, Cin)] -> [N][tap*Cin + ci], rows padded to a multiple of 32
-  int add_conv(const std::map<std::string, HostTensor>& sd, const std::string& prefix, int N,
-               int Cin, int taps, bool conv3d, const std::string& bn_prefix, ConvW* out) {
-    int err = 0;
-    const HostTensor* wt = conv3d ? get(sd, prefix + ".weight", {N, Cin, taps}, &err)
-                                  : get(sd, prefix + ".weight", {N, Cin}, &err);
-    if (!wt) return err;
-    const HostTensor* bs = get(sd, prefix + ".bias", {N}, &err);
-    if (!bs) return err;
-    out->N = N; out->Cin = Cin; out->taps = taps;
-    out->ldw = round_up(Cin * taps, 32);
-    std::vector<float> packed((size_t)N * out->ldw, 0.f);
-    for (int n = 0; n < N; ++n)
-      for (int ci = 0; ci < Cin; ++ci)
-        for (int j = 0; j < taps; ++j)
-          packed[(size_t)n * out->ldw + (size_t)j * Cin + ci] =
-              wt->data[((size_t)n * Cin + ci) * taps + j];
-    out->w = arena.add(packed);
-    out->b = arena.add(bs->data);
-    out->has_b = true;
-    if (!bn_prefix.empty()) {
-      std::vector<double> sc, sh;
-      if ((err = bn_affine(sd, bn_prefix, N, &sc, &sh))) return err;
-      std::vector<float> f(sc.begin(), sc.end()), g(sh.begin(), sh.end());
-      out->scale = arena.add(f);
-      out->shift = arena.add(g);
-      out->has_bn = true;
-    }
-    return 0;
-  }
-
-  int finalize(const std::map<std::string, HostTensor>& sd, int max_batch,
-               int max_frames) override {
-    int err = 0;
-    zeros_off = arena.add(nullptr, 64);
-    if ((err = add_conv(sd, "layer1.conv", C, feat_dim, 5, true, "layer1.bn", &layer1))) return err;
+    if ((err = pack_conv1d(sd, "layer1.conv", C, feat_dim, 5, true, "", "layer1.bn", &layer1))) return err;
     for (int L = 0; L < 3; ++L) {
       std::string p = "layer" + std::to_string(L + 2) + ".se_res2block";
-      if ((err = add_conv(sd, p + ".0.conv", C, C, 1, true, p + ".0.bn", &blk0[L]))) return err;
+      if ((err = pack_conv1d(sd, p + ".0.conv", C, C, 1, true, "", p + ".0.bn", &blk0[L]))) return err;
       for (int i = 0; i < 7; ++i)
-        if ((err = add_conv(sd, p + ".1.convs." + std::to_string(i), w, w, 3, true,
-                            p + ".1.bns." + std::to_string(i), &res2[L][i])))
+        if ((err = pack_conv1d(sd, p + ".1.convs." + std::to_string(i), w, w, 3, true, "",
+                               p + ".1.bns." + std::to_string(i), &res2[L][i])))
           return err;
-      if ((err = add_conv(sd, p + ".2.conv", C, C, 1, true, p + ".2.bn", &blk2[L]))) return err;
+      if ((err = pack_conv1d(sd, p + ".2.conv", C, C, 1, true, "", p + ".2.bn", &blk2[L]))) return err;
       const HostTensor* t;
       if (!(t = get(sd, p + ".3.linear1.weight", {128, C}, &err))) return err;
       se_w1[L] = arena.add(t->data);
-      if (!(t = get(sd, p + ".3.linear1.bias", {128}, &err))) return err;
-      se_b1[L] = arena.add(t->data);
+      if ((err = add_vec(sd, p + ".3.linear1.bias", 128, &se_b1[L]))) return err;
       if (!(t = get(sd, p + ".3.linear2.weight", {C, 128}, &err))) return err;
       se_w2[L] = arena.add(t->data);
-      if (!(t = get(sd, p + ".3.linear2.bias", {C}, &err))) return err;
-      se_b2[L] = arena.add(t->data);
+      if ((err = add_vec(sd, p + ".3.linear2.bias", C, &se_b2[L]))) return err;
     }
-    if ((err = add_conv(sd, "conv", 1536, 3 * C, 1, true, "", &catconv))) return err;
-    if ((err = add_conv(sd, "pool.linear1", 128, glob ? 4608 : 1536, 1, true, "", &pool1)))
+    if ((err = pack_conv1d(sd, "conv", 1536, 3 * C, 1, true, "", "", &catconv))) return err;
+    if ((err = pack_conv1d(sd, "pool.linear1", 128, glob ? 4608 : 1536, 1, true, "", "", &pool1)))
       return err;
-    if ((err = add_conv(sd, "pool.linear2", 1536, 128, 1, true, "", &pool2))) return err;
+    if ((err = pack_conv1d(sd, "pool.linear2", 1536, 128, 1, true, "", "", &pool2))) return err;
     // bn (3072) -> linear (E x 3072) [-> bn2]: folded in float64
     {
       std::vector<double> sc, sh;
@@ -184,21 +81,16 @@ struct EcapaModel : Model {
       for (int o = 0; o < embed_dim; ++o) {
         double acc = lb->data[o];
         for (int k = 0; k < 3072; ++k) {
-          double wv = lw->data[(size_t)o * 3072 + k];
+          const double wv = lw->data[(size_t)o * 3072 + k];
           acc += wv * sh[k];
           W[(size_t)o * 3072 + k] = (float)(wv * sc[k] * s2[o]);
         }
         B[o] = (float)(acc * s2[o] + t2[o]);
       }
-      final_lin.N = embed_dim; final_lin.Cin = 3072; final_lin.taps = 1; final_lin.ldw = 3072;
+      final_lin.N = embed_dim; final_lin.Cin = 3072; final_lin.ldw = 3072;
       final_lin.w = arena.add(W);
       final_lin.b = arena.add(B);
       final_lin.has_b = true;
-    }
-    hipError_t he = arena.upload();
-    if (he != hipSuccess) {
-      set_error("weight upload failed: %s", hipGetErrorString(he));
-      return WS_ERR_HIP;
     }
 
     maxB = max_batch; maxT = max_frames;
@@ -210,70 +102,13 @@ struct EcapaModel : Model {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * embed_dim), o_feats = take(M * feat_dim);
-    he = ws.alloc(total * sizeof(float));
-    if (he != hipSuccess) {
-      set_error("workspace allocation of %zu MB failed: %s", total * 4 >> 20, hipGetErrorString(he));
-      return WS_ERR_HIP;
-    }
+    if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
     h = base + o_h; att = base + o_att; e = base + o_e; se_s = base + o_s; stats = base + o_stats;
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
     feats_ws = base + o_feats;
     return 0;
-  }
-
-  float* feats_workspace() override { return feats_ws; }
-  int max_batch() const override { return maxB; }
-  int max_frames() const override { return maxT; }
-
-  // ------------------------------------------------------------------------------- launch helper
-  ConvGemmParams conv1d(const ConvW& cw, const float* A, int lda, int a_off, float* D, int ldd,
-                        int d_off, int B, int T, int dil, int act) const {
-    ConvGemmParams p;
-    std::memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = lda; p.a_off = a_off;
-    p.W = arena.at(cw.w); p.ldw = cw.ldw;
-    p.D = D; p.ldd = ldd; p.d_off = d_off;
-    p.M = B * T; p.N = cw.N; p.K = cw.Cin * cw.taps; p.Cin = cw.Cin;
-    p.Hin = 1; p.Hout = 1; p.Win = T; p.Wout = T;
-    p.stride_h = 1; p.stride_w = 1; p.kh = 1; p.kw = cw.taps; p.dil_h = 1; p.dil_w = dil;
-    p.pad_h = 0; p.pad_w = dil * (cw.taps / 2);
-    p.bias = cw.has_b ? arena.at(cw.b) : nullptr;
-    p.act = act;
-    if (cw.has_bn) { p.post_scale = arena.at(cw.scale); p.post_shift = arena.at(cw.shift); }
-    p.splitk = 1;
-    p.zeros = arena.at(zeros_off);
-    return p;
-  }
-
-#define WS_LAUNCH(expr)                                                               \
-  do {                                                                                \
-    hipError_t _e = (expr);                                                           \
-    if (_e != hipSuccess) {                                                           \
-      set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
-      return WS_ERR_HIP;                                                              \
-    }                                                                                 \
-  } while (0)
-
-  // conv-GEMM launch with optional event timing (class 0/1 = MFMA tile variant, 3 = split-K)
-  hipError_t gemm(const ConvGemmParams& p, hipStream_t st) {
-    if (prof.enabled) {
-      const double flops = 2.0 * p.M * (double)p.N * p.K;
-      const double bytes = 4.0 * ((double)p.M * p.Cin * (p.A2 ? 2 : 1) + (double)p.N * p.K +
-                                  (double)p.M * p.N);
-      prof.begin(p.splitk > 1 ? 3 : (p.N <= 64 ? 1 : 0), flops, bytes, st);
-    }
-    hipError_t e = launch_conv_gemm(p, st);
-    prof.end(st);
-    return e;
-  }
-  template <typename F>
-  hipError_t other(double bytes, hipStream_t st, F&& f) {
-    prof.begin(2, 0.0, bytes, st);
-    hipError_t e = f();
-    prof.end(st);
-    return e;
   }
 
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
@@ -323,11 +158,8 @@ struct EcapaModel : Model {
       return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st);
     }));
     // BN + Linear (+bn2), folded: split-K GEMM over K = 3072
-    ConvGemmParams f = conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE);
-    f.splitk = kSplitK;
-    f.partial = partial;
-    WS_LAUNCH(gemm(f, st));
-    WS_LAUNCH(launch_splitk_reduce(f, st));
+    WS_LAUNCH(gemm_splitk(conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
+                          partial, kSplitK, st));
     return 0;
   }
 
@@ -336,13 +168,8 @@ struct EcapaModel : Model {
       set_error("num_frames %d outside the finalized capacity [1, %d]", frames, maxT);
       return WS_ERR_CAPACITY;
     }
-    // chunk so that chunk_B * frames <= maxB * maxT
-    const long long cap = (long long)maxB * maxT;
-    int chunk = (int)(cap / frames);
-    if (chunk > 4 * maxB) chunk = 4 * maxB;      // per-utterance buffers are sized 1x maxB ... keep safe
-    if (chunk > maxB) chunk = maxB;
-    for (int b0 = 0; b0 < batch; b0 += chunk) {
-      const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+    for (int b0 = 0; b0 < batch; b0 += maxB) {
+      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
       int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
                             emb + (size_t)b0 * embed_dim, st);
       if (r) return r;

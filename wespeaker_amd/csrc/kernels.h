@@ -16,6 +16,9 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 struct ConvGemmParams {
   const float* A;  int lda;  int a_off;       // input rows: lda floats per pixel
   const float* A2; int lda2; int a2_off;      // optional second input, added element-wise to A
+  const float* pre_scale; const float* pre_shift;   // optional pre-activation on A (CAM++ BN-ReLU
+                                              // before the conv): a = relu(A*pre_scale[ci] + pre_shift[ci]),
+                                              // applied to in-bounds pixels only (padding stays 0)
   const float* W;  int ldw;                   // [N][ldw]; ldw >= taps*Cin, multiple of 32, zero padded
   float* D;  int ldd;  int d_off;             // output rows
   float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
@@ -28,6 +31,8 @@ struct ConvGemmParams {
   const float* residual; int ldr; int r_off;  // optional, added before the activation
   int act;
   const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
+  const float* seg_scale; int seg_len; int segs_per_img;  // optional y *= seg_scale[(img*segs + ox/seg_len)][n]
+                                              // (CAM++ context mask, campplus.py:110-115)
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
 };
@@ -53,6 +58,21 @@ hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C
 // -> pooled[b] = [mean(C) | std(C)]
 hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
                             float* pooled, hipStream_t stream);
+
+// ResNet / FCM stem: Conv2d(1 -> C, 3x3, pad 1, no bias) + folded BN + ReLU, reading the (B, T, F)
+// feature tensor as the (F x T) image and writing channels-last [B][F][T][C].  w: [C][9], b: [C].
+hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
+                               const float* b, int C, float* out, hipStream_t stream);
+// TSTP (pooling_layers.py:78-85) over channels-last x[(b*F + f)*T + t][c]: mean and
+// sqrt(unbiased var + 1e-7) over t; optional pre-activation relu(x*pre_scale[c] + pre_shift[c])
+// (CAM++ out_nonlinear).  pooled[b][c*F + f] = mean, pooled[b][C*F + c*F + f] = std.
+hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
+                       const float* pre_shift, float* pooled, hipStream_t stream);
+// CAM++ context (campplus.py:108-135): ctx = mean_T(h) + segmean_100(h); m = sigmoid(W2 relu(W1 ctx + b1) + b2)
+// h: [B*T][C] (C = 128); mask out: [B][segs][Cout]
+hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
+                              const float* w1, const float* b1, int hidden, const float* w2,
+                              const float* b2, int Cout, float* mask, hipStream_t stream);
 
 // ---- frontend
 struct FbankTables {

@@ -1,0 +1,250 @@
+// Shared host-side machinery of the model engines (ECAPA-TDNN, ResNet, CAM++): weight ingestion by
+// the reference's state_dict names, BatchNorm folding, conv-GEMM parameter construction and the
+// event-profiled launch wrappers.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace wsamd {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct ConvW {        // one conv / linear layer resident on the device
+  size_t w = 0, b = 0, scale = 0, shift = 0;
+  bool has_b = false, has_post = false;
+  int N = 0, Cin = 0, kh = 1, kw = 1, ldw = 0;
+  int taps() const { return kh * kw; }
+};
+
+#define WS_LAUNCH(expr)                                                                            \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__);    \
+      return WS_ERR_HIP;                                                                           \
+    }                                                                                              \
+  } while (0)
+
+struct ModelBase : Model {
+  std::string name;
+  int feat_dim = 0, embed_dim = 0;
+  int maxB = 0, maxT = 0;
+  WeightArena arena;
+  size_t zeros_off = 0;
+  DevBuf ws;
+  float* feats_ws = nullptr;
+  typedef std::map<std::string, HostTensor> SD;
+
+  ModelBase(const std::string& n, int fd, int ed) : name(n), feat_dim(fd), embed_dim(ed) {
+    zeros_off = arena.add(nullptr, 64);
+  }
+  float* feats_workspace() override { return feats_ws; }
+  int max_batch() const override { return maxB; }
+  int max_frames() const override { return maxT; }
+
+  // ------------------------------------------------------------------------- tensor lookup
+  const HostTensor* get(const SD& sd, const std::string& key, std::vector<int64_t> want, int* err) {
+    auto it = sd.find(key);
+    if (it == sd.end()) {
+      set_error("missing tensor '%s' for model %s", key.c_str(), name.c_str());
+      *err = WS_ERR_MISSING_TENSOR;
+      return nullptr;
+    }
+    if (it->second.shape != want) {
+      std::string got, exp;
+      for (auto s : it->second.shape) got += std::to_string(s) + ",";
+      for (auto s : want) exp += std::to_string(s) + ",";
+      set_error("tensor '%s' has shape (%s) but model %s expects (%s)", key.c_str(), got.c_str(),
+                name.c_str(), exp.c_str());
+      *err = WS_ERR_SHAPE;
+      return nullptr;
+    }
+    return &it->second;
+  }
+
+  // eval-mode BatchNorm (eps 1e-5) -> y = x*scale + shift, in float64
+  int bn_affine(const SD& sd, const std::string& prefix, int n, std::vector<double>* scale,
+                std::vector<double>* shift, bool affine = true) {
+    int err = 0;
+    const HostTensor* mean = get(sd, prefix + ".running_mean", {n}, &err);
+    if (!mean) return err;
+    const HostTensor* var = get(sd, prefix + ".running_var", {n}, &err);
+    if (!var) return err;
+    const HostTensor *g = nullptr, *bt = nullptr;
+    if (affine) {
+      if (!(g = get(sd, prefix + ".weight", {n}, &err))) return err;
+      if (!(bt = get(sd, prefix + ".bias", {n}, &err))) return err;
+    }
+    scale->resize(n);
+    shift->resize(n);
+    for (int i = 0; i < n; ++i) {
+      const double inv = 1.0 / std::sqrt((double)var->data[i] + 1e-5);
+      const double s = (g ? (double)g->data[i] : 1.0) * inv;
+      (*scale)[i] = s;
+      (*shift)[i] = (bt ? (double)bt->data[i] : 0.0) - (double)mean->data[i] * s;
+    }
+    return 0;
+  }
+
+  int add_vec(const SD& sd, const std::string& key, int n, size_t* off) {
+    int err = 0;
+    const HostTensor* t = get(sd, key, {n}, &err);
+    if (!t) return err;
+    *off = arena.add(t->data);
+    return 0;
+  }
+
+  // per-channel BN-ReLU that precedes a conv (CAM++ pre-activation): scale/shift vectors
+  int add_bn_vectors(const SD& sd, const std::string& prefix, int n, size_t* scale, size_t* shift,
+                     bool affine = true) {
+    std::vector<double> sc, sh;
+    int err = bn_affine(sd, prefix, n, &sc, &sh, affine);
+    if (err) return err;
+    std::vector<float> f(sc.begin(), sc.end()), g(sh.begin(), sh.end());
+    *scale = arena.add(f);
+    *shift = arena.add(g);
+    return 0;
+  }
+
+  // Generic conv / linear packer.
+  //   wshape : expected shape of `<prefix>.weight`
+  //   src(n, tap, ci) -> flat index into the source weight
+  //   bias   : `<prefix>.bias` is required iff has_bias
+  //   fold_bn: BN applied directly to the conv output (conv -> BN): folded into W and bias
+  //   post_bn: BN applied after the activation (ECAPA conv -> ReLU -> BN): epilogue affine
+  int pack_conv(const SD& sd, const std::string& prefix, std::vector<int64_t> wshape, int N, int Cin,
+                int kh, int kw, const std::function<size_t(int, int, int)>& src, bool has_bias,
+                const std::string& fold_bn, const std::string& post_bn, ConvW* out,
+                bool fold_affine = true) {
+    int err = 0;
+    const HostTensor* wt = get(sd, prefix + ".weight", wshape, &err);
+    if (!wt) return err;
+    const HostTensor* bs = nullptr;
+    if (has_bias && !(bs = get(sd, prefix + ".bias", {N}, &err))) return err;
+    std::vector<double> fsc(N, 1.0), fsh(N, 0.0);
+    if (!fold_bn.empty() && (err = bn_affine(sd, fold_bn, N, &fsc, &fsh, fold_affine))) return err;
+    out->N = N; out->Cin = Cin; out->kh = kh; out->kw = kw;
+    const int taps = kh * kw;
+    out->ldw = round_up(Cin * taps, 32);
+    std::vector<float> packed((size_t)N * out->ldw, 0.f);
+    for (int n = 0; n < N; ++n)
+      for (int tp = 0; tp < taps; ++tp)
+        for (int ci = 0; ci < Cin; ++ci)
+          packed[(size_t)n * out->ldw + (size_t)tp * Cin + ci] =
+              (float)((double)wt->data[src(n, tp, ci)] * fsc[n]);
+    out->w = arena.add(packed);
+    if (has_bias || !fold_bn.empty()) {
+      std::vector<float> b(N);
+      for (int n = 0; n < N; ++n) b[n] = (float)((bs ? (double)bs->data[n] : 0.0) * fsc[n] + fsh[n]);
+      out->b = arena.add(b);
+      out->has_b = true;
+    }
+    if (!post_bn.empty()) {
+      std::vector<double> sc, sh;
+      if ((err = bn_affine(sd, post_bn, N, &sc, &sh))) return err;
+      std::vector<float> f(sc.begin(), sc.end()), g(sh.begin(), sh.end());
+      out->scale = arena.add(f);
+      out->shift = arena.add(g);
+      out->has_post = true;
+    }
+    return 0;
+  }
+
+  // Conv1d weight (N, Cin, k) -> [n][tap*Cin + ci]
+  int pack_conv1d(const SD& sd, const std::string& prefix, int N, int Cin, int k, bool has_bias,
+                  const std::string& fold_bn, const std::string& post_bn, ConvW* out) {
+    return pack_conv(sd, prefix, {N, Cin, k}, N, Cin, 1, k,
+                     [=](int n, int tp, int ci) { return ((size_t)n * Cin + ci) * k + tp; }, has_bias,
+                     fold_bn, post_bn, out);
+  }
+  // Conv2d weight (N, Cin, kh, kw) -> [n][(ty*kw + tx)*Cin + ci]
+  int pack_conv2d(const SD& sd, const std::string& prefix, int N, int Cin, int kh, int kw,
+                  const std::string& fold_bn, ConvW* out) {
+    return pack_conv(sd, prefix, {N, Cin, kh, kw}, N, Cin, kh, kw,
+                     [=](int n, int tp, int ci) { return ((size_t)n * Cin + ci) * kh * kw + tp; },
+                     false, fold_bn, "", out);
+  }
+  // Linear weight (N, Cin)
+  int pack_linear(const SD& sd, const std::string& prefix, int N, int Cin, bool has_bias, ConvW* out) {
+    return pack_conv(sd, prefix, {N, Cin}, N, Cin, 1, 1,
+                     [=](int n, int, int ci) { return (size_t)n * Cin + ci; }, has_bias, "", "", out);
+  }
+
+  int upload_and_alloc(size_t ws_floats) {
+    hipError_t he = arena.upload();
+    if (he != hipSuccess) {
+      set_error("weight upload failed: %s", hipGetErrorString(he));
+      return WS_ERR_HIP;
+    }
+    he = ws.alloc(ws_floats * sizeof(float));
+    if (he != hipSuccess) {
+      set_error("workspace allocation of %zu MB failed: %s", (ws_floats * 4) >> 20,
+                hipGetErrorString(he));
+      return WS_ERR_HIP;
+    }
+    return 0;
+  }
+
+  // --------------------------------------------------------------------- conv-GEMM parameters
+  // generic 2-D convolution over images [B][Hin][Win][lda]
+  ConvGemmParams conv2d(const ConvW& cw, const float* A, int lda, int a_off, float* D, int ldd,
+                        int d_off, int B, int Hin, int Win, int stride_h, int stride_w, int dil_h,
+                        int dil_w, int pad_h, int pad_w, int act) const {
+    ConvGemmParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.a_off = a_off;
+    p.W = arena.at(cw.w); p.ldw = cw.ldw;
+    p.D = D; p.ldd = ldd; p.d_off = d_off;
+    p.Hin = Hin; p.Win = Win;
+    p.Hout = (Hin + 2 * pad_h - dil_h * (cw.kh - 1) - 1) / stride_h + 1;
+    p.Wout = (Win + 2 * pad_w - dil_w * (cw.kw - 1) - 1) / stride_w + 1;
+    p.M = B * p.Hout * p.Wout; p.N = cw.N; p.K = cw.Cin * cw.taps(); p.Cin = cw.Cin;
+    p.stride_h = stride_h; p.stride_w = stride_w; p.kh = cw.kh; p.kw = cw.kw;
+    p.dil_h = dil_h; p.dil_w = dil_w; p.pad_h = pad_h; p.pad_w = pad_w;
+    p.bias = cw.has_b ? arena.at(cw.b) : nullptr;
+    p.act = act;
+    if (cw.has_post) { p.post_scale = arena.at(cw.scale); p.post_shift = arena.at(cw.shift); }
+    p.splitk = 1;
+    p.zeros = arena.at(zeros_off);
+    return p;
+  }
+  // Conv1d over time ("same" padding for odd kernels), rows = B*T
+  ConvGemmParams conv1d(const ConvW& cw, const float* A, int lda, int a_off, float* D, int ldd,
+                        int d_off, int B, int T, int dil, int act) const {
+    return conv2d(cw, A, lda, a_off, D, ldd, d_off, B, 1, T, 1, 1, 1, dil, 0, dil * (cw.kw / 2), act);
+  }
+
+  // ------------------------------------------------------------------------- profiled launches
+  hipError_t gemm(const ConvGemmParams& p, hipStream_t st) {
+    if (prof.enabled) {
+      const double flops = 2.0 * p.M * (double)p.N * p.K;
+      const double bytes = 4.0 * ((double)p.M * p.Cin * (p.A2 ? 2 : 1) + (double)p.N * p.K +
+                                  (double)p.M * p.N);
+      prof.begin(p.splitk > 1 ? 3 : (p.N <= 64 ? 1 : 0), flops, bytes, st);
+    }
+    hipError_t e = launch_conv_gemm(p, st);
+    prof.end(st);
+    return e;
+  }
+  // split-K GEMM + reduce (M small, K large: the embedding layers)
+  hipError_t gemm_splitk(ConvGemmParams p, float* partial, int splitk, hipStream_t st) {
+    p.splitk = splitk;
+    p.partial = partial;
+    hipError_t e = gemm(p, st);
+    if (e != hipSuccess) return e;
+    return launch_splitk_reduce(p, st);
+  }
+  template <typename F>
+  hipError_t other(double bytes, hipStream_t st, F&& f) {
+    prof.begin(2, 0.0, bytes, st);
+    hipError_t e = f();
+    prof.end(st);
+    return e;
+  }
+};
+
+}  // namespace wsamd

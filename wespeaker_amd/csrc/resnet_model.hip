@@ -1,0 +1,229 @@
+// ResNet speaker-embedding forward (ResNet18/34/50/101/152/221/293) scheduled onto the gfx950
+// kernels.
+//
+// Reference (file:line in wenet-e2e/wespeaker):
+//   wespeaker/models/resnet.py:110-204  ResNet (conv1+bn1+relu, 4 stages, TSTP, seg_1 [, seg_bn_1, seg_2])
+//   wespeaker/models/resnet.py:35-69    BasicBlock;  :72-107 Bottleneck (stride on the 3x3)
+//   wespeaker/models/resnet.py:207-260  ctor names
+//   wespeaker/models/pooling_layers.py:78-85 TSTP
+//
+// Layout: the (B, T, F) feature tensor is the single-channel (F x T) image; every activation is
+// channels-last [b][f][t][c] fp32, so each Conv2d is one implicit GEMM with K = kh*kw*Cin contiguous.
+// conv -> BN has no non-linearity in between, so every BatchNorm2d is folded into its conv's
+// weights + bias on the host (float64); the residual add and ReLU live in the GEMM epilogue.
+#include "model_common.h"
+
+namespace wsamd {
+
+namespace {
+
+struct Layout { const char* name; bool bottleneck; int blocks[4]; };
+const Layout kLayouts[] = {
+    {"ResNet18", false, {2, 2, 2, 2}},   {"ResNet34", false, {3, 4, 6, 3}},
+    {"ResNet50", true, {3, 4, 6, 3}},    {"ResNet101", true, {3, 4, 23, 3}},
+    {"ResNet152", true, {3, 8, 36, 3}},  {"ResNet221", true, {6, 16, 48, 3}},
+    {"ResNet293", true, {10, 20, 64, 3}},
+};
+
+struct Block {
+  ConvW c1, c2, c3, sc;
+  bool has_sc = false;
+  int stride = 1, in_planes = 0, planes = 0;
+};
+
+struct ResNetModel : ModelBase {
+  Layout lay;
+  int exp = 1;
+  size_t stem_w = 0, stem_b = 0;
+  std::vector<Block> blocks;
+  ConvW seg1, seg2;
+  bool two_emb = false;
+  size_t seg_bn_scale = 0, seg_bn_shift = 0;
+  float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *pooled = nullptr, *partial = nullptr, *emb_a = nullptr;
+  int stats_dim = 0;
+  static constexpr int kSplitK = 16;
+
+  ResNetModel(const Layout& l, int fd, int ed) : ModelBase(l.name, fd, ed), lay(l) {
+    exp = l.bottleneck ? 4 : 1;
+  }
+
+  bool wants(const std::string& key) const override {
+    if (key.size() > 20 && key.compare(key.size() - 19, 19, "num_batches_tracked") == 0)
+      return false;
+    static const char* prefixes[] = {"conv1.", "bn1.", "layer1.", "layer2.", "layer3.", "layer4.",
+                                     "seg_1.", "seg_bn_1.", "seg_2."};
+    for (auto p : prefixes)
+      if (key.compare(0, std::strlen(p), p) == 0) return true;
+    return false;
+  }
+
+  int finalize(const SD& sd, int max_batch, int max_frames) override {
+    int err = 0;
+    const int m = 32;
+    if (feat_dim % 8) {
+      set_error("ResNet needs feat_dim %% 8 == 0, got %d", feat_dim);
+      return WS_ERR_INVALID_ARG;
+    }
+    {   // stem: Conv2d(1, 32, 3x3) + bn1 folded -> [C][9] + [C]
+      const HostTensor* wt = get(sd, "conv1.weight", {m, 1, 3, 3}, &err);
+      if (!wt) return err;
+      std::vector<double> sc, sh;
+      if ((err = bn_affine(sd, "bn1", m, &sc, &sh))) return err;
+      std::vector<float> wf(m * 9), bf(m);
+      for (int c = 0; c < m; ++c) {
+        for (int k = 0; k < 9; ++k) wf[c * 9 + k] = (float)(wt->data[c * 9 + k] * sc[c]);
+        bf[c] = (float)sh[c];
+      }
+      stem_w = arena.add(wf);
+      stem_b = arena.add(bf);
+    }
+    int in_planes = m;
+    for (int s = 0; s < 4; ++s) {
+      const int planes = m << s;
+      for (int b = 0; b < lay.blocks[s]; ++b) {
+        Block blk;
+        blk.stride = (b == 0 && s > 0) ? 2 : 1;
+        blk.in_planes = in_planes; blk.planes = planes;
+        const std::string p = "layer" + std::to_string(s + 1) + "." + std::to_string(b);
+        if (lay.bottleneck) {
+          if ((err = pack_conv2d(sd, p + ".conv1", planes, in_planes, 1, 1, p + ".bn1", &blk.c1))) return err;
+          if ((err = pack_conv2d(sd, p + ".conv2", planes, planes, 3, 3, p + ".bn2", &blk.c2))) return err;
+          if ((err = pack_conv2d(sd, p + ".conv3", planes * 4, planes, 1, 1, p + ".bn3", &blk.c3))) return err;
+        } else {
+          if ((err = pack_conv2d(sd, p + ".conv1", planes, in_planes, 3, 3, p + ".bn1", &blk.c1))) return err;
+          if ((err = pack_conv2d(sd, p + ".conv2", planes, planes, 3, 3, p + ".bn2", &blk.c2))) return err;
+        }
+        if (blk.stride != 1 || in_planes != planes * exp) {
+          blk.has_sc = true;
+          if ((err = pack_conv2d(sd, p + ".shortcut.0", planes * exp, in_planes, 1, 1,
+                                 p + ".shortcut.1", &blk.sc)))
+            return err;
+        }
+        in_planes = planes * exp;
+        blocks.push_back(blk);
+      }
+    }
+    stats_dim = (feat_dim / 8) * m * 8 * exp;          // C_last * F_last   (resnet.py:123)
+    if ((err = pack_linear(sd, "seg_1", embed_dim, 2 * stats_dim, true, &seg1))) return err;
+    two_emb = sd.count("seg_2.weight") > 0;
+    if (two_emb) {
+      if ((err = add_bn_vectors(sd, "seg_bn_1", embed_dim, &seg_bn_scale, &seg_bn_shift, false))) return err;
+      seg1.scale = seg_bn_scale; seg1.shift = seg_bn_shift;     // relu -> BN(affine=False) epilogue
+      if ((err = pack_linear(sd, "seg_2", embed_dim, embed_dim, true, &seg2))) return err;
+    }
+
+    maxB = max_batch; maxT = max_frames;
+    // largest activation: stage-1 output (F x T x 32*exp); scratch planes are never larger
+    const size_t act = (size_t)maxB * feat_dim * maxT * (size_t)(m * exp);
+    size_t total = 0;
+    auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
+    size_t ob[4];
+    for (int i = 0; i < 4; ++i) ob[i] = take(act);
+    size_t o_pool = take((size_t)maxB * 2 * stats_dim),
+           o_part = take((size_t)kSplitK * maxB * embed_dim), o_emba = take((size_t)maxB * embed_dim),
+           o_feats = take((size_t)maxB * maxT * feat_dim);
+    if ((err = upload_and_alloc(total))) return err;
+    float* base = ws.as<float>();
+    for (int i = 0; i < 4; ++i) buf[i] = base + ob[i];
+    pooled = base + o_pool; partial = base + o_part; emb_a = base + o_emba; feats_ws = base + o_feats;
+    return 0;
+  }
+
+  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
+    int H = feat_dim, W = T;
+    float* x = buf[0];
+    WS_LAUNCH(other(4.0 * B * H * (double)W * 33, st, [&] {
+      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, x, st);
+    }));
+    int cur = 0;          // index of the buffer holding x
+    for (const Block& blk : blocks) {
+      float* t1 = buf[(cur + 1) & 3];
+      float* t2 = buf[(cur + 2) & 3];
+      float* out = buf[(cur + 3) & 3];
+      const int s = blk.stride;
+      const int Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
+      const int Cx = blk.in_planes, P = blk.planes, Co = P * exp;
+      const float* res = x;
+      int ldr = Cx;
+      if (blk.has_sc) {     // 1x1 stride-s conv + BN on the block input
+        WS_LAUNCH(gemm(conv2d(blk.sc, x, Cx, 0, t2, Co, 0, B, H, W, s, s, 1, 1, 0, 0, ACT_NONE), st));
+        res = t2;
+        ldr = Co;
+      }
+      if (lay.bottleneck) {
+        WS_LAUNCH(gemm(conv2d(blk.c1, x, Cx, 0, t1, P, 0, B, H, W, 1, 1, 1, 1, 0, 0, ACT_RELU), st));
+        WS_LAUNCH(gemm(conv2d(blk.c2, t1, P, 0, out, P, 0, B, H, W, s, s, 1, 1, 1, 1, ACT_RELU), st));
+        ConvGemmParams p3 = conv2d(blk.c3, out, P, 0, t1, Co, 0, B, Ho, Wo, 1, 1, 1, 1, 0, 0, ACT_RELU);
+        p3.residual = res; p3.ldr = ldr; p3.r_off = 0;
+        WS_LAUNCH(gemm(p3, st));
+        cur = (cur + 1) & 3;            // result in t1
+      } else {
+        WS_LAUNCH(gemm(conv2d(blk.c1, x, Cx, 0, t1, P, 0, B, H, W, s, s, 1, 1, 1, 1, ACT_RELU), st));
+        ConvGemmParams p2 = conv2d(blk.c2, t1, P, 0, out, Co, 0, B, Ho, Wo, 1, 1, 1, 1, 1, 1, ACT_RELU);
+        p2.residual = res; p2.ldr = ldr; p2.r_off = 0;
+        WS_LAUNCH(gemm(p2, st));
+        cur = (cur + 3) & 3;            // result in out
+      }
+      x = buf[cur];
+      H = Ho; W = Wo;
+    }
+    const int Cl = 256 * exp;           // channels of the last stage
+    WS_LAUNCH(other(8.0 * B * H * (double)W * Cl, st, [&] {
+      return launch_tstp(x, Cl, B, H, W, Cl, nullptr, nullptr, pooled, st);
+    }));
+    if (!two_emb) {
+      WS_LAUNCH(gemm_splitk(conv1d(seg1, pooled, 2 * stats_dim, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
+                            partial, kSplitK, st));
+    } else {            // embed_b = seg_2(seg_bn_1(relu(seg_1(stats))))   (resnet.py:198-202)
+      ConvGemmParams a = conv1d(seg1, pooled, 2 * stats_dim, 0, emb_a, embed_dim, 0, B, 1, 1, ACT_RELU);
+      a.post_scale = arena.at(seg_bn_scale); a.post_shift = arena.at(seg_bn_shift);
+      WS_LAUNCH(gemm_splitk(a, partial, kSplitK, st));
+      WS_LAUNCH(gemm(conv1d(seg2, emb_a, embed_dim, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE), st));
+    }
+    return 0;
+  }
+
+  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
+    if (frames > maxT || frames < 2) {
+      set_error("num_frames %d outside the finalized capacity [2, %d]", frames, maxT);
+      return WS_ERR_CAPACITY;
+    }
+    for (int b0 = 0; b0 < batch; b0 += maxB) {
+      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
+      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
+                            emb + (size_t)b0 * embed_dim, st);
+      if (r) return r;
+    }
+    return 0;
+  }
+
+  double flops(int batch, int T) const override {
+    double macs = 0;
+    int H = feat_dim, W = T;
+    macs += (double)H * W * 9 * 32;
+    for (const Block& blk : blocks) {
+      const int s = blk.stride, Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
+      const double in = blk.in_planes, P = blk.planes, Co = P * exp;
+      if (lay.bottleneck)
+        macs += (double)H * W * in * P + (double)Ho * Wo * 9 * P * P + (double)Ho * Wo * P * Co;
+      else
+        macs += (double)Ho * Wo * 9 * in * P + (double)Ho * Wo * 9 * P * P;
+      if (blk.has_sc) macs += (double)Ho * Wo * in * Co;
+      H = Ho; W = Wo;
+    }
+    macs += 2.0 * stats_dim * embed_dim;
+    if (two_emb) macs += (double)embed_dim * embed_dim;
+    return 2.0 * macs * batch;
+  }
+};
+
+}  // namespace
+
+Model* make_resnet(const std::string& model_name, int feat_dim, int embed_dim) {
+  for (const Layout& l : kLayouts)
+    if (model_name == l.name) return new ResNetModel(l, feat_dim, embed_dim);
+  return nullptr;
+}
+
+}  // namespace wsamd

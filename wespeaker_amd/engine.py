@@ -19,7 +19,8 @@ from . import _lib
 WINDOW_TYPES = {"hamming": 0, "povey": 1}
 
 SUPPORTED_MODELS = ("ECAPA_TDNN_c512", "ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c1024",
-                    "ECAPA_TDNN_GLOB_c1024")
+                    "ECAPA_TDNN_GLOB_c1024", "ResNet18", "ResNet34", "ResNet50", "ResNet101",
+                    "ResNet152", "ResNet221", "ResNet293", "CAMPPlus")
 
 DEFAULT_EMBED_DIM = {"ECAPA": 192, "ResNe": 256, "CAMPP": 512}
 
@@ -166,9 +167,16 @@ class NativeSpeakerModel:
         return emb
 
     def __call__(self, feats: torch.Tensor):
-        # ECAPA returns (out4, embed) in the reference (ecapa_tdnn.py:227-234); callers take [-1].
-        # The frame-level tensor is not materialised on this path.
-        return None, self.embed(feats)
+        """Return convention of the reference modules (callers use `outputs[-1] if tuple`):
+        ECAPA -> (out4, embed) (ecapa_tdnn.py:227-234), ResNet -> (tensor(0.0), embed_a) or
+        (embed_a, embed_b) (resnet.py:192-204), CAM++ -> tensor (campplus.py:409-413).
+        The leading element is not materialised on this path (None for ECAPA / two-layer ResNet)."""
+        emb = self.embed(feats)
+        if self.model_name.startswith("CAMPPlus"):
+            return emb
+        if self.model_name.startswith("ResNet"):
+            return torch.tensor(0.0), emb
+        return None, emb
 
     def extract(self, frontend: Frontend, wav: torch.Tensor, window_type="hamming", scale=1.0):
         """Fused wav -> fbank -> CMN -> forward (ws_extract).  wav (B, N) int16/float32."""

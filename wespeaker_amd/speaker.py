@@ -47,9 +47,13 @@ def load_model_pt(model_name_or_path: str, device=None, max_batch=64, max_frames
     pooling = model_args.pop("pooling_func", None)
     if config["model"].startswith("ECAPA") and pooling not in (None, "ASTP"):
         raise NotImplementedError("ECAPA-TDNN with pooling_func=%r (only ASTP)" % pooling)
+    if config["model"].startswith(("ResNet", "CAMPPlus")) and pooling not in (None, "TSTP"):
+        raise NotImplementedError("%s with pooling_func=%r (only TSTP)" % (config["model"], pooling))
     sd = _load_state_dict(os.path.join(model_dir, "avg_model.pt"))
     if model_args.pop("emb_bn", False) and "bn2.running_mean" not in sd:
         raise KeyError("emb_bn=True but bn2.* is missing from the checkpoint")
+    if model_args.pop("two_emb_layer", False) and "seg_2.weight" not in sd:
+        raise KeyError("two_emb_layer=True but seg_2.* is missing from the checkpoint")
     model = NativeSpeakerModel(config["model"], sd, device=device, max_batch=max_batch,
                                max_frames=max_frames, **model_args)
     model.frontend_type = frontend_type

@@ -112,10 +112,104 @@ def synth_ecapa_state_dict(model_name="ECAPA_TDNN_GLOB_c512", feat_dim=80, embed
     return g.sd
 
 
+RESNET_LAYOUTS = {      # reference resnet.py:207-260: (bottleneck, blocks per stage)
+    "ResNet18": (False, [2, 2, 2, 2]), "ResNet34": (False, [3, 4, 6, 3]),
+    "ResNet50": (True, [3, 4, 6, 3]), "ResNet101": (True, [3, 4, 23, 3]),
+    "ResNet152": (True, [3, 8, 36, 3]), "ResNet221": (True, [6, 16, 48, 3]),
+    "ResNet293": (True, [10, 20, 64, 3]),
+}
+
+
+def synth_resnet_state_dict(model_name="ResNet34", feat_dim=80, embed_dim=256,
+                            two_emb_layer=False, seed=42):
+    bottleneck, blocks = RESNET_LAYOUTS[model_name]
+    exp = 4 if bottleneck else 1
+    m = 32
+    g = _Init(seed)
+    g.conv("conv1", m, 1, 3, 3, bias=False)
+    g.bn("bn1", m)
+    in_planes = m
+    for s, nb in enumerate(blocks):
+        planes = m * (2 ** s)
+        for b in range(nb):
+            stride = (1 if s == 0 else 2) if b == 0 else 1
+            p = "layer%d.%d" % (s + 1, b)
+            if bottleneck:
+                g.conv(p + ".conv1", planes, in_planes, 1, 1, bias=False)
+                g.bn(p + ".bn1", planes)
+                g.conv(p + ".conv2", planes, planes, 3, 3, bias=False)
+                g.bn(p + ".bn2", planes)
+                g.conv(p + ".conv3", planes * 4, planes, 1, 1, bias=False, gain=0.02)
+                g.bn(p + ".bn3", planes * 4)
+            else:
+                g.conv(p + ".conv1", planes, in_planes, 3, 3, bias=False)
+                g.bn(p + ".bn1", planes)
+                g.conv(p + ".conv2", planes, planes, 3, 3, bias=False, gain=0.25)
+                g.bn(p + ".bn2", planes)
+            if stride != 1 or in_planes != planes * exp:
+                g.conv(p + ".shortcut.0", planes * exp, in_planes, 1, 1, bias=False, gain=1.0)
+                g.bn(p + ".shortcut.1", planes * exp)
+            in_planes = planes * exp
+    stats_dim = (feat_dim // 8) * m * 8 * exp * 2
+    g.linear("seg_1", embed_dim, stats_dim)
+    if two_emb_layer:
+        g.bn("seg_bn_1", embed_dim, affine=False)
+        g.linear("seg_2", embed_dim, embed_dim)
+    return g.sd
+
+
+def synth_campplus_state_dict(feat_dim=80, embed_dim=512, seed=42):
+    g = _Init(seed)
+    g.conv("head.conv1", 32, 1, 3, 3, bias=False)
+    g.bn("head.bn1", 32)
+    for layer in ("head.layer1", "head.layer2"):
+        for b in (0, 1):
+            p = "%s.%d" % (layer, b)
+            g.conv(p + ".conv1", 32, 32, 3, 3, bias=False)
+            g.bn(p + ".bn1", 32)
+            g.conv(p + ".conv2", 32, 32, 3, 3, bias=False, gain=0.5)
+            g.bn(p + ".bn2", 32)
+            if b == 0:
+                g.conv(p + ".shortcut.0", 32, 32, 1, 1, bias=False, gain=1.0)
+                g.bn(p + ".shortcut.1", 32)
+    g.conv("head.conv2", 32, 32, 3, 3, bias=False)
+    g.bn("head.bn2", 32)
+    ch = 32 * (feat_dim // 8)
+    g.conv("xvector.tdnn.linear", 128, ch, 5, bias=False)
+    g.bn("xvector.tdnn.nonlinear.batchnorm", 128)
+    ch = 128
+    for k, layers in enumerate((12, 24, 16)):
+        for j in range(layers):
+            p = "xvector.block%d.tdnnd%d" % (k + 1, j + 1)
+            cin = ch + 32 * j
+            g.bn(p + ".nonlinear1.batchnorm", cin)
+            g.conv(p + ".linear1", 128, cin, 1, bias=False)
+            g.bn(p + ".nonlinear2.batchnorm", 128)
+            g.conv(p + ".cam_layer.linear_local", 32, 128, 3, bias=False)
+            g.conv(p + ".cam_layer.linear1", 64, 128, 1)
+            g.conv(p + ".cam_layer.linear2", 32, 64, 1, gain=6.0)
+        ch = ch + 32 * layers
+        p = "xvector.transit%d" % (k + 1)
+        g.bn(p + ".nonlinear.batchnorm", ch)
+        g.conv(p + ".linear", ch // 2, ch, 1, bias=False)
+        ch //= 2
+    g.bn("xvector.out_nonlinear.batchnorm", ch)
+    g.conv("xvector.dense.linear", embed_dim, ch * 2, 1, bias=False, gain=1.0)
+    g.bn("xvector.dense.nonlinear.batchnorm", embed_dim, affine=False)
+    return g.sd
+
+
 def synth_state_dict(model_name, feat_dim=80, embed_dim=None, seed=42, **kw):
     if model_name.startswith("ECAPA_TDNN"):
+        kw.pop("pooling_func", None)
         return synth_ecapa_state_dict(model_name, feat_dim, embed_dim or 192, seed=seed, **kw)
-    raise KeyError("no synthetic weights for model %r yet" % model_name)
+    if model_name.startswith("ResNet"):
+        kw.pop("pooling_func", None)
+        return synth_resnet_state_dict(model_name, feat_dim, embed_dim or 256, seed=seed, **kw)
+    if model_name.startswith("CAMPPlus"):
+        kw.pop("pooling_func", None)
+        return synth_campplus_state_dict(feat_dim, embed_dim or 512, seed=seed)
+    raise KeyError("no synthetic weights for model %r" % model_name)
 
 
 def write_model_dir(model_dir, model_name, feat_dim=80, embed_dim=192, seed=42, **model_kw):
@@ -129,8 +223,7 @@ def write_model_dir(model_dir, model_name, feat_dim=80, embed_dim=192, seed=42, 
     torch.save(OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in sd.items()),
                os.path.join(model_dir, "avg_model.pt"))
     model_args = dict(feat_dim=feat_dim, embed_dim=embed_dim)
-    if model_name.startswith("ECAPA"):
-        model_args["pooling_func"] = "ASTP"
+    model_args["pooling_func"] = "ASTP" if model_name.startswith("ECAPA") else "TSTP"
     model_args.update(model_kw)
     cfg = {
         "model": model_name,
