@@ -106,7 +106,9 @@ double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
  * synchronises them and fills 4-element arrays indexed by kernel class
  * (0 = fp32-MFMA conv-GEMM 128x128 tile, 1 = 128x64 tile, 2 = reductions/element-wise,
  * 3 = split-K GEMM): summed milliseconds, algorithmic FLOPs, algorithmic bytes, launch counts.
- * Returns the number of classes. */
+ * `on` is a bit mask of the classes to record (0 = off, 0xF = all, 1 = only the dominant GEMM):
+ * timing events between kernels cost a few per cent of throughput, so the headline run records
+ * only the dominant kernel.  Returns the number of classes. */
 int ws_engine_profile_enable(ws_engine* eng, int on);
 int ws_engine_profile_read(ws_engine* eng, double* ms, double* flops, double* bytes, int* launches);
 

@@ -266,6 +266,7 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
 int ws_engine_profile_enable(ws_engine* eng, int on) {
   if (!eng) { set_error("ws_engine_profile_enable: invalid argument"); return WS_ERR_INVALID_ARG; }
   eng->model->prof.enabled = on != 0;
+  eng->model->prof.mask = on > 0 ? (unsigned)on : 0xFu;      // bit c = record kernel class c
   return WS_OK;
 }
 

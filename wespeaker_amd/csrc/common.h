@@ -85,6 +85,8 @@ struct HostTensor {
 struct KernelProfiler {
   enum { kClasses = 4 };      // 0: conv_gemm 128x128 tile, 1: conv_gemm 128x64 tile, 2: other, 3: split-K path
   bool enabled = false;
+  unsigned mask = 0xF;          // which classes are recorded (events between kernels cost a few %)
+  bool open = false;
   struct Rec { int cls; double flops, bytes; hipEvent_t a, b; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
@@ -100,15 +102,18 @@ struct KernelProfiler {
   }
   // call before / after a launch
   void begin(int cls, double flops, double bytes, hipStream_t st) {
-    if (!enabled) return;
+    open = false;
+    if (!enabled || !(mask & (1u << cls))) return;
     Rec r{cls, flops, bytes, take(), take()};
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, st);
     recs.push_back(r);
+    open = true;
   }
   void end(hipStream_t st) {
-    if (!enabled || recs.empty()) return;
+    if (!open) return;
     (void)hipEventRecord(recs.back().b, st);
+    open = false;
   }
   // synchronises; sums per class; clears
   void read(double* ms, double* flops, double* bytes, int* launches) {

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     constexpr int RPP = 256 / C4;              // rows per pass
     const int c4 = tid % C4, rr = tid / C4;
     const int n = n0 + c4 * 4;
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
     if (n < p.N) {                             // N % 4 == 0 (checked on the host)
       f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -230,6 +231,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
       }
       const bool to_d2 = p.D2 && n >= p.d2_col0;
+      // rows >= rb belong to the next image (per-image column sums; HW >= BM is checked on the host)
+      const int rb = (m0 / HW + 1) * HW - m0;
 #pragma unroll 4
       for (int row = rr; row < BM; row += RPP) {
         const int m = m0 + row;
@@ -253,6 +256,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
         if (to_d2)
           *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
+        if (p.colsum) {
+          if (row < rb) cs0 += v; else cs1 += v;
+        }
+      }
+    }
+    if (p.colsum) {
+      // Deterministic per-(row tile, image) column sums of the stored values (SE / statistics
+      // pooling without re-reading the tensor): fold the RPP row phases through LDS, then one
+      // plain store per column -> colsum[(tile_m*2 + which)][N].
+      __syncthreads();                                  // everyone is done reading the E tile
+      float* red = lds;                                 // [RPP][2][BN]
+      *reinterpret_cast<f32x4*>(&red[(rr * 2 + 0) * BN + c4 * 4]) = cs0;
+      *reinterpret_cast<f32x4*>(&red[(rr * 2 + 1) * BN + c4 * 4]) = cs1;
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, col = tid - which * BN;
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) sacc += red[(q * 2 + which) * BN + col];
+        if (n0 + col < p.N) p.colsum[((long long)tile_m * 2 + which) * p.N + n0 + col] = sacc;
       }
     }
   }
@@ -283,6 +306,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
   if (p.pre_scale && p.A2) return hipErrorInvalidValue;
+  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 128)) return hipErrorInvalidValue;
   if (p.N <= 64) {
     if (p.pre_scale) return launch_variant<128, 64, 4, 1, false, true>(p, stream);
     return p.A2 ? launch_variant<128, 64, 4, 1, true, false>(p, stream)

@@ -24,7 +24,7 @@ struct EcapaModel : ModelBase {
   size_t se_w1[3], se_b1[3], se_w2[3], se_b2[3];
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
-        *pooled = nullptr, *partial = nullptr;
+        *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
   static constexpr int kSplitK = 16;
 
   EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
@@ -101,13 +101,14 @@ struct EcapaModel : ModelBase {
            o_cat = take(M * 3 * C), o_h = take(M * 1536), o_att = take(M * 128),
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
-           o_part = take((size_t)kSplitK * maxB * embed_dim), o_feats = take(M * feat_dim);
+           o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
+           o_colsum = take(((M + 127) / 128) * 2 * C), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
     h = base + o_h; att = base + o_att; e = base + o_e; se_s = base + o_s; stats = base + o_stats;
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
-    feats_ws = base + o_feats;
+    colsum = base + o_colsum; feats_ws = base + o_feats;
     return 0;
   }
 
@@ -124,17 +125,42 @@ struct EcapaModel : ModelBase {
       p.D2 = y2; p.ldd2 = C; p.d2_off = 7 * w; p.d2_col0 = 7 * w;
       WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
-      for (int i = 0; i < 7; ++i) {
-        ConvGemmParams q = conv1d(res2[L][i], y1, C, i * w, y2, C, i * w, B, T, d, ACT_RELU);
-        if (i >= 1) { q.A2 = y2; q.lda2 = C; q.a2_off = (i - 1) * w; }
-        WS_LAUNCH(gemm(q, st));
+      if (res2_chain_supported(w, T, d)) {       // one launch, running activation kept in LDS
+        Res2ChainParams r;
+        r.y1 = y1; r.ldy1 = C; r.y2 = y2; r.ldy2 = C; r.ldw = res2[L][0].ldw;
+        for (int i = 0; i < 7; ++i) {
+          r.w[i] = arena.at(res2[L][i].w); r.bias[i] = arena.at(res2[L][i].b);
+          r.scale[i] = arena.at(res2[L][i].scale); r.shift[i] = arena.at(res2[L][i].shift);
+        }
+        r.B = B; r.T = T; r.W = w; r.dil = d;
+        if (prof.enabled) prof.begin(1, 2.0 * B * (double)T * w * 3 * w * 7, 4.0 * B * (double)T * C * 2, st);
+        hipError_t re = launch_res2_chain(r, st);
+        prof.end(st);
+        WS_LAUNCH(re);
+      } else {
+        for (int i = 0; i < 7; ++i) {
+          ConvGemmParams q = conv1d(res2[L][i], y1, C, i * w, y2, C, i * w, B, T, d, ACT_RELU);
+          if (i >= 1) { q.A2 = y2; q.lda2 = C; q.a2_off = (i - 1) * w; }
+          WS_LAUNCH(gemm(q, st));
+        }
       }
-      WS_LAUNCH(gemm(conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU), st));
       const double mc = 4.0 * B * (double)T * C;
-      WS_LAUNCH(other(mc, st, [&] {
-        return launch_se_pool_fc(y3, C, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                 arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
-      }));
+      ConvGemmParams p3 = conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU);
+      if (T >= 128) {
+        // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
+        p3.colsum = colsum;
+        WS_LAUNCH(gemm(p3, st));
+        WS_LAUNCH(other(0.0, st, [&] {
+          return launch_se_fc_from_colsum(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
+                                          arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
+        }));
+      } else {
+        WS_LAUNCH(gemm(p3, st));
+        WS_LAUNCH(other(mc, st, [&] {
+          return launch_se_pool_fc(y3, C, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
+                                   arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
+        }));
+      }
       WS_LAUNCH(other(3 * mc, st, [&] {
         return launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st);
       }));
@@ -145,10 +171,13 @@ struct EcapaModel : ModelBase {
     ConvGemmParams a1 = conv1d(pool1, h, 1536, 0, att, 128, 0, B, T, 1, ACT_TANH);
     a1.K = 1536; a1.Cin = 1536;                      // GLOB: only the first 1536 columns multiply h
     if (glob) {
+      // [mean; std] statistics, then bias_img = W1[:, C:3C] [mean; std] + b1 as a split-K GEMM
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
-        return launch_astp_context_bias(h, 1536, B, T, 1536, arena.at(pool1.w), pool1.ldw,
-                                        arena.at(pool1.b), 128, stats, bias_img, st);
+        return launch_astp_stats(h, 1536, B, T, 1536, stats, st);
       }));
+      ConvGemmParams cb = conv1d(pool1, stats, 3072, 0, bias_img, 128, 0, B, 1, 1, ACT_NONE);
+      cb.W = arena.at(pool1.w) + 1536; cb.K = 3072; cb.Cin = 3072;
+      WS_LAUNCH(gemm_splitk(cb, partial, kSplitK, st));
       a1.bias = nullptr;
       a1.bias_img = bias_img;
     }

@@ -91,6 +91,64 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
   return hipGetLastError();
 }
 
+// ------------------------------------------------------ SE FCs from GEMM-epilogue column sums
+// grid = B, block = 512.  C <= 1024, bottleneck <= 256.
+__global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
+    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    int bott, float* __restrict__ s) {
+  __shared__ float mean[1024];
+  __shared__ float hidden[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long r0 = (long long)b * T, r1 = r0 + T - 1;
+  const int t_first = (int)(r0 / 128), t_last = (int)(r1 / 128);
+  for (int c = tid; c < C; c += 512) {
+    float v = 0.f;
+    for (int tm = t_first; tm <= t_last; ++tm) {
+      const int first_img = (int)(((long long)tm * 128) / T);
+      const int which = (first_img == b) ? 0 : 1;
+      v += colsum[((long long)tm * 2 + which) * C + c];
+    }
+    mean[c] = v / (float)T;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = wave; j < bott; j += 8) {
+    const float* wr = w1 + (long long)j * C;
+    float v = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+      v += w[0] * mean[c] + w[1] * mean[c + 1] + w[2] * mean[c + 2] + w[3] * mean[c + 3];
+    }
+    v = wave_sum(v);
+    if (lane == 0) hidden[j] = fmaxf(v + b1[j], 0.f);
+  }
+  __syncthreads();
+  // one half-wave (32 lanes x float4 = 128 k) per output row: coalesced 512-B row reads
+  const int half = lane >> 5, hl = lane & 31;
+  for (int c = wave * 2 + half; c < C; c += 16) {
+    const float* wr = w2 + (long long)c * bott;
+    float v = 0.f;
+    for (int k = hl * 4; k < bott; k += 128) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+      v += w[0] * hidden[k] + w[1] * hidden[k + 1] + w[2] * hidden[k + 2] + w[3] * hidden[k + 3];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (hl == 0) s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + b2[c])));
+  }
+}
+
+hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
+                                    const float* b1, const float* w2, const float* b2,
+                                    int bottleneck, float* s, hipStream_t stream) {
+  if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || T < 128)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(se_fc_from_colsum_kernel, dim3(B), dim3(512), 0, stream, colsum, T, C, w1, b1,
+                     w2, b2, bottleneck, s);
+  return hipGetLastError();
+}
+
 // --------------------------------------------------------------------- SE scale + block residual
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(
     const float* __restrict__ x, int ldx, int x_off, const float* __restrict__ y, int ldy,
@@ -172,6 +230,13 @@ __global__ __launch_bounds__(256) void astp_context_bias_kernel(const float* __r
     v = wave_sum(v);
     if (lane == 0) out[(long long)b * bott + j] = v + b1[j];
   }
+}
+
+hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(astp_stats_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, h, ldh, T,
+                     C, stats);
+  return hipGetLastError();
 }
 
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,

@@ -33,6 +33,9 @@ struct ConvGemmParams {
   const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
   const float* seg_scale; int seg_len; int segs_per_img;  // optional y *= seg_scale[(img*segs + ox/seg_len)][n]
                                               // (CAM++ context mask, campplus.py:110-115)
+  float* colsum;                              // optional [tiles_m][2][N]: per row-tile column sums of the
+                                              // stored values, split at the image boundary inside
+                                              // the tile (needs Hout*Wout >= 128 rows per image)
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
 };
@@ -41,6 +44,24 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
 
+// Fused Res2 chain (ecapa_tdnn.py:58-78): 7 serial k=3 dilated convs of width W, one workgroup per
+// utterance, running activation kept in LDS.  y1: output of the block's first 1x1 conv [B*T][ldy1]
+// (8 splits of W channels); y2: [B*T][ldy2], splits 0..6 written here (split 7 is the pass-through).
+struct Res2ChainParams {
+  const float* y1; int ldy1;
+  float* y2; int ldy2;
+  const float* w[7]; int ldw;               // packed [W][tap*W + ci], ldw = 3W
+  const float* bias[7]; const float* scale[7]; const float* shift[7];
+  int B, T, W, dil;
+};
+bool res2_chain_supported(int W, int T, int dil);
+hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
+
+// SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 128 rows):
+// mean[b][c] = (sum of the tile partials covering rows [b*T, (b+1)*T)) / T, then the two FCs.
+hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
+                                    const float* b1, const float* w2, const float* b2,
+                                    int bottleneck, float* s, hipStream_t stream);
 // SE_Connect (ecapa_tdnn.py:120-126): s[b][c] = sigmoid(W2 relu(W1 mean_t(y[b,t,:]) + b1) + b2)
 hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
                              const float* b1, const float* w2, const float* b2, int bottleneck,
@@ -51,6 +72,8 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
                                     int C, hipStream_t stream);
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
+hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
+                             hipStream_t stream);
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
                                     int ldw1, const float* b1, int bottleneck, float* stats,
                                     float* bias_img, hipStream_t stream);

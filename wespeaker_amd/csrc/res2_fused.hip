@@ -1,0 +1,157 @@
+// Fused Res2 chain of an ECAPA SE-Res2Block: the 7 serial (w -> w, k = 3, dilation d) convolutions
+//   sp_i = BN(ReLU(conv_i(sp_{i-1} + split_i)))          (wespeaker/models/ecapa_tdnn.py:58-78)
+// in ONE launch, one workgroup per utterance.  The running activation lives in LDS for the whole
+// chain (it never round-trips HBM between the 7 steps), each step is a [T x 3w] x [3w x w] GEMM on
+// exact-fp32 v_mfma_f32_16x16x4_f32 with the step's weights held in registers.
+//
+//  * 8 wavefronts: wave -> (16-column output tile wn, row group wm); MTW 16-row tiles per wave.
+//  * X (LDS): rows t = -d .. Tpad+d (zero halo = the conv's zero padding), row stride w+8 floats so
+//    that a ds_read_b128 lane group (16 rows x 4 k-quads) touches 16 distinct 16-B slots.
+//  * lane (i = l & 15, q = l >> 4) reads 4 consecutive k per ds_read_b128 and feeds 4 MFMAs; the
+//    weight fragment uses the same k permutation, so the sum is over all k exactly once.
+//  * epilogue per step: + bias, ReLU, BN affine -> store sp_i to y2[:, i*w ...] and write
+//    sp_i + split_{i+1} back into X for the next step.
+#include "kernels.h"
+
+namespace wsamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int W, int MTW>
+__global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p) {
+  constexpr int NT = W / 16;            // output column tiles
+  constexpr int MW = 8 / NT;            // row groups of waves
+  constexpr int XS = W + 8;             // LDS row stride (floats)
+  constexpr int KG = 3 * W / 16;        // k groups of 16 per step
+  extern __shared__ __attribute__((aligned(16))) float X[];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % NT, wm = wave / NT;
+  const int li = lane & 15, lq = lane >> 4;
+  const int T = p.T, d = p.dil;
+  const int rows_total = MW * MTW * 16 + 2 * d;         // LDS rows incl. halo and row padding
+  const long long m_base = (long long)b * T;
+
+  // zero the whole X once: halo rows and rows >= T stay zero for all steps
+  for (int i = tid * 4; i < rows_total * XS; i += 512 * 4)
+    *reinterpret_cast<f32x4*>(&X[i]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // stage split 0: X[t + d][c] = y1[m][c]
+  {
+    constexpr int C4 = W / 4;
+    for (int i = tid; i < T * C4; i += 512) {
+      const int t = i / C4, c = (i - t * C4) * 4;
+      *reinterpret_cast<f32x4*>(&X[(t + d) * XS + c]) =
+          *reinterpret_cast<const f32x4*>(p.y1 + (m_base + t) * p.ldy1 + c);
+    }
+  }
+  __syncthreads();
+
+  const int co = wn * 16 + li;                          // this lane's output channel
+  for (int step = 0; step < 7; ++step) {
+    // weights of this step for column co: k = 16 g + 4 q + s   (packed [co][tap*W + ci], ld 3W)
+    const float* wrow = p.w[step] + (long long)co * p.ldw + lq * 4;
+    f32x4 bw[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) bw[g] = *reinterpret_cast<const f32x4*>(wrow + g * 16);
+    const float bias = p.bias[step][co], sc = p.scale[step][co], sh = p.shift[step][co];
+
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // rows of this wave's tiles: t = (wm*MTW + mt)*16 + li ; X row = t + d + (tap-1)*d = t + tap*d.
+    // Two row tiles at a time (independent accumulators hide the 40-cycle dependent-MFMA latency),
+    // A fragments software-pipelined one k-group ahead; sched_barrier keeps hipcc from hoisting
+    // every ds_read of the unrolled loop to the top (which spills).
+    const float* xbase = &X[(wm * MTW * 16 + li) * XS + lq * 4];
+    auto xaddr = [&](int mt, int g) {
+      const int tap = g / (W / 16), cg = g % (W / 16);
+      return xbase + (mt * 16 + tap * d) * XS + cg * 16;
+    };
+#pragma unroll
+    for (int mp = 0; mp < MTW; mp += 2) {
+      constexpr int kDummy = 0;
+      (void)kDummy;
+      const bool two = mp + 1 < MTW;
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(xaddr(mp, 0));
+      f32x4 a1 = two ? *reinterpret_cast<const f32x4*>(xaddr(mp + 1, 0)) : a0;
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        f32x4 n0 = a0, n1 = a1;
+        if (g + 1 < KG) {
+          n0 = *reinterpret_cast<const f32x4*>(xaddr(mp, g + 1));
+          if (two) n1 = *reinterpret_cast<const f32x4*>(xaddr(mp + 1, g + 1));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bw[g][s], acc[mp], 0, 0, 0);
+          if (two)
+            acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bw[g][s], acc[mp + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1;
+      }
+    }
+    __syncthreads();                                    // everyone finished reading X
+    // C/D layout 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg.
+    // The row strides are laundered through an empty asm so the 4*MTW row addresses are
+    // recomputed here instead of being hoisted out of the step loop (where they would live
+    // across the MFMA section and spill).
+    int ld1 = p.ldy1, ld2 = p.ldy2;
+    asm volatile("" : "+v"(ld1), "+v"(ld2));
+    const float* y1u = p.y1 + m_base * ld1 + (step + 1) * W + co;
+    float* y2u = p.y2 + m_base * ld2 + step * W + co;
+    const int t0 = wm * MTW * 16 + lq * 4;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + mt * 16 + r;
+        if (t < T) {
+          float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
+          y2u[t * ld2] = v;
+          if (step < 6) X[(t + d) * XS + co] = v + y1u[t * ld1];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int W, int MTW>
+static hipError_t launch_res2_variant(const Res2ChainParams& p, hipStream_t stream) {
+  constexpr int MW = 8 / (W / 16);
+  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 8) * sizeof(float);
+  auto kern = res2_chain_kernel<W, MTW>;
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+  return hipGetLastError();
+}
+
+bool res2_chain_supported(int W, int T, int dil) {
+  if (W == 64) return T <= 2 * 13 * 16 && (size_t)(2 * 13 * 16 + 2 * dil) * 72 * 4 <= 160 * 1024;
+  if (W == 128) return T <= 13 * 16;
+  return false;
+}
+
+hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
+  if (p.B <= 0) return hipSuccess;
+  if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
+  if (p.W == 64) {
+    if (p.T <= 2 * 7 * 16) return launch_res2_variant<64, 7>(p, stream);
+    if (p.T <= 2 * 13 * 16) return launch_res2_variant<64, 13>(p, stream);
+  } else if (p.W == 128) {
+    if (p.T <= 13 * 16) return launch_res2_variant<128, 13>(p, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace wsamd

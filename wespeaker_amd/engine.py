@@ -47,8 +47,8 @@ class Frontend:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().ws_frontend_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.ws_frontend_destroy(h)
             self._h = None
 
     def num_frames(self, num_samples: int) -> int:
@@ -112,8 +112,8 @@ class NativeSpeakerModel:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().ws_engine_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.ws_engine_destroy(h)
             self._h = None
 
     # nn.Module look-alikes so reference-style call sites keep working
@@ -134,8 +134,10 @@ class NativeSpeakerModel:
     PROFILE_CLASSES = ("conv_gemm_f32_128x128", "conv_gemm_f32_128x64", "reduce_elementwise",
                        "conv_gemm_f32_splitk")
 
-    def profile(self, on: bool):
-        _lib.check(_lib.lib().ws_engine_profile_enable(self._h, int(bool(on))))
+    def profile(self, on):
+        """on: False/0 = off, True = all kernel classes, int = bit mask (1 = dominant GEMM only)."""
+        mask = 0xF if on is True else int(on)
+        _lib.check(_lib.lib().ws_engine_profile_enable(self._h, mask))
 
     def profile_read(self):
         """-> {class: dict(ms, flops, bytes, launches)}; synchronises the recorded events."""

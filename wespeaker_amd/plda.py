@@ -61,9 +61,9 @@ class TwoCovPLDA:
         return self._h
 
     def _invalidate(self):
-        if self._h:
-            _lib.lib().ws_plda_destroy(self._h)
-            self._h = None
+        if self._h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.ws_plda_destroy(self._h)
+        self._h = None
 
     def __del__(self):
         try:
