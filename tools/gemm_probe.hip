@@ -13,7 +13,9 @@ int main(int argc, char** argv) {
   struct Shape { int M, N, K, taps; const char* name; };
   std::vector<Shape> shapes = {{50688, 512, 512, 1, "1x1 512"}, {50688, 1536, 1536, 1, "cat 1536"},
                                {50688, 128, 1536, 1, "astp1"}, {50688, 1536, 128, 1, "astp2"},
-                               {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"}};
+                               {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"},
+                               {49152, 512, 512, 1, "512 M=384t"}, {32768, 512, 512, 1, "512 M=256t"},
+                               {16384, 512, 512, 1, "512 M=128t"}, {49152, 1536, 1536, 1, "cat M=384t"}};
   float *A, *W, *D, *Z, *bias;
   size_t maxA = 50688ull * 1536, maxW = 1536ull * 1536, maxD = 50688ull * 1536;
   CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&W, maxW * 4)); CK(hipMalloc(&D, maxD * 4));

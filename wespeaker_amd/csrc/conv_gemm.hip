@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE>
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int S = LDS_STRIDE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
   const int tile_m = work / tiles_n;
   const int tile_n = work - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
 
   // ---------------- staging roles: thread -> (16-B chunk kc of the K-tile, rows r0 + 32 i)
   const int kc = tid & 7;
@@ -84,8 +84,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     kt_end = (int)(((long long)nk_total * (blockIdx.y + 1)) / p.splitk);
   }
 
+  // SIMPLE mode (1x1, stride 1, no padding, K % 32 == 0: most of the FLOPs): running per-row
+  // pointers, no tap arithmetic and no predicates inside the K loop.
+  const float* sa_ptr[A_IT];
+  const float* sw_ptr[W_IT];
+  int sa_inc[A_IT], sw_inc[W_IT];
+  if (SIMPLE) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      const bool ok = m < p.M;
+      sa_ptr[i] = ok ? p.A + (long long)m * p.lda + p.a_off + (long long)kt_begin * BK + kc * 4 : p.zeros;
+      sa_inc[i] = ok ? BK : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      const bool ok = n < p.N;
+      sw_ptr[i] = ok ? p.W + (long long)n * p.ldw + (long long)kt_begin * BK + kc * 4 : p.zeros;
+      sw_inc[i] = ok ? BK : 0;
+    }
+  }
+
   f32x4 ra[A_IT], rw[W_IT];
   auto load_tile = [&](int kt) {
+    if (SIMPLE) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(sa_ptr[i]);
+        sa_ptr[i] += sa_inc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        rw[i] = *reinterpret_cast<const f32x4*>(sw_ptr[i]);
+        sw_ptr[i] += sw_inc[i];
+      }
+      return;
+    }
     const int kg = kt * BK + kc * 4;
     const bool kok = kg < p.K;
     const int tap = kg / p.Cin;
@@ -160,6 +195,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #endif
     const float* As = lds + buf * (BM + BN) * S + (wm * TM * 32 + li) * S + lh * 4;
     const float* Ws = lds + buf * (BM + BN) * S + BM * S + (wn * TN * 32 + li) * S + lh * 4;
+#if 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 a[TM], b[TN];
@@ -177,6 +215,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
           for (int in = 0; in < TN; ++in)
             acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
     }
+#if 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #if !defined(WS_ABLATE) || WS_ABLATE < 2
     if (has_next) store_tile(buf ^ 1);
     __syncthreads();
@@ -222,7 +263,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     constexpr int RPP = 256 / C4;              // rows per pass
     const int c4 = tid % C4, rr = tid / C4;
     const int n = n0 + c4 * 4;
-    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NH = BM / 64;                // 64-row halves (column-sum granularity)
+    f32x4 cs[NH][2];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) cs[hf][0] = cs[hf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (n < p.N) {                             // N % 4 == 0 (checked on the host)
       f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -231,73 +275,84 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
       }
       const bool to_d2 = p.D2 && n >= p.d2_col0;
-      // rows >= rb belong to the next image (per-image column sums; HW >= BM is checked on the host)
-      const int rb = (m0 / HW + 1) * HW - m0;
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf) {
+        // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
+        const int mh = m0 + hf * 64;
+        const int rb = (mh / HW + 1) * HW - mh;
 #pragma unroll 4
-      for (int row = rr; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= p.M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
-        if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
-        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
-        if (p.act == ACT_RELU) {
+        for (int rl = rr; rl < 64; rl += RPP) {
+          const int row = hf * 64 + rl;
+          const int m = m0 + row;
+          if (m >= p.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
+          if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
+          if (p.act == ACT_RELU) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        } else if (p.act == ACT_TANH) {
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          } else if (p.act == ACT_TANH) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
-        }
-        if (p.post_scale) v = v * ps + pb;
-        if (p.seg_scale) {
-          const int img = m / HW, ox = (m - img * HW) % p.Wout;
-          v *= *reinterpret_cast<const f32x4*>(
-              p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
-        }
-        *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
-        if (to_d2)
-          *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
-        if (p.colsum) {
-          if (row < rb) cs0 += v; else cs1 += v;
+            for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+          }
+          if (p.post_scale) v = v * ps + pb;
+          if (p.seg_scale) {
+            const int img = m / HW, ox = (m - img * HW) % p.Wout;
+            v *= *reinterpret_cast<const f32x4*>(
+                p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
+          }
+          *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
+          if (to_d2)
+            *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
+          if (p.colsum) {
+            if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
+          }
         }
       }
     }
     if (p.colsum) {
-      // Deterministic per-(row tile, image) column sums of the stored values (SE / statistics
+      // Deterministic per-(64-row tile, image) column sums of the stored values (SE / statistics
       // pooling without re-reading the tensor): fold the RPP row phases through LDS, then one
-      // plain store per column -> colsum[(tile_m*2 + which)][N].
+      // plain store per column -> colsum[(tile64*2 + which)][N].
       __syncthreads();                                  // everyone is done reading the E tile
-      float* red = lds;                                 // [RPP][2][BN]
-      *reinterpret_cast<f32x4*>(&red[(rr * 2 + 0) * BN + c4 * 4]) = cs0;
-      *reinterpret_cast<f32x4*>(&red[(rr * 2 + 1) * BN + c4 * 4]) = cs1;
+      float* red = lds;                                 // [NH][2][RPP][BN]
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh)
+          *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
       __syncthreads();
-      if (tid < 2 * BN) {
-        const int which = tid / BN, col = tid - which * BN;
+      for (int o = tid; o < NH * 2 * BN; o += 256) {
+        const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
         float sacc = 0.f;
 #pragma unroll
-        for (int q = 0; q < RPP; ++q) sacc += red[(q * 2 + which) * BN + col];
-        if (n0 + col < p.N) p.colsum[((long long)tile_m * 2 + which) * p.N + n0 + col] = sacc;
+        for (int q = 0; q < RPP; ++q) sacc += red[(hw * RPP + q) * BN + col];
+        if (n0 + col < p.N)
+          p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE>
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE = false>
 static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
   const size_t lds_bytes = 2ull * (BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE>;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  if (tiles_m <= 0) return hipSuccess;
   dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
+#define WS_SETPRIO_ON 1
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   // 16-byte paths: channel counts / offsets / row strides must be multiples of 4 floats
@@ -306,15 +361,55 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
   if (p.pre_scale && p.A2) return hipErrorInvalidValue;
-  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 128)) return hipErrorInvalidValue;
+  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
+  if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.N <= 64) {
     if (p.pre_scale) return launch_variant<128, 64, 4, 1, false, true>(p, stream);
     return p.A2 ? launch_variant<128, 64, 4, 1, true, false>(p, stream)
                 : launch_variant<128, 64, 4, 1, false, false>(p, stream);
   }
-  if (p.pre_scale) return launch_variant<128, 128, 2, 2, false, true>(p, stream);
-  return p.A2 ? launch_variant<128, 128, 2, 2, true, false>(p, stream)
-              : launch_variant<128, 128, 2, 2, false, false>(p, stream);
+  const bool simple = !p.pre_scale && !p.A2 && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
+                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K % BK == 0 &&
+                      p.K == p.Cin;
+  // Tail peeling.  128x128 tiles run two per CU; a last partial round of tiles costs a whole tile
+  // time on a mostly idle chip (measured: 94 -> 123 TF at K = 512 when the tile count is a
+  // multiple of the slot count).  Rows beyond the last full round go to a 64x64-tile launch that
+  // spreads them over all CUs.
+  ConvGemmParams main = p, tail = p;
+  bool peel = false;
+  if (p.splitk <= 1 && p.m_begin == 0) {
+    static int slots = 0;
+    if (!slots) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      slots = 2 * cus;
+    }
+    const long long tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
+    const long long total = tiles_m * tiles_n, rem = total % slots;
+    if (total > slots && rem != 0 && rem * 10 <= slots * 7) {
+      const long long main_tiles_m = (total - rem) / tiles_n;
+      if (main_tiles_m > 0 && main_tiles_m < tiles_m) {
+        main.M = (int)(main_tiles_m * 128);
+        tail.m_begin = main.M;
+        peel = true;
+      }
+    }
+  }
+  hipError_t e;
+  // (A forked side stream for the tail was measured slower than same-stream order: the
+  // cross-queue event dependencies cost more than the overlap gains.)
+  hipStream_t tail_stream = stream;
+  if (p.pre_scale) e = launch_variant<128, 128, 2, 2, false, true>(main, stream);
+  else if (p.A2) e = launch_variant<128, 128, 2, 2, true, false>(main, stream);
+  else if (simple) e = launch_variant<128, 128, 2, 2, false, false, true>(main, stream);
+  else e = launch_variant<128, 128, 2, 2, false, false, false>(main, stream);
+  if (e != hipSuccess || !peel) return e;
+  if (p.pre_scale) e = launch_variant<64, 64, 2, 2, false, true>(tail, tail_stream);
+  else if (p.A2) e = launch_variant<64, 64, 2, 2, true, false>(tail, tail_stream);
+  else if (simple) e = launch_variant<64, 64, 2, 2, false, false, true>(tail, tail_stream);
+  else e = launch_variant<64, 64, 2, 2, false, false, false>(tail, tail_stream);
+  return e;
 }
 
 // --------------------------------------------------------------------------- split-K reduce

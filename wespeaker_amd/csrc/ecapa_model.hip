@@ -102,7 +102,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
-           o_colsum = take(((M + 127) / 128) * 2 * C), o_feats = take(M * feat_dim);
+           o_colsum = take(((M + 63) / 64 + 2) * 2 * C), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
@@ -146,7 +146,7 @@ struct EcapaModel : ModelBase {
       }
       const double mc = 4.0 * B * (double)T * C;
       ConvGemmParams p3 = conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU);
-      if (T >= 128) {
+      if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;
         WS_LAUNCH(gemm(p3, st));

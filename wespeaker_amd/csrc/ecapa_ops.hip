@@ -101,11 +101,11 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   __shared__ float hidden[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
-  const int t_first = (int)(r0 / 128), t_last = (int)(r1 / 128);
+  const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
   for (int c = tid; c < C; c += 512) {
     float v = 0.f;
     for (int tm = t_first; tm <= t_last; ++tm) {
-      const int first_img = (int)(((long long)tm * 128) / T);
+      const int first_img = (int)(((long long)tm * 64) / T);
       const int which = (first_img == b) ? 0 : 1;
       v += colsum[((long long)tm * 2 + which) * C + c];
     }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                     const float* b1, const float* w2, const float* b2,
                                     int bottleneck, float* s, hipStream_t stream) {
-  if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || T < 128)
+  if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || T < 64)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(se_fc_from_colsum_kernel, dim3(B), dim3(512), 0, stream, colsum, T, C, w1, b1,
                      w2, b2, bottleneck, s);

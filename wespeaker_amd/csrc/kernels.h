@@ -23,6 +23,8 @@ struct ConvGemmParams {
   float* D;  int ldd;  int d_off;             // output rows
   float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
   int M, N, K;                                // M output pixels, N output channels, K = taps*Cin
+  int m_begin;                                // first output pixel of this launch (multiple of 64;
+                                              // used by the launcher's tail peeling)
   int Cin;
   int Hin, Win, Hout, Wout;
   int stride_h, stride_w, kh, kw, dil_h, dil_w, pad_h, pad_w;
@@ -33,9 +35,9 @@ struct ConvGemmParams {
   const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
   const float* seg_scale; int seg_len; int segs_per_img;  // optional y *= seg_scale[(img*segs + ox/seg_len)][n]
                                               // (CAM++ context mask, campplus.py:110-115)
-  float* colsum;                              // optional [tiles_m][2][N]: per row-tile column sums of the
-                                              // stored values, split at the image boundary inside
-                                              // the tile (needs Hout*Wout >= 128 rows per image)
+  float* colsum;                              // optional [ceil(M/64)][2][N]: column sums of the stored
+                                              // values per 64-row tile, split at the image boundary
+                                              // inside the tile (needs Hout*Wout >= 64 rows per image)
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
 };
@@ -57,7 +59,7 @@ struct Res2ChainParams {
 bool res2_chain_supported(int W, int T, int dil);
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
 
-// SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 128 rows):
+// SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 64 rows):
 // mean[b][c] = (sum of the tile partials covering rows [b*T, (b+1)*T)) / T, then the two FCs.
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                     const float* b1, const float* w2, const float* b2,
