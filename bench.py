@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--trials", type=int, default=1000000)
     ap.add_argument("--cpu-utts", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="GEMM contraction back-end (see include/wespeaker_amd.h)")
     args = ap.parse_args()
 
     rank, world, local_rank = parallel.init_distributed()
@@ -106,6 +108,7 @@ def main():
     T = fe.num_frames(num_samples)
     model = NativeSpeakerModel(args.model, sd, feat_dim=80, embed_dim=192, device=device,
                                max_batch=args.chunk, max_frames=T)
+    model.set_precision(args.precision)
     wav = device_wavs(args.batch, num_samples, device, seed_base=rank)
     n_total = args.batch * world
 

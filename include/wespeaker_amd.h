@@ -97,6 +97,16 @@ int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, fl
 int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
                ws_stream stream);
+/* Contraction back-end of every conv/linear GEMM (the reference computes them in fp32):
+ *   WS_PREC_FP32    exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TF peak)
+ *   WS_PREC_F16X3   each fp32 operand split x = hi + lo into two binary16 values (22 significant
+ *                   bits) and the product formed as hi*hi + hi*lo + lo*hi on
+ *                   v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative product error,
+ *                   i.e. fp32-grade results at 3/16 of the fp32-MFMA issue cost.
+ * May be switched at any time between forwards. */
+#define WS_PREC_FP32 0
+#define WS_PREC_F16X3 1
+int ws_engine_set_precision(ws_engine* eng, int mode);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 

@@ -110,6 +110,35 @@ def test_ecapa_forward_matches_oracle_and_golden(name, golden_dir):
     assert _rel_err(got_s, g[name + "/emb_T57"]).max() < REL_TOL
 
 
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c1024"])
+def test_ecapa_f16x3_split_precision_matches_oracle(name, golden_dir):
+    """The 3-pass split-binary16 MFMA back-end (hi*hi + hi*lo + lo*hi, fp32 accumulate) must meet
+    the same bars as the exact fp32 path."""
+    sd, model = _engine(name)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(3)])
+    exact = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    model.set_precision("f16x3")
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    ref = oecapa.ecapa_forward(sd, feats).numpy()
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < REL_TOL
+    assert _rel_err(got, exact).max() < REL_TOL
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))
+    assert _rel_err(got[:2], g[name + "/emb"]).max() < REL_TOL
+    for T in (5, 57, 201):
+        f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
+        e = model(torch.from_numpy(f))[-1].cpu().numpy()
+        assert _rel_err(e, oecapa.ecapa_forward(sd, f).numpy()).max() < REL_TOL
+    # large-magnitude and tiny-magnitude inputs (binary16 range / subnormal lo parts)
+    for scale in (1e-3, 30.0):
+        f = (np.random.RandomState(7).randn(2, 100, 80) * scale).astype(np.float32)
+        e = model(torch.from_numpy(f))[-1].cpu().numpy()
+        assert _rel_err(e, oecapa.ecapa_forward(sd, f).numpy()).max() < REL_TOL
+    model.set_precision("fp32")
+    back = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    assert np.array_equal(back, exact)
+
+
 def test_ecapa_emb_bn_and_shapes(golden_dir):
     sd, model = _engine("ECAPA_TDNN_c512", embed_dim=256, seed=5, emb_bn=True)
     feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])

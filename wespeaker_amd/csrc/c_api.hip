@@ -263,6 +263,13 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
   return WS_OK;
 }
 
+int ws_engine_set_precision(ws_engine* eng, int mode) {
+  if (!eng) { set_error("ws_engine_set_precision: invalid argument"); return WS_ERR_INVALID_ARG; }
+  int r = eng->model->set_precision(mode);
+  if (r) set_error("ws_engine_set_precision: unknown mode %d (0 = fp32 MFMA, 1 = split-f16 x3)", mode);
+  return r;
+}
+
 int ws_engine_profile_enable(ws_engine* eng, int on) {
   if (!eng) { set_error("ws_engine_profile_enable: invalid argument"); return WS_ERR_INVALID_ARG; }
   eng->model->prof.enabled = on != 0;

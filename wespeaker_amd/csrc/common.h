@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -69,6 +70,46 @@ struct WeightArena {
   }
   const float* at(size_t off) const { return dev.as<float>() + off; }
 };
+
+// IEEE binary16 conversion, round-to-nearest-even, subnormals preserved (host side; used to
+// pre-split weights into hi + lo half planes for the 3-pass f16 MFMA path).
+inline uint16_t float_to_half_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7FFFFFFFu;
+  if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x200u : 0u));
+  if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // overflow -> inf
+  if (x < 0x38800000u) {                                               // subnormal half (or zero)
+    if (x < 0x33000000u) return (uint16_t)sign;
+    const int shift = 126 - (int)(x >> 23);                            // 14..24
+    uint32_t mant = (x & 0x7FFFFFu) | 0x800000u;
+    uint32_t h = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((x - 0x38000000u) >> 13);
+  const uint32_t rem = x & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+inline float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      int s = 0;
+      while (!(m & 0x400u)) { m <<= 1; ++s; }
+      x = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3FFu) << 13);
+    }
+  } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+  else x = sign | ((e + 112) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
 
 struct HostTensor {
   std::vector<int64_t> shape;
@@ -141,6 +182,7 @@ struct Model {
   virtual int forward(const float* feats, int batch, int frames, float* emb,
                       hipStream_t stream) = 0;
   virtual double flops(int batch, int frames) const = 0;
+  virtual int set_precision(int mode) = 0;   // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
   virtual float* feats_workspace() = 0;      // (max_batch, max_frames, feat_dim) floats
   virtual int max_batch() const = 0;
   virtual int max_frames() const = 0;

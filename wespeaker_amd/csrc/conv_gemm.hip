@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution on channels-last activations for gfx950 (MI355X), exact fp32.
+// Implicit-GEMM convolution on channels-last activations for gfx950 (MI355X).
 //
 // Replaces the conv1d / conv2d / linear ATen calls of the reference forward
 // (wespeaker/models/ecapa_tdnn.py:85-106 Conv1dReluBn, :58-78 Res2 convs, :196 cat conv;
@@ -8,36 +8,58 @@
 //  * activations are [pixel][channel] (channels-last), weights [cout][tap*Cin + ci]: both GEMM
 //    operands are K-contiguous, so global loads are 16 B/lane along K and both LDS tiles are
 //    read with ds_read_b128 along K.
-//  * contraction on v_mfma_f32_32x32x2_f32: the exact-f32 matrix instruction (bit-identical to an
-//    fmaf chain, 157 TF peak).  A 64-lane wavefront owns TM x TN tiles of 32x32; lane l holds
-//    row/col (l & 31) and the k-half (l >> 5).  One ds_read_b128 feeds 4 MFMAs per tile (the four
-//    k values of a lane pair with the four of its partner lane: k order inside a tile is permuted,
-//    which a sum does not care about).
-//  * LDS row stride BK+4 floats makes every ds_read_b128 lane group hit 16 distinct 16-B slots
-//    (conflict-free).
+//  * two contraction back-ends behind one tiling (template PREC):
+//      PREC 0  v_mfma_f32_32x32x2_f32: exact fp32 products (bit-identical to an fmaf chain),
+//              157 TF peak.  One ds_read_b128 feeds 4 MFMAs per tile (k-permuted lanes).
+//      PREC 1  "f16x3": every fp32 operand is split x = hi + lo (hi = half(x), lo = half(x - hi),
+//              22 significant bits) and the product is formed as hi*hi + hi*lo + lo*hi on
+//              v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative product error
+//              (fp32-grade) at 3/16 of the fp32-MFMA issue cost.  Weights are pre-split on the
+//              host; activations are split while they are staged into LDS.
+//  * 128x128x32 tile, 4 wavefronts x (2x2) 32x32 accumulators (128x64 and 64x64 variants);
+//    LDS row strides (36 floats / 40 halfs) make every ds_read_b128 lane group hit 16 distinct
+//    16-B slots (conflict-free).
 //  * im2col-free: a K-chunk of 4 floats lies inside one filter tap; the tap's pixel offset and the
 //    zero-padding predicate are evaluated per 16-B chunk while staging (masked chunks are read
-//    from a 16-B zero page, so the loads stay unconditional and pipelined).
+//    from a 16-B zero page, so the loads stay unconditional and pipelined).  1x1 / stride-1 layers
+//    (most of the FLOPs) use running row pointers with no per-tile address arithmetic (SIMPLE).
 //  * register-prefetch double buffering: tile k+1's global loads are issued before tile k's
 //    MFMAs and written to the other LDS buffer after them -> one barrier per K-tile.
-//  * fused epilogue: bias (+ per-utterance bias), residual, ReLU/tanh, BN-after-activation affine,
-//    dual store (Res2 pass-through split), or raw split-K partials.
+//  * XCD-aware bijective tile order; tail peeling: rows beyond the last full round of
+//    (2 tiles per CU) go to a 64x64-tile launch (a partial last round costs a whole tile time).
+//  * epilogue transposed through LDS -> 16-B stores; fused bias (+ per-utterance bias), residual,
+//    ReLU/tanh, BN-after-activation affine, dual store (Res2 pass-through split), segment mask,
+//    deterministic per-64-row column sums (SE mean), or raw split-K partials.
 #include "kernels.h"
 
 namespace wsamd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row
+constexpr int LDS_STRIDE = BK + 4;   // fp32 path: floats per LDS row
+constexpr int HS = BK + 8;           // f16x3 path: halfs per LDS row (80 B)
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE>
+template <int BM, int BN, int PREC>
+constexpr size_t tile_lds_bytes() {
+  // per buffer: A and W tiles; PREC 1 keeps a hi and a lo half plane per tile (same bytes as fp32)
+  const size_t stage = PREC == 0 ? (size_t)(BM + BN) * LDS_STRIDE * 4 : (size_t)(BM + BN) * HS * 2 * 2;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  return 2 * stage > epi ? 2 * stage : epi;
+}
+
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int S = LDS_STRIDE;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_IT = BM / 32, W_IT = BN / 32;
+  constexpr int A_IT = BM / 32;                       // float4 chunks of A per thread per K-tile
+  constexpr int W_IT = PREC == 0 ? BN / 32 : BN / 64; // W chunks per thread (per plane for PREC 1)
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(PREC == 0 || BN % 64 == 0, "f16x3 stages 64 weight rows per pass");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -59,22 +81,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   // ---------------- staging roles: thread -> (16-B chunk kc of the K-tile, rows r0 + 32 i)
   const int kc = tid & 7;
   const int r0 = tid >> 3;
+  // f16x3 weight planes: thread -> (16-B chunk of 8 halfs wc, rows wr0 + 64 i)
+  const int wc = tid & 3;
+  const int wr0 = tid >> 2;
   const int HW = p.Hout * p.Wout;
   int a_pix[A_IT], a_iy[A_IT], a_ix[A_IT];
+  if (!SIMPLE) {
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + r0 + 32 * i;
-    bool ok = m < p.M;
-    int mm = ok ? m : 0;
-    int img = mm / HW;
-    int rem = mm - img * HW;
-    int oy = rem / p.Wout;
-    int ox = rem - oy * p.Wout;
-    int iy0 = oy * p.stride_h - p.pad_h;
-    int ix0 = ox * p.stride_w - p.pad_w;
-    a_pix[i] = (img * p.Hin + iy0) * p.Win + ix0;
-    a_iy[i] = ok ? iy0 : -(1 << 28);   // forces the bounds predicate false for rows >= M
-    a_ix[i] = ix0;
+    for (int i = 0; i < A_IT; ++i) {
+      int m = m0 + r0 + 32 * i;
+      bool ok = m < p.M;
+      int mm = ok ? m : 0;
+      int img = mm / HW;
+      int rem = mm - img * HW;
+      int oy = rem / p.Wout;
+      int ox = rem - oy * p.Wout;
+      int iy0 = oy * p.stride_h - p.pad_h;
+      int ix0 = ox * p.stride_w - p.pad_w;
+      a_pix[i] = (img * p.Hin + iy0) * p.Win + ix0;
+      a_iy[i] = ok ? iy0 : -(1 << 28);   // forces the bounds predicate false for rows >= M
+      a_ix[i] = ix0;
+    }
   }
 
   const int nk_total = (p.K + BK - 1) / BK;
@@ -87,8 +114,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   // SIMPLE mode (1x1, stride 1, no padding, K % 32 == 0: most of the FLOPs): running per-row
   // pointers, no tap arithmetic and no predicates inside the K loop.
   const float* sa_ptr[A_IT];
-  const float* sw_ptr[W_IT];
-  int sa_inc[A_IT], sw_inc[W_IT];
+  int sa_inc[A_IT];
   if (SIMPLE) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -97,27 +123,52 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       sa_ptr[i] = ok ? p.A + (long long)m * p.lda + p.a_off + (long long)kt_begin * BK + kc * 4 : p.zeros;
       sa_inc[i] = ok ? BK : 0;
     }
+  }
+  // running weight pointers (all modes): fp32 rows, or hi/lo half planes
+  const float* sw_ptr[W_IT];
+  const uint16_t* swh_ptr[W_IT];
+  const uint16_t* swl_ptr[W_IT];
+  int sw_inc[W_IT];
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
+  for (int i = 0; i < W_IT; ++i) {
+    if (PREC == 0) {
       const int n = n0 + r0 + 32 * i;
       const bool ok = n < p.N;
       sw_ptr[i] = ok ? p.W + (long long)n * p.ldw + (long long)kt_begin * BK + kc * 4 : p.zeros;
       sw_inc[i] = ok ? BK : 0;
+    } else {
+      const int n = n0 + wr0 + 64 * i;
+      const bool ok = n < p.N;
+      const long long off = (long long)n * p.ldw + (long long)kt_begin * BK + wc * 8;
+      swh_ptr[i] = ok ? p.Wh + off : reinterpret_cast<const uint16_t*>(p.zeros);
+      swl_ptr[i] = ok ? p.Wl + off : reinterpret_cast<const uint16_t*>(p.zeros);
+      sw_inc[i] = ok ? BK : 0;
     }
   }
 
-  f32x4 ra[A_IT], rw[W_IT];
+  f32x4 ra[A_IT];
+  f32x4 rw[PREC == 0 ? W_IT : 1];
+  u32x4 rwh[PREC == 1 ? W_IT : 1], rwl[PREC == 1 ? W_IT : 1];
   auto load_tile = [&](int kt) {
+    // ---- weights
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      if (PREC == 0) {
+        rw[i] = *reinterpret_cast<const f32x4*>(sw_ptr[i]);
+        sw_ptr[i] += sw_inc[i];
+      } else {
+        rwh[i] = *reinterpret_cast<const u32x4*>(swh_ptr[i]);
+        rwl[i] = *reinterpret_cast<const u32x4*>(swl_ptr[i]);
+        swh_ptr[i] += sw_inc[i];
+        swl_ptr[i] += sw_inc[i];
+      }
+    }
+    // ---- activations
     if (SIMPLE) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         ra[i] = *reinterpret_cast<const f32x4*>(sa_ptr[i]);
         sa_ptr[i] += sa_inc[i];
-      }
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i) {
-        rw[i] = *reinterpret_cast<const f32x4*>(sw_ptr[i]);
-        sw_ptr[i] += sw_inc[i];
       }
       return;
     }
@@ -151,22 +202,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         ra[i] = v;
       }
     }
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int n = n0 + r0 + 32 * i;
-      const float* src = (n < p.N) ? p.W + (long long)n * p.ldw + kt * BK + kc * 4 : p.zeros;
-      rw[i] = *reinterpret_cast<const f32x4*>(src);
-    }
   };
+
+  // LDS map.  PREC 0: [buf][A rows | W rows][36 floats].
+  //           PREC 1: [buf][A_hi | A_lo | W_hi | W_lo] planes of [rows][40 halfs].
+  constexpr int STAGE_FLOATS = PREC == 0 ? (BM + BN) * S : (BM + BN) * HS;   // floats per buffer
   auto store_tile = [&](int buf) {
-    float* As = lds + buf * (BM + BN) * S;
-    float* Ws = As + BM * S;
+    if (PREC == 0) {
+      float* As = lds + buf * STAGE_FLOATS;
+      float* Ws = As + BM * S;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * S + kc * 4]) = ra[i];
+      for (int i = 0; i < A_IT; ++i)
+        *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * S + kc * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i)
-      *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * i) * S + kc * 4]) = rw[i];
+      for (int i = 0; i < W_IT; ++i)
+        *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * i) * S + kc * 4]) = rw[i];
+    } else {
+      _Float16* base = reinterpret_cast<_Float16*>(lds + buf * STAGE_FLOATS);
+      _Float16* Ah = base;
+      _Float16* Al = Ah + BM * HS;
+      _Float16* Wh = Al + BM * HS;
+      _Float16* Wl = Wh + BN * HS;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const _Float16 h = (_Float16)ra[i][q];
+          hi[q] = h;
+          lo[q] = (_Float16)(ra[i][q] - (float)h);
+        }
+        *reinterpret_cast<f16x4*>(&Ah[(r0 + 32 * i) * HS + kc * 4]) = hi;
+        *reinterpret_cast<f16x4*>(&Al[(r0 + 32 * i) * HS + kc * 4]) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        *reinterpret_cast<u32x4*>(&Wh[(wr0 + 64 * i) * HS + wc * 8]) = rwh[i];
+        *reinterpret_cast<u32x4*>(&Wl[(wr0 + 64 * i) * HS + wc * 8]) = rwl[i];
+      }
+    }
   };
 
   // ---------------- compute roles
@@ -190,42 +264,73 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   int buf = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool has_next = kt + 1 < kt_end;
-#if !defined(WS_ABLATE) || WS_ABLATE < 1
     if (has_next) load_tile(kt + 1);
-#endif
-    const float* As = lds + buf * (BM + BN) * S + (wm * TM * 32 + li) * S + lh * 4;
-    const float* Ws = lds + buf * (BM + BN) * S + BM * S + (wn * TN * 32 + li) * S + lh * 4;
-#if 1
     __builtin_amdgcn_s_setprio(1);
-#endif
+    if (PREC == 0) {
+      const float* As = lds + buf * STAGE_FLOATS + (wm * TM * 32 + li) * S + lh * 4;
+      const float* Ws = lds + buf * STAGE_FLOATS + BM * S + (wn * TN * 32 + li) * S + lh * 4;
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 a[TM], b[TN];
+      for (int g = 0; g < BK / 8; ++g) {
+        f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
-        a[im] = *reinterpret_cast<const f32x4*>(&As[im * 32 * S + g * 8]);
+        for (int im = 0; im < TM; ++im)
+          a[im] = *reinterpret_cast<const f32x4*>(&As[im * 32 * S + g * 8]);
 #pragma unroll
-      for (int in = 0; in < TN; ++in)
-        b[in] = *reinterpret_cast<const f32x4*>(&Ws[in * 32 * S + g * 8]);
+        for (int in = 0; in < TN; ++in)
+          b[in] = *reinterpret_cast<const f32x4*>(&Ws[in * 32 * S + g * 8]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+      }
+    } else {
+      // 32x32x16 f16 MFMA: lane (i = l & 31, h = l >> 5) holds k = 8h .. 8h+7 of row/col i
+      const _Float16* base = reinterpret_cast<const _Float16*>(lds + buf * STAGE_FLOATS);
+      const _Float16* Ah = base + (wm * TM * 32 + li) * HS + lh * 8;
+      const _Float16* Al = Ah + BM * HS;
+      const _Float16* Wh = base + 2 * BM * HS + (wn * TN * 32 + li) * HS + lh * 8;
+      const _Float16* Wl = Wh + BN * HS;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+          ah[im] = *reinterpret_cast<const f16x8*>(&Ah[im * 32 * HS + ks * 16]);
+          al[im] = *reinterpret_cast<const f16x8*>(&Al[im * 32 * HS + ks * 16]);
+        }
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          bh[in] = *reinterpret_cast<const f16x8*>(&Wh[in * 32 * HS + ks * 16]);
+          bl[in] = *reinterpret_cast<const f16x8*>(&Wl[in * 32 * HS + ks * 16]);
+        }
+        // small cross terms first, the hi*hi term last
 #pragma unroll
         for (int im = 0; im < TM; ++im)
 #pragma unroll
           for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], bh[in], acc[im][in], 0, 0, 0);
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bh[in], acc[im][in], 0, 0, 0);
+      }
     }
-#if 1
     __builtin_amdgcn_s_setprio(0);
-#endif
-#if !defined(WS_ABLATE) || WS_ABLATE < 2
     if (has_next) store_tile(buf ^ 1);
     __syncthreads();
-#endif
     buf ^= 1;
   }
 
-  // ---------------- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31,
+  // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   if (p.splitk > 1) {
 #pragma unroll
@@ -334,11 +439,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE = false>
-static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
-  const size_t lds_bytes = 2ull * (BM + BN) * LDS_STRIDE * sizeof(float);
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
+static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr size_t lds_bytes = tile_lds_bytes<BM, BN, PREC>();
   static bool attr_set = false;
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE>;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE, PREC>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -352,29 +457,29 @@ static hipError_t launch_variant(const ConvGemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-#define WS_SETPRIO_ON 1
-hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  // 16-byte paths: channel counts / offsets / row strides must be multiples of 4 floats
-  if ((p.N | p.Cin | p.lda | p.a_off | p.ldw | p.ldd | p.d_off) & 3) return hipErrorInvalidValue;
-  if (p.A2 && ((p.lda2 | p.a2_off) & 3)) return hipErrorInvalidValue;
-  if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
-  if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
-  if (p.pre_scale && p.A2) return hipErrorInvalidValue;
-  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
-  if (p.m_begin & 63) return hipErrorInvalidValue;
-  if (p.N <= 64) {
-    if (p.pre_scale) return launch_variant<128, 64, 4, 1, false, true>(p, stream);
-    return p.A2 ? launch_variant<128, 64, 4, 1, true, false>(p, stream)
-                : launch_variant<128, 64, 4, 1, false, false>(p, stream);
+// mode: 0 general, 1 A2 (second addend), 2 PRE (BN-ReLU on A), 3 SIMPLE (1x1 running pointers)
+template <int BM, int BN, int WM, int WN, int PREC>
+static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t stream) {
+  switch (mode) {
+    case 1: return launch_one<BM, BN, WM, WN, true, false, false, PREC>(p, stream);
+    case 2: return launch_one<BM, BN, WM, WN, false, true, false, PREC>(p, stream);
+    case 3: return launch_one<BM, BN, WM, WN, false, false, true, PREC>(p, stream);
+    default: return launch_one<BM, BN, WM, WN, false, false, false, PREC>(p, stream);
   }
+}
+
+template <int PREC>
+static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool simple = !p.pre_scale && !p.A2 && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                       p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K % BK == 0 &&
                       p.K == p.Cin;
+  const int mode = p.A2 ? 1 : (p.pre_scale ? 2 : (simple ? 3 : 0));
+  if (p.N <= 64) return launch_mode<128, 64, 4, 1, PREC>(p, mode, stream);
   // Tail peeling.  128x128 tiles run two per CU; a last partial round of tiles costs a whole tile
   // time on a mostly idle chip (measured: 94 -> 123 TF at K = 512 when the tile count is a
   // multiple of the slot count).  Rows beyond the last full round go to a 64x64-tile launch that
-  // spreads them over all CUs.
+  // spreads them over all CUs.  (A forked side stream for the tail was measured slower than
+  // same-stream order: the cross-queue event dependencies cost more than the overlap gains.)
   ConvGemmParams main = p, tail = p;
   bool peel = false;
   if (p.splitk <= 1 && p.m_begin == 0) {
@@ -396,20 +501,27 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
       }
     }
   }
-  hipError_t e;
-  // (A forked side stream for the tail was measured slower than same-stream order: the
-  // cross-queue event dependencies cost more than the overlap gains.)
-  hipStream_t tail_stream = stream;
-  if (p.pre_scale) e = launch_variant<128, 128, 2, 2, false, true>(main, stream);
-  else if (p.A2) e = launch_variant<128, 128, 2, 2, true, false>(main, stream);
-  else if (simple) e = launch_variant<128, 128, 2, 2, false, false, true>(main, stream);
-  else e = launch_variant<128, 128, 2, 2, false, false, false>(main, stream);
+  hipError_t e = launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
   if (e != hipSuccess || !peel) return e;
-  if (p.pre_scale) e = launch_variant<64, 64, 2, 2, false, true>(tail, tail_stream);
-  else if (p.A2) e = launch_variant<64, 64, 2, 2, true, false>(tail, tail_stream);
-  else if (simple) e = launch_variant<64, 64, 2, 2, false, false, true>(tail, tail_stream);
-  else e = launch_variant<64, 64, 2, 2, false, false, false>(tail, tail_stream);
-  return e;
+  return launch_mode<64, 64, 2, 2, PREC>(tail, mode, stream);
+}
+
+hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  // 16-byte paths: channel counts / offsets / row strides must be multiples of 4 floats
+  if ((p.N | p.Cin | p.lda | p.a_off | p.ldw | p.ldd | p.d_off) & 3) return hipErrorInvalidValue;
+  if (p.ldw & 31) return hipErrorInvalidValue;
+  if (p.A2 && ((p.lda2 | p.a2_off) & 3)) return hipErrorInvalidValue;
+  if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
+  if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
+  if (p.pre_scale && p.A2) return hipErrorInvalidValue;
+  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
+  if (p.m_begin & 63) return hipErrorInvalidValue;
+  if (p.prec == 1) {
+    if (!p.Wh || !p.Wl) return hipErrorInvalidValue;
+    return launch_prec<1>(p, stream);
+  }
+  return launch_prec<0>(p, stream);
 }
 
 // --------------------------------------------------------------------------- split-K reduce

@@ -89,6 +89,7 @@ struct EcapaModel : ModelBase {
       }
       final_lin.N = embed_dim; final_lin.Cin = 3072; final_lin.ldw = 3072;
       final_lin.w = arena.add(W);
+      add_split(&final_lin, W);
       final_lin.b = arena.add(B);
       final_lin.has_b = true;
     }
@@ -176,7 +177,7 @@ struct EcapaModel : ModelBase {
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st);
       }));
       ConvGemmParams cb = conv1d(pool1, stats, 3072, 0, bias_img, 128, 0, B, 1, 1, ACT_NONE);
-      cb.W = arena.at(pool1.w) + 1536; cb.K = 3072; cb.Cin = 3072;
+      cb.W = arena.at(pool1.w) + 1536; cb.Wh += 1536; cb.Wl += 1536; cb.K = 3072; cb.Cin = 3072;
       WS_LAUNCH(gemm_splitk(cb, partial, kSplitK, st));
       a1.bias = nullptr;
       a1.bias_img = bias_img;

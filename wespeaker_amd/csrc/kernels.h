@@ -20,6 +20,9 @@ struct ConvGemmParams {
                                               // before the conv): a = relu(A*pre_scale[ci] + pre_shift[ci]),
                                               // applied to in-bounds pixels only (padding stays 0)
   const float* W;  int ldw;                   // [N][ldw]; ldw >= taps*Cin, multiple of 32, zero padded
+  const uint16_t* Wh; const uint16_t* Wl;     // hi / lo binary16 planes of W (same layout), prec == 1
+  int prec;                                   // 0: v_mfma_f32_32x32x2_f32 (exact fp32)
+                                              // 1: 3 x v_mfma_f32_32x32x16_f16 on hi/lo splits
   float* D;  int ldd;  int d_off;             // output rows
   float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
   int M, N, K;                                // M output pixels, N output channels, K = taps*Cin

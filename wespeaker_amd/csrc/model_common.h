@@ -15,6 +15,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct ConvW {        // one conv / linear layer resident on the device
   size_t w = 0, b = 0, scale = 0, shift = 0;
+  size_t wh = 0, wl = 0;    // hi / lo binary16 planes of w (same [N][ldw] layout), arena float offsets
   bool has_b = false, has_post = false;
   int N = 0, Cin = 0, kh = 1, kw = 1, ldw = 0;
   int taps() const { return kh * kw; }
@@ -42,9 +43,30 @@ struct ModelBase : Model {
   ModelBase(const std::string& n, int fd, int ed) : name(n), feat_dim(fd), embed_dim(ed) {
     zeros_off = arena.add(nullptr, 64);
   }
+  int set_precision(int mode) override {
+    if (mode != 0 && mode != 1) return WS_ERR_INVALID_ARG;
+    gemm_precision = mode;
+    return WS_OK;
+  }
   float* feats_workspace() override { return feats_ws; }
   int max_batch() const override { return maxB; }
   int max_frames() const override { return maxT; }
+
+  // w = hi + lo with hi = half(w), lo = half(w - hi): the weight operand of the 3-pass f16 MFMA
+  // path (hi*hi + hi*lo + lo*hi reproduces the fp32 product to ~2^-21).
+  void add_split(ConvW* cw, const std::vector<float>& packed) {
+    const size_t n = packed.size();            // multiple of 32
+    std::vector<uint16_t> hi(n), lo(n);
+    for (size_t i = 0; i < n; ++i) {
+      hi[i] = float_to_half_bits(packed[i]);
+      lo[i] = float_to_half_bits(packed[i] - half_bits_to_float(hi[i]));
+    }
+    cw->wh = arena.add(nullptr, n / 2);
+    std::memcpy(arena.host.data() + cw->wh, hi.data(), n * 2);
+    cw->wl = arena.add(nullptr, n / 2);
+    std::memcpy(arena.host.data() + cw->wl, lo.data(), n * 2);
+  }
+  int gemm_precision = 0;     // 0: exact fp32 MFMA, 1: 3-pass split-f16 MFMA (fp32 accumulate)
 
   // ------------------------------------------------------------------------- tensor lookup
   const HostTensor* get(const SD& sd, const std::string& key, std::vector<int64_t> want, int* err) {
@@ -137,6 +159,7 @@ struct ModelBase : Model {
           packed[(size_t)n * out->ldw + (size_t)tp * Cin + ci] =
               (float)((double)wt->data[src(n, tp, ci)] * fsc[n]);
     out->w = arena.add(packed);
+    add_split(out, packed);
     if (has_bias || !fold_bn.empty()) {
       std::vector<float> b(N);
       for (int n = 0; n < N; ++n) b[n] = (float)((bs ? (double)bs->data[n] : 0.0) * fsc[n] + fsh[n]);
@@ -198,6 +221,9 @@ struct ModelBase : Model {
     std::memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.a_off = a_off;
     p.W = arena.at(cw.w); p.ldw = cw.ldw;
+    p.Wh = reinterpret_cast<const uint16_t*>(arena.at(cw.wh));
+    p.Wl = reinterpret_cast<const uint16_t*>(arena.at(cw.wl));
+    p.prec = gemm_precision;
     p.D = D; p.ldd = ldd; p.d_off = d_off;
     p.Hin = Hin; p.Win = Win;
     p.Hout = (Hin + 2 * pad_h - dil_h * (cw.kh - 1) - 1) / stride_h + 1;

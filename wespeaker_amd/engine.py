@@ -109,6 +109,7 @@ class NativeSpeakerModel:
             if not used:
                 self.ignored_keys.append(key)
         _lib.check(L.ws_engine_finalize(h, self.max_batch, self.max_frames), "ws_engine_finalize")
+        self.precision = "fp32"
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -127,6 +128,16 @@ class NativeSpeakerModel:
         if dev.type == "cpu":
             return self          # outputs are returned wherever the caller asks; compute stays on the GPU
         raise _lib.NativeError("engine was created on %s; create a new one for %s" % (self.device, dev))
+
+    PRECISIONS = {"fp32": 0, "f16x3": 1}
+
+    def set_precision(self, mode):
+        """'fp32' (exact fp32 MFMA, default) or 'f16x3' (3-pass split-binary16 MFMA with fp32
+        accumulation; fp32-grade accuracy, several times faster)."""
+        code = self.PRECISIONS[mode] if isinstance(mode, str) else int(mode)
+        _lib.check(_lib.lib().ws_engine_set_precision(self._h, code), "ws_engine_set_precision")
+        self.precision = {v: k for k, v in self.PRECISIONS.items()}[code]
+        return self
 
     def flops(self, batch, frames) -> float:
         return float(_lib.lib().ws_engine_flops(self._h, int(batch), int(frames)))
