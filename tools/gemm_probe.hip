@@ -16,9 +16,13 @@ int main(int argc, char** argv) {
                                {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"},
                                {49152, 512, 512, 1, "512 M=384t"}, {32768, 512, 512, 1, "512 M=256t"},
                                {16384, 512, 512, 1, "512 M=128t"}, {49152, 1536, 1536, 1, "cat M=384t"}};
+  const int prec = argc > 1 ? atoi(argv[1]) : 0;
   float *A, *W, *D, *Z, *bias;
+  uint16_t *Wh, *Wl;
   size_t maxA = 50688ull * 1536, maxW = 1536ull * 1536, maxD = 50688ull * 1536;
   CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&W, maxW * 4)); CK(hipMalloc(&D, maxD * 4));
+  CK(hipMalloc(&Wh, maxW * 2)); CK(hipMalloc(&Wl, maxW * 2));
+  CK(hipMemset(Wh, 0x3c, maxW * 2)); CK(hipMemset(Wl, 0x1c, maxW * 2));
   CK(hipMalloc(&Z, 256)); CK(hipMemset(Z, 0, 256)); CK(hipMalloc(&bias, 1536 * 4));
   std::vector<float> h(maxA);
   for (size_t i = 0; i < maxA; ++i) h[i] = (float)((rand() % 2001) - 1000) / 1000.f;
@@ -29,6 +33,7 @@ int main(int argc, char** argv) {
   for (auto& s : shapes) {
     ConvGemmParams p; memset(&p, 0, sizeof(p));
     int Cin = s.K / s.taps;
+    p.prec = prec; p.Wh = Wh; p.Wl = Wl;
     p.A = A; p.lda = Cin; p.W = W; p.ldw = (s.K + 31) / 32 * 32; p.D = D; p.ldd = s.N;
     p.M = s.M; p.N = s.N; p.K = s.K; p.Cin = Cin;
     p.Hin = p.Hout = 1; p.Win = p.Wout = 198; p.stride_h = p.stride_w = 1; p.kh = 1; p.kw = s.taps;

@@ -53,13 +53,16 @@ constexpr size_t tile_lds_bytes() {
 }
 
 template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2))
+void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int S = LDS_STRIDE;
+  constexpr int NT = 64 * WM * WN;                    // threads per workgroup (4 or 8 wavefronts)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_IT = BM / 32;                       // float4 chunks of A per thread per K-tile
-  constexpr int W_IT = PREC == 0 ? BN / 32 : BN / 64; // W chunks per thread (per plane for PREC 1)
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(PREC == 0 || BN % 64 == 0, "f16x3 stages 64 weight rows per pass");
+  constexpr int AROWS = NT / 8, WROWS = NT / 4;       // rows covered per staging pass
+  constexpr int A_IT = BM / AROWS;                    // float4 chunks of A per thread per K-tile
+  constexpr int W_IT = PREC == 0 ? BN / AROWS : BN / WROWS;  // W chunks per thread (per plane for PREC 1)
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  static_assert(A_IT >= 1 && W_IT >= 1, "tile too small for the thread count");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   if (!SIMPLE) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int m = m0 + r0 + 32 * i;
+      int m = m0 + r0 + AROWS * i;
       bool ok = m < p.M;
       int mm = ok ? m : 0;
       int img = mm / HW;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   if (SIMPLE) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int m = m0 + r0 + 32 * i;
+      const int m = m0 + r0 + AROWS * i;
       const bool ok = m < p.M;
       sa_ptr[i] = ok ? p.A + (long long)m * p.lda + p.a_off + (long long)kt_begin * BK + kc * 4 : p.zeros;
       sa_inc[i] = ok ? BK : 0;
@@ -132,12 +135,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
   for (int i = 0; i < W_IT; ++i) {
     if (PREC == 0) {
-      const int n = n0 + r0 + 32 * i;
+      const int n = n0 + r0 + AROWS * i;
       const bool ok = n < p.N;
       sw_ptr[i] = ok ? p.W + (long long)n * p.ldw + (long long)kt_begin * BK + kc * 4 : p.zeros;
       sw_inc[i] = ok ? BK : 0;
     } else {
-      const int n = n0 + wr0 + 64 * i;
+      const int n = n0 + wr0 + WROWS * i;
       const bool ok = n < p.N;
       const long long off = (long long)n * p.ldw + (long long)kt_begin * BK + wc * 8;
       swh_ptr[i] = ok ? p.Wh + off : reinterpret_cast<const uint16_t*>(p.zeros);
@@ -213,10 +216,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       float* Ws = As + BM * S;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * S + kc * 4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&As[(r0 + AROWS * i) * S + kc * 4]) = ra[i];
 #pragma unroll
       for (int i = 0; i < W_IT; ++i)
-        *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * i) * S + kc * 4]) = rw[i];
+        *reinterpret_cast<f32x4*>(&Ws[(r0 + AROWS * i) * S + kc * 4]) = rw[i];
     } else {
       _Float16* base = reinterpret_cast<_Float16*>(lds + buf * STAGE_FLOATS);
       _Float16* Ah = base;
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
           hi[q] = h;
           lo[q] = (_Float16)(ra[i][q] - (float)h);
         }
-        *reinterpret_cast<f16x4*>(&Ah[(r0 + 32 * i) * HS + kc * 4]) = hi;
-        *reinterpret_cast<f16x4*>(&Al[(r0 + 32 * i) * HS + kc * 4]) = lo;
+        *reinterpret_cast<f16x4*>(&Ah[(r0 + AROWS * i) * HS + kc * 4]) = hi;
+        *reinterpret_cast<f16x4*>(&Al[(r0 + AROWS * i) * HS + kc * 4]) = lo;
       }
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
-        *reinterpret_cast<u32x4*>(&Wh[(wr0 + 64 * i) * HS + wc * 8]) = rwh[i];
-        *reinterpret_cast<u32x4*>(&Wl[(wr0 + 64 * i) * HS + wc * 8]) = rwl[i];
+        *reinterpret_cast<u32x4*>(&Wh[(wr0 + WROWS * i) * HS + wc * 8]) = rwh[i];
+        *reinterpret_cast<u32x4*>(&Wl[(wr0 + WROWS * i) * HS + wc * 8]) = rwl[i];
       }
     }
   };
@@ -261,10 +264,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     store_tile(0);
   }
   __syncthreads();
-  int buf = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool has_next = kt + 1 < kt_end;
-    if (has_next) load_tile(kt + 1);
+  auto compute_tile = [&](int buf) {
     __builtin_amdgcn_s_setprio(1);
     if (PREC == 0) {
       const float* As = lds + buf * STAGE_FLOATS + (wm * TM * 32 + li) * S + lh * 4;
@@ -325,10 +325,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (has_next) store_tile(buf ^ 1);
+  };
+  // Branch-free steady state (the last K-tile is peeled) so that the scheduler may interleave the
+  // conversion / LDS writes of tile k+1 with the MFMAs of tile k.
+  int buf = 0;
+  for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
+    load_tile(kt + 1);
+    compute_tile(buf);
+    store_tile(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
+  if (kt_begin < kt_end) compute_tile(buf);
+  __syncthreads();
 
   // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   __syncthreads();
   {
     constexpr int C4 = BN / 4;                 // float4 columns per tile row
-    constexpr int RPP = 256 / C4;              // rows per pass
+    constexpr int RPP = NT / C4;               // rows per pass
     const int c4 = tid % C4, rr = tid / C4;
     const int n = n0 + c4 * 4;
     constexpr int NH = BM / 64;                // 64-row halves (column-sum granularity)
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         for (int wh = 0; wh < 2; ++wh)
           *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
       __syncthreads();
-      for (int o = tid; o < NH * 2 * BN; o += 256) {
+      for (int o = tid; o < NH * 2 * BN; o += NT) {
         const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
         float sacc = 0.f;
 #pragma unroll
@@ -453,7 +462,7 @@ static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
   dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -501,7 +510,11 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       }
     }
   }
+#ifdef WS_EIGHT_WAVES
+  hipError_t e = launch_mode<128, 128, 2, 4, PREC>(main, mode, stream);
+#else
   hipError_t e = launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
+#endif
   if (e != hipSuccess || !peel) return e;
   return launch_mode<64, 64, 2, 2, PREC>(tail, mode, stream);
 }

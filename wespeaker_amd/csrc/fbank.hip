@@ -24,6 +24,16 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
+// Each wavefront owns its frame and its private slice of LDS: only wave-level ordering is needed
+// between the phases (DS operations of one wave execute in order; the fences stop the compiler from
+// moving LDS accesses across the phase boundary).  No workgroup barrier -> the four frames of a
+// block never wait for each other.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     part += v;
   }
   const float mean = wave_sum_f(part) / (float)L;
-  __syncthreads();
+  wave_sync();
   // 2. pre-emphasis (replicate-pad first sample) + window, zero pad to 512
   for (int j = lane; j < FFT_N; j += 64) {
     float y = 0.f;
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     }
     zr[j] = y;
   }
-  __syncthreads();
+  wave_sync();
 
   // 3. 256-point complex FFT, Stockham radix-4: A -> B -> A -> B -> A
   float2* src = bufA[wave];
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     dst[d0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
     dst[d0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
     dst[d0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
-    __syncthreads();
+    wave_sync();
     float2* t = src; src = dst; dst = t;
   }
   // result Z[0..255] in src (= bufA)
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     const float xi = ei + (orr * w.y + oi * w.x);
     P[k] = xr * xr + xi * xi;
   }
-  __syncthreads();
+  wave_sync();
 
   // 5. mel filterbank + log
   for (int bin = lane; bin < tb.num_bins; bin += 64) {

@@ -49,13 +49,31 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   __syncthreads();
 
   const int co = wn * 16 + li;                          // this lane's output channel
-  for (int step = 0; step < 7; ++step) {
-    // weights of this step for column co: k = 16 g + 4 q + s   (packed [co][tap*W + ci], ld 3W)
+  constexpr bool PF = MTW <= 7;     // enough registers to prefetch the next split during the MFMAs
+  const int t0 = wm * MTW * 16 + lq * 4;
+  // weights of a step for column co: k = 16 g + 4 q + s   (packed [co][tap*W + ci], ld 3W)
+  f32x4 bw[KG];
+  auto load_weights = [&](int step) {
     const float* wrow = p.w[step] + (long long)co * p.ldw + lq * 4;
-    f32x4 bw[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) bw[g] = *reinterpret_cast<const f32x4*>(wrow + g * 16);
+  };
+  load_weights(0);
+  for (int step = 0; step < 7; ++step) {
     const float bias = p.bias[step][co], sc = p.scale[step][co], sh = p.shift[step][co];
+    // next split of y1 (added to this step's output to form the next input): issued now, consumed
+    // in the epilogue, so its latency hides under the MFMAs
+    float y1n[PF ? MTW : 1][4];
+    if (PF && step < 6) {
+      const float* y1u = p.y1 + m_base * p.ldy1 + (step + 1) * W + co;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = t0 + mt * 16 + r;
+          y1n[PF ? mt : 0][r] = t < T ? y1u[(long long)t * p.ldy1] : 0.f;
+        }
+    }
 
     f32x4 acc[MTW];
 #pragma unroll
@@ -72,8 +90,6 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     };
 #pragma unroll
     for (int mp = 0; mp < MTW; mp += 2) {
-      constexpr int kDummy = 0;
-      (void)kDummy;
       const bool two = mp + 1 < MTW;
       f32x4 a0 = *reinterpret_cast<const f32x4*>(xaddr(mp, 0));
       f32x4 a1 = two ? *reinterpret_cast<const f32x4*>(xaddr(mp + 1, 0)) : a0;
@@ -94,6 +110,8 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
         a0 = n0; a1 = n1;
       }
     }
+    // the weight registers are free now: fetch the next step's weights under the epilogue
+    if (step < 6) load_weights(step + 1);
     __syncthreads();                                    // everyone finished reading X
     // C/D layout 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg.
     // The row strides are laundered through an empty asm so the 4*MTW row addresses are
@@ -103,7 +121,6 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     asm volatile("" : "+v"(ld1), "+v"(ld2));
     const float* y1u = p.y1 + m_base * ld1 + (step + 1) * W + co;
     float* y2u = p.y2 + m_base * ld2 + step * W + co;
-    const int t0 = wm * MTW * 16 + lq * 4;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
         if (t < T) {
           float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
           y2u[t * ld2] = v;
-          if (step < 6) X[(t + d) * XS + co] = v + y1u[t * ld1];
+          if (step < 6) X[(t + d) * XS + co] = v + (PF ? y1n[PF ? mt : 0][r] : y1u[t * ld1]);
         }
       }
     }
