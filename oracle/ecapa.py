@@ -99,11 +99,16 @@ def tstp(x):
 
 
 @torch.no_grad()
-def ecapa_forward(sd, feats, return_intermediates=False):
+def ecapa_forward(sd, feats, return_intermediates=False, dtype=torch.float32):
     """feats: (B, T, F) float32 (already CMN'd) -> embeddings (B, E) float32.
 
-    sd: state_dict with the reference's key names (tensors or numpy arrays)."""
-    x = torch.as_tensor(feats, dtype=torch.float32).permute(0, 2, 1)
+    sd: state_dict with the reference's key names (tensors or numpy arrays).
+    dtype=torch.float64 evaluates the same network in double precision (a ground truth for
+    judging fp32 rounding noise; the reference itself runs in float32)."""
+    if dtype != torch.float32:
+        sd = {k: (torch.as_tensor(v).to(dtype) if torch.as_tensor(v).is_floating_point()
+                  else torch.as_tensor(v)) for k, v in sd.items()}
+    x = torch.as_tensor(feats).to(dtype).permute(0, 2, 1)
     out1 = _conv_relu_bn(sd, "layer1", x, padding=2)
     out2 = _se_res2block(sd, "layer2", out1, 2)
     out3 = _se_res2block(sd, "layer3", out2, 3)

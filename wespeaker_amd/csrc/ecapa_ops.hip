@@ -92,13 +92,14 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
 }
 
 // ------------------------------------------------------ SE FCs from GEMM-epilogue column sums
-// grid = B, block = 512.  C <= 1024, bottleneck <= 256.
+// grid = B, block = 512.  C <= 1024, bottleneck <= 256.  Both FCs keep many independent 16-B
+// weight loads in flight per lane (the dependent one-row-at-a-time form was L2-latency bound).
 __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
     const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
     int bott, float* __restrict__ s) {
-  __shared__ float mean[1024];
-  __shared__ float hidden[256];
+  __shared__ __attribute__((aligned(16))) float mean[1024];
+  __shared__ __attribute__((aligned(16))) float hidden[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
   const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
@@ -113,36 +114,46 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  for (int j = wave; j < bott; j += 8) {
-    const float* wr = w1 + (long long)j * C;
-    float v = 0.f;
+  // FC1: hidden = relu(W1 mean + b1); 4 rows per wavefront pass (4 x C/256 loads in flight)
+  for (int j0 = wave * 4; j0 < bott; j0 += 32) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
-      v += w[0] * mean[c] + w[1] * mean[c + 1] + w[2] * mean[c + 2] + w[3] * mean[c + 3];
-    }
-    v = wave_sum(v);
-    if (lane == 0) hidden[j] = fmaxf(v + b1[j], 0.f);
-  }
-  __syncthreads();
-  // one half-wave (32 lanes x float4 = 128 k) per output row: coalesced 512-B row reads
-  const int half = lane >> 5, hl = lane & 31;
-  for (int c = wave * 2 + half; c < C; c += 16) {
-    const float* wr = w2 + (long long)c * bott;
-    float v = 0.f;
-    for (int k = hl * 4; k < bott; k += 128) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
-      v += w[0] * hidden[k] + w[1] * hidden[k + 1] + w[2] * hidden[k + 2] + w[3] * hidden[k + 3];
+      const f32x4 m = *reinterpret_cast<const f32x4*>(&mean[c]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + (long long)(j0 + q) * C + c);
+        v[q] += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
+      }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (hl == 0) s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + b2[c])));
+    for (int q = 0; q < 4; ++q) {
+      const float t = wave_sum(v[q]);
+      if (lane == 0) hidden[j0 + q] = fmaxf(t + b1[j0 + q], 0.f);
+    }
+  }
+  __syncthreads();
+  // FC2: thread per output channel; its weight row is bott contiguous floats, 8 loads in flight
+  for (int c = tid; c < C; c += 512) {
+    const float* wr = w2 + (long long)c * bott;
+    float v = 0.f;
+    for (int k = 0; k < bott; k += 32) {
+      f32x4 w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(wr + k + q * 4);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(&hidden[k + q * 4]);
+        v += w[q][0] * h[0] + w[q][1] * h[1] + w[q][2] * h[2] + w[q][3] * h[3];
+      }
+    }
+    s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + b2[c])));
   }
 }
 
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                     const float* b1, const float* w2, const float* b2,
                                     int bottleneck, float* s, hipStream_t stream) {
-  if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || T < 64)
+  if (C > 1024 || (C & 255) || bottleneck > 256 || (bottleneck & 31) || T < 64)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(se_fc_from_colsum_kernel, dim3(B), dim3(512), 0, stream, colsum, T, C, w1, b1,
                      w2, b2, bottleneck, s);
