@@ -131,9 +131,11 @@ struct EcapaModel : ModelBase {
         r.y1 = y1; r.ldy1 = C; r.y2 = y2; r.ldy2 = C; r.ldw = res2[L][0].ldw;
         for (int i = 0; i < 7; ++i) {
           r.w[i] = arena.at(res2[L][i].w); r.bias[i] = arena.at(res2[L][i].b);
+          r.wh[i] = reinterpret_cast<const uint16_t*>(arena.at(res2[L][i].wh));
+          r.wl[i] = reinterpret_cast<const uint16_t*>(arena.at(res2[L][i].wl));
           r.scale[i] = arena.at(res2[L][i].scale); r.shift[i] = arena.at(res2[L][i].shift);
         }
-        r.B = B; r.T = T; r.W = w; r.dil = d;
+        r.B = B; r.T = T; r.W = w; r.dil = d; r.prec = gemm_precision;
         if (prof.enabled) prof.begin(1, 2.0 * B * (double)T * w * 3 * w * 7, 4.0 * B * (double)T * C * 2, st);
         hipError_t re = launch_res2_chain(r, st);
         prof.end(st);

@@ -56,8 +56,10 @@ struct Res2ChainParams {
   const float* y1; int ldy1;
   float* y2; int ldy2;
   const float* w[7]; int ldw;               // packed [W][tap*W + ci], ldw = 3W
+  const uint16_t* wh[7]; const uint16_t* wl[7];   // hi / lo binary16 planes of w (prec == 1)
   const float* bias[7]; const float* scale[7]; const float* shift[7];
   int B, T, W, dil;
+  int prec;                                 // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
 };
 bool res2_chain_supported(int W, int T, int dil);
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);

@@ -137,6 +137,166 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same chain on the split-binary16 back-end: X is kept in LDS as hi / lo half planes, every product
+// is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (fp32 accumulate).  Row stride W+16 halfs
+// keeps the ds_read_b128 lane groups on 16 distinct 16-B slots.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int W, int MTW>
+__global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainParams p) {
+  constexpr int NT = W / 16;
+  constexpr int MW = 8 / NT;
+  constexpr int XS = W + 16;            // halfs per LDS row
+  constexpr int KS = 3 * W / 32;        // 32-wide k-steps per conv step
+  extern __shared__ __attribute__((aligned(16))) _Float16 Xs[];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % NT, wm = wave / NT;
+  const int li = lane & 15, lq = lane >> 4;
+  const int T = p.T, d = p.dil;
+  const int rows_total = MW * MTW * 16 + 2 * d;
+  _Float16* Xh = Xs;
+  _Float16* Xl = Xs + rows_total * XS;
+  const long long m_base = (long long)b * T;
+
+  for (int i = tid * 8; i < 2 * rows_total * XS; i += 512 * 8)
+    *reinterpret_cast<f16x8*>(&Xs[i]) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();
+  {
+    constexpr int C4 = W / 4;
+    for (int i = tid; i < T * C4; i += 512) {
+      const int t = i / C4, c = (i - t * C4) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.y1 + (m_base + t) * p.ldy1 + c);
+      f16x4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hi[q] = (_Float16)v[q];
+        lo[q] = (_Float16)(v[q] - (float)hi[q]);
+      }
+      *reinterpret_cast<f16x4*>(&Xh[(t + d) * XS + c]) = hi;
+      *reinterpret_cast<f16x4*>(&Xl[(t + d) * XS + c]) = lo;
+    }
+  }
+  __syncthreads();
+
+  const int co = wn * 16 + li;
+  constexpr bool PF = MTW <= 7;
+  const int t0 = wm * MTW * 16 + lq * 4;
+  // lane (j = co, q) holds k = 32 ks + 8 q .. +7 of its weight row
+  f16x8 bh[KS], bl[KS];
+  auto load_weights = [&](int step) {
+    const long long off = (long long)co * p.ldw + lq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[ks] = *reinterpret_cast<const f16x8*>(p.wh[step] + off + ks * 32);
+      bl[ks] = *reinterpret_cast<const f16x8*>(p.wl[step] + off + ks * 32);
+    }
+  };
+  load_weights(0);
+  for (int step = 0; step < 7; ++step) {
+    const float bias = p.bias[step][co], sc = p.scale[step][co], sh = p.shift[step][co];
+    // Row strides / the LDS write base are laundered through an empty asm once per step so the
+    // 4*MTW per-element addresses are recomputed inside the step instead of being hoisted out of
+    // the step loop (where they would live across the MFMA section and spill).
+    int ld1 = p.ldy1, ld2 = p.ldy2, xw = (t0 + d) * XS + co;
+    asm volatile("" : "+v"(ld1), "+v"(ld2), "+v"(xw));
+    float y1n[PF ? MTW : 1][4];
+    if (PF && step < 6) {
+      const float* y1u = p.y1 + m_base * ld1 + (step + 1) * W + co + (long long)t0 * ld1;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = t0 + mt * 16 + r;
+          y1n[PF ? mt : 0][r] = t < T ? y1u[(mt * 16 + r) * ld1] : 0.f;
+        }
+    }
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // k-step ks covers k in [32 ks, 32 ks + 32) = tap (32 ks) / W, channels (32 ks) % W ...
+    const int xrow = wm * MTW * 16 + li;
+    auto xoff = [&](int mt, int ks) {
+      const int tap = (32 * ks) / W, cg = (32 * ks) % W;
+      return (xrow + mt * 16 + tap * d) * XS + cg + lq * 8;
+    };
+#pragma unroll
+    for (int mp = 0; mp < MTW; mp += 2) {
+      const bool two = mp + 1 < MTW;
+      int o0 = xoff(mp, 0), o1 = xoff(two ? mp + 1 : mp, 0);
+      f16x8 a0h = *reinterpret_cast<const f16x8*>(&Xh[o0]);
+      f16x8 a0l = *reinterpret_cast<const f16x8*>(&Xl[o0]);
+      f16x8 a1h = *reinterpret_cast<const f16x8*>(&Xh[o1]);
+      f16x8 a1l = *reinterpret_cast<const f16x8*>(&Xl[o1]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
+        if (ks + 1 < KS) {                       // fragments of the next k-step, one step ahead
+          o0 = xoff(mp, ks + 1); o1 = xoff(two ? mp + 1 : mp, ks + 1);
+          n0h = *reinterpret_cast<const f16x8*>(&Xh[o0]);
+          n0l = *reinterpret_cast<const f16x8*>(&Xl[o0]);
+          if (two) {
+            n1h = *reinterpret_cast<const f16x8*>(&Xh[o1]);
+            n1l = *reinterpret_cast<const f16x8*>(&Xl[o1]);
+          }
+        }
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, bh[ks], acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh[ks], acc[mp + 1], 0, 0, 0);
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bl[ks], acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl[ks], acc[mp + 1], 0, 0, 0);
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bh[ks], acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh[ks], acc[mp + 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+      }
+    }
+    if (step < 6) load_weights(step + 1);
+    __syncthreads();
+    const float* y1e = p.y1 + m_base * ld1 + (step + 1) * W + co + (long long)t0 * ld1;
+    float* y2u = p.y2 + m_base * ld2 + step * W + co + (long long)t0 * ld2;
+    _Float16* xh = Xh + xw;
+    _Float16* xl = Xl + xw;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + mt * 16 + r;
+        if (t < T) {
+          const float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
+          y2u[(mt * 16 + r) * ld2] = v;
+          if (step < 6) {
+            const float x = v + (PF ? y1n[PF ? mt : 0][r] : y1e[(mt * 16 + r) * ld1]);
+            const _Float16 h = (_Float16)x;
+            xh[(mt * 16 + r) * XS] = h;
+            xl[(mt * 16 + r) * XS] = (_Float16)(x - (float)h);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int W, int MTW>
+static hipError_t launch_res2_f16_variant(const Res2ChainParams& p, hipStream_t stream) {
+  constexpr int MW = 8 / (W / 16);
+  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16);
+  auto kern = res2_chain_f16x3_kernel<W, MTW>;
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+  return hipGetLastError();
+}
+
 template <int W, int MTW>
 static hipError_t launch_res2_variant(const Res2ChainParams& p, hipStream_t stream) {
   constexpr int MW = 8 / (W / 16);
@@ -162,6 +322,15 @@ bool res2_chain_supported(int W, int T, int dil) {
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
+  if (p.prec == 1) {
+    if (p.W == 64) {
+      if (p.T <= 2 * 7 * 16) return launch_res2_f16_variant<64, 7>(p, stream);
+      if (p.T <= 2 * 13 * 16) return launch_res2_f16_variant<64, 13>(p, stream);
+    } else if (p.W == 128) {
+      if (p.T <= 13 * 16) return launch_res2_f16_variant<128, 13>(p, stream);
+    }
+    return hipErrorInvalidValue;
+  }
   if (p.W == 64) {
     if (p.T <= 2 * 7 * 16) return launch_res2_variant<64, 7>(p, stream);
     if (p.T <= 2 * 13 * 16) return launch_res2_variant<64, 13>(p, stream);
