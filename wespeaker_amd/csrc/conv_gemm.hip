@@ -381,6 +381,63 @@ void conv_gemm_kernel(const ConvGemmParams p) {
     f32x4 cs[NH][2];
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) cs[hf][0] = cs[hf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // softmax-pooling partials (ASTP fused into the logit GEMM): running max + 3 weighted sums
+    f32x4 pm[NH][2], p0[NH][2], p1[NH][2], p2[NH][2];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh) {
+        pm[hf][wh] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+        p0[hf][wh] = p1[hf][wh] = p2[hf][wh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    if (p.pool_partial) {
+      // ASTP fused into the logit GEMM: the logits are never written to HBM.  All h rows of a
+      // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
+      // online-softmax tuples of the (half, image part) groups.
+      if (n < p.N) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+          const int mh = m0 + hf * 64;
+          const int rb = (mh / HW + 1) * HW - mh;
+          constexpr int RI = 64 / RPP;
+          f32x4 hv[RI];
+#pragma unroll
+          for (int i = 0; i < RI; ++i) {
+            const int m = mh + rr + RPP * i;
+            const int mc = m < p.M ? m : p.M - 1;
+            hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+          }
+#pragma unroll
+          for (int i = 0; i < RI; ++i) {
+            const int rl = rr + RPP * i;
+            if (mh + rl < p.M) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
+              const bool second = rl >= rb;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float mo = second ? pm[hf][1][q] : pm[hf][0][q];
+                const float mn = fmaxf(mo, v[q]);
+                const float sc = __expf(mo - mn), pe = __expf(v[q] - mn);
+                const float h1 = pe * hv[i][q], h2 = h1 * hv[i][q];
+                if (second) {
+                  pm[hf][1][q] = mn;
+                  p0[hf][1][q] = p0[hf][1][q] * sc + pe;
+                  p1[hf][1][q] = p1[hf][1][q] * sc + h1;
+                  p2[hf][1][q] = p2[hf][1][q] * sc + h2;
+                } else {
+                  pm[hf][0][q] = mn;
+                  p0[hf][0][q] = p0[hf][0][q] * sc + pe;
+                  p1[hf][0][q] = p1[hf][0][q] * sc + h1;
+                  p2[hf][0][q] = p2[hf][0][q] * sc + h2;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else
     if (n < p.N) {                             // N % 4 == 0 (checked on the host)
       f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -443,6 +500,41 @@ void conv_gemm_kernel(const ConvGemmParams p) {
         for (int q = 0; q < RPP; ++q) sacc += red[(hw * RPP + q) * BN + col];
         if (n0 + col < p.N)
           p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
+      }
+    }
+    if (p.pool_partial) {
+      // fold the RPP row phases: (max, s0, s1, s2) tuples combined with the usual rescaling;
+      // one [4]-tuple per (64-row tile, image part, column) -> pool_partial[tile64*2 + which][N][4]
+      __syncthreads();
+      float* red = lds;                                 // [NH*2][RPP][4][BN]
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh) {
+          float* r0p = &red[(((hf * 2 + wh) * RPP + rr) * 4) * BN + c4 * 4];
+          *reinterpret_cast<f32x4*>(r0p) = pm[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + BN) = p0[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + 2 * BN) = p1[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + 3 * BN) = p2[hf][wh];
+        }
+      __syncthreads();
+      for (int o = tid; o < NH * 2 * BN; o += NT) {
+        const int hw = o / BN, col = o - hw * BN;
+        float mx = -1e30f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) mx = fmaxf(mx, red[((hw * RPP + q) * 4) * BN + col]);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) {
+          const float* e = &red[((hw * RPP + q) * 4) * BN + col];
+          const float sc = __expf(e[0] - mx);
+          a0 += e[BN] * sc; a1 += e[2 * BN] * sc; a2 += e[3 * BN] * sc;
+        }
+        if (n0 + col < p.N) {
+          f32x4 outv = {mx, a0, a1, a2};
+          *reinterpret_cast<f32x4*>(
+              p.pool_partial + (((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col) * 4) = outv;
+        }
       }
     }
   }
@@ -529,6 +621,8 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
   if (p.pre_scale && p.A2) return hipErrorInvalidValue;
   if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
+  if (p.pool_partial && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64 || !p.pool_h || (p.ldh & 3)))
+    return hipErrorInvalidValue;
   if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.prec == 1) {
     if (!p.Wh || !p.Wl) return hipErrorInvalidValue;

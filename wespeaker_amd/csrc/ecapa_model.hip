@@ -11,6 +11,8 @@
 // split is dual-stored by the producing GEMM, eval-mode BN is an epilogue affine after the ReLU
 // (the reference order is conv -> ReLU -> BN, so it cannot be folded into the conv weights), the
 // last BN + Linear (+ bn2) are folded on the host in float64.
+#include <cstdlib>
+
 #include "model_common.h"
 
 namespace wsamd {
@@ -185,10 +187,21 @@ struct EcapaModel : ModelBase {
       a1.bias_img = bias_img;
     }
     WS_LAUNCH(gemm(a1, st));
-    WS_LAUNCH(gemm(conv1d(pool2, att, 128, 0, e, 1536, 0, B, T, 1, ACT_NONE), st));
-    WS_LAUNCH(other(8.0 * B * (double)T * 1536, st, [&] {
-      return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st);
-    }));
+    static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
+    if (T >= 64 && !no_fuse) {
+      // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
+      ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
+      l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer
+      WS_LAUNCH(gemm(l2, st));
+      WS_LAUNCH(other(0.0, st, [&] {
+        return launch_astp_pool_from_partials(e, B, T, 1536, pooled, st);
+      }));
+    } else {
+      WS_LAUNCH(gemm(conv1d(pool2, att, 128, 0, e, 1536, 0, B, T, 1, ACT_NONE), st));
+      WS_LAUNCH(other(8.0 * B * (double)T * 1536, st, [&] {
+        return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st);
+      }));
+    }
     // BN + Linear (+bn2), folded: split-K GEMM over K = 3072
     WS_LAUNCH(gemm_splitk(conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
                           partial, kSplitK, st));

@@ -308,6 +308,41 @@ __global__ __launch_bounds__(256) void astp_pool_kernel(const float* __restrict_
   pooled[(long long)b * 2 * C + C + c] = sqrtf(fmaxf(var, 1e-7f));
 }
 
+// grid = (B, C/256): merge the per-tile online-softmax tuples written by the logit GEMM
+__global__ __launch_bounds__(256) void astp_pool_from_partials_kernel(
+    const float* __restrict__ partials, int T, int C, float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)b * T, r1 = r0 + T - 1;
+  const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
+  float mx = -1e30f;
+  for (int tm = t_first; tm <= t_last; ++tm) {
+    const int which = ((int)(((long long)tm * 64) / T) == b) ? 0 : 1;
+    mx = fmaxf(mx, partials[(((long long)tm * 2 + which) * C + c) * 4]);
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int tm = t_first; tm <= t_last; ++tm) {
+    const int which = ((int)(((long long)tm * 64) / T) == b) ? 0 : 1;
+    const f32x4 e = *reinterpret_cast<const f32x4*>(partials + (((long long)tm * 2 + which) * C + c) * 4);
+    const float sc = expf(e[0] - mx);
+    s0 += e[1] * sc; s1 += e[2] * sc; s2 += e[3] * sc;
+  }
+  const float inv = 1.f / s0;
+  const float mean = s1 * inv;
+  const float var = s2 * inv - mean * mean;
+  pooled[(long long)b * 2 * C + c] = mean;
+  pooled[(long long)b * 2 * C + C + c] = sqrtf(fmaxf(var, 1e-7f));
+}
+
+hipError_t launch_astp_pool_from_partials(const float* partials, int B, int T, int C, float* pooled,
+                                          hipStream_t stream) {
+  if (T < 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(astp_pool_from_partials_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream,
+                     partials, T, C, pooled);
+  return hipGetLastError();
+}
+
 hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
                             float* pooled, hipStream_t stream) {
   hipLaunchKernelGGL(astp_pool_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, e, lde, h,

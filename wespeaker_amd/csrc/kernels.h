@@ -41,6 +41,11 @@ struct ConvGemmParams {
   float* colsum;                              // optional [ceil(M/64)][2][N]: column sums of the stored
                                               // values per 64-row tile, split at the image boundary
                                               // inside the tile (needs Hout*Wout >= 64 rows per image)
+  const float* pool_h; int ldh;               // optional fused attentive-statistics pooling: the GEMM
+  float* pool_partial;                        // output is the LOGIT tensor e; instead of storing it,
+                                              // online-softmax partials over rows of (max, sum w,
+                                              // sum w*h, sum w*h^2), w = exp(e - max), per 64-row tile
+                                              // and image part -> pool_partial[ceil(M/64)*2][N][4]
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
 };
@@ -84,6 +89,10 @@ hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
                                     int ldw1, const float* b1, int bottleneck, float* stats,
                                     float* bias_img, hipStream_t stream);
+// Final combine of ConvGemmParams::pool_partial: per (b, c) merge the tile tuples of utterance b,
+// mean = S1/S0, std = sqrt(max(S2/S0 - mean^2, 1e-7)) -> pooled[b] = [mean(C) | std(C)]
+hipError_t launch_astp_pool_from_partials(const float* partials, int B, int T, int C, float* pooled,
+                                          hipStream_t stream);
 // ASTP pooling (pooling_layers.py:138-144): softmax over T of logits e, weighted mean / std of h
 // -> pooled[b] = [mean(C) | std(C)]
 hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
