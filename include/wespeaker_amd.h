@@ -145,16 +145,19 @@ int ws_plda_prepare_test(ws_plda* plda, const float* emb, int n, const double* m
 int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_stream stream);
 /* Dense LLR matrix: log_likelihood_ratio (two_cov_plda.py:165-184) for every (enroll i, test j).
  * enroll DEVICE float64 (n_enroll, dim) transformed; n_sessions DEVICE int32[n_enroll] (the `n`
- * argument: 1 if multisession_avg else #utts, :219-222); test DEVICE float64 (n_test, dim);
+ * argument: 1 if multisession_avg else #utts, :219-222), or NULL when every model has the same
+ * count n_uniform > 0 (multisession_avg=True => n_uniform = 1): the score is then one dim-long
+ * contraction plus a per-model and a per-test constant; test DEVICE float64 (n_test, dim);
  * out DEVICE float64 (n_enroll, n_test). */
 int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
-                       int n_enroll, const double* test, int n_test, double* out,
+                       int n_uniform, int n_enroll, const double* test, int n_test, double* out,
                        ws_stream stream);
 /* Explicit trial list (the eval_sv trial loop :246-256): out[p] = LLR(enroll[idx_e[p]],
  * test[idx_t[p]], n_sessions[idx_e[p]]).  idx_* DEVICE int32[num_trials]; out DEVICE float64. */
 int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
-                      int n_enroll, const double* test, int n_test, const int32_t* idx_e,
-                      const int32_t* idx_t, int64_t num_trials, double* out, ws_stream stream);
+                      int n_uniform, int n_enroll, const double* test, int n_test,
+                      const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
+                      ws_stream stream);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,32 @@ def test_plda_matches_oracle_and_reference_golden(normalize_length, golden_dir):
     assert plda.llr_pairs(E, nn, T, ie[:0], it[:0]).shape == (0,)
 
 
+@pytest.mark.parametrize("normalize_length", [False, True])
+def test_plda_large_tables_take_the_gemm_paths(normalize_length):
+    """>= 128 vectors: pre-processing runs as rows -> f64 MFMA GEMM -> row norm; uniform and per-model
+    session counts take different contraction lengths (D vs 2D).  All must agree with the oracle."""
+    from wespeaker_amd import TwoCovPLDA
+    p = synth.synth_plda(192, seed=7, normalize_length=normalize_length)
+    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    emb, _ = synth.synth_embeddings(700, 192, seed=3)
+    mean = emb.mean(0).astype(np.float64)
+    t_t = plda.prepare_test(emb[:300], mean).cpu().numpy()
+    ref_t = np.stack([oplda.prepare_test(p, e, mean) for e in emb[:300]])
+    assert np.abs(t_t - ref_t).max() < 1e-9
+    offs = np.arange(0, 401, 2)                       # 200 enrollment models of 2 utterances
+    e_t = plda.prepare_enroll(emb[300:700], offs, mean).cpu().numpy()
+    ref_e = np.stack([oplda.prepare_enroll(p, emb[300 + 2 * i:302 + 2 * i], mean)[0] for i in range(200)])
+    assert np.abs(e_t - ref_e).max() < 1e-9
+    for n in (1, 2):
+        mat = plda.llr_matrix(e_t, n, t_t).cpu().numpy()                    # uniform-n path
+        gen = plda.llr_matrix(e_t, torch.full((200,), n, dtype=torch.int32), t_t).cpu().numpy()
+        ref = oplda.llr_matrix_vectorised(p, ref_e, np.full(200, n), ref_t)
+        assert np.abs(mat - ref).max() < 1e-8 and np.abs(gen - ref).max() < 1e-8
+        ie, it = synth.synth_trial_pairs(5000, 200, 300, seed=n)
+        pr = plda.llr_pairs(e_t, n, t_t, ie, it).cpu().numpy()
+        assert np.abs(pr - ref[ie, it]).max() < 1e-8
+
+
 @pytest.mark.parametrize("normalize_length,multisession_avg", [(False, True), (True, False)])
 def test_score_plda_and_eval_sv_files(tmp_path, normalize_length, multisession_avg):
     from wespeaker_amd import TwoCovPLDA, kaldi_io, score_plda

@@ -41,10 +41,10 @@ SIGNATURES = {
                                        c_void_p]),
     "ws_plda_prepare_test": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ws_plda_transform": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "ws_plda_llr_matrix": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                   c_void_p]),
-    "ws_plda_llr_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                  c_void_p, c_int64, c_void_p, c_void_p]),
+    "ws_plda_llr_matrix": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p]),
+    "ws_plda_llr_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 

@@ -33,8 +33,9 @@ struct ws_frontend {
 struct ws_plda {
   int dim = 0, device = 0, normalize_length = 0;
   DevBuf mu, transform, psi, offset, mean_vec;
-  DevBuf EA, rowc, TT;            // GEMM operand scratch (grown on demand)
-  size_t cap_e = 0, cap_t = 0;
+  DevBuf EA, rowc, TT, colc;      // GEMM operand scratch (grown on demand)
+  DevBuf V;                       // pre-processed rows before the transform GEMM
+  size_t cap_e = 0, cap_t = 0, cap_v = 0;
 };
 
 extern "C" {
@@ -133,6 +134,7 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
   t.mel_start = fe->mel_start.as<int>(); t.mel_len = fe->mel_len.as<int>();
   t.mel_off = fe->mel_off.as<int>(); t.mel_w = fe->mel_w.as<float>();
   t.frame_len = L; t.frame_shift = fe->frame_shift; t.fft_n = NF; t.num_bins = num_mel_bins;
+  t.mel_w_total = (int)wts.size();
   *out = fe;
   return WS_OK;
 }
@@ -328,9 +330,22 @@ static int plda_prepare(ws_plda* p, const void* emb, int is_f64, const int32_t* 
                                 hipMemcpyHostToDevice, st));
     mv = p->mean_vec.as<double>();
   }
-  WS_HIP_CHECK(launch_plda_prepare(emb, is_f64, groups, n_out, p->dim, mv,
-                                   p->transform.as<double>(), p->offset.as<double>(), pre_norm,
-                                   p->normalize_length, out, st));
+  if (n_out < 128) {            // few vectors: one workgroup per vector
+    WS_HIP_CHECK(launch_plda_prepare(emb, is_f64, groups, n_out, p->dim, mv,
+                                     p->transform.as<double>(), p->offset.as<double>(), pre_norm,
+                                     p->normalize_length, out, st));
+    return WS_OK;
+  }
+  // many vectors: rows -> V, Y = V transform^T + offset on the f64 MFMA GEMM, row re-normalisation
+  if ((size_t)n_out > p->cap_v) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));
+    WS_HIP_CHECK(p->V.alloc((size_t)n_out * p->dim * sizeof(double)));
+    p->cap_v = n_out;
+  }
+  WS_HIP_CHECK(launch_plda_rows(emb, is_f64, groups, n_out, p->dim, mv, pre_norm, p->V.as<double>(), st));
+  WS_HIP_CHECK(launch_plda_llr_gemm(p->V.as<double>(), nullptr, p->offset.as<double>(), n_out,
+                                    p->transform.as<double>(), p->dim, p->dim, out, st));
+  if (p->normalize_length) WS_HIP_CHECK(launch_plda_rownorm(out, n_out, p->dim, st));
   return WS_OK;
 }
 
@@ -362,8 +377,12 @@ int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_str
   return plda_prepare(plda, x, 1, nullptr, n, nullptr, 0, out, (hipStream_t)stream);
 }
 
-static int plda_terms(ws_plda* p, const double* enroll, const int32_t* n_sessions, int n_enroll,
-                      const double* test, int n_test, hipStream_t st) {
+// GEMM / gather operands.  Uniform n (n_sessions == NULL): K = dim, B operand = the test matrix
+// itself, the t^2 term is the per-test constant colc.  Per-model n: K = 2 dim, B = [t | t^2].
+struct PldaOps { const double* A; const double* Bm; const double* colc; int K; };
+
+static int plda_terms(ws_plda* p, const double* enroll, const int32_t* n_sessions, int n_uniform,
+                      int n_enroll, const double* test, int n_test, hipStream_t st, PldaOps* ops) {
   const size_t D2 = 2 * (size_t)p->dim;
   if ((size_t)n_enroll > p->cap_e) {
     WS_HIP_CHECK(hipStreamSynchronize(st));
@@ -374,36 +393,49 @@ static int plda_terms(ws_plda* p, const double* enroll, const int32_t* n_session
   if ((size_t)n_test > p->cap_t) {
     WS_HIP_CHECK(hipStreamSynchronize(st));
     WS_HIP_CHECK(p->TT.alloc((size_t)n_test * D2 * sizeof(double)));
+    WS_HIP_CHECK(p->colc.alloc((size_t)n_test * sizeof(double)));
     p->cap_t = n_test;
   }
-  WS_HIP_CHECK(launch_plda_enroll_terms(enroll, n_sessions, n_enroll, p->dim, p->psi.as<double>(),
-                                        p->EA.as<double>(), p->rowc.as<double>(), st));
-  WS_HIP_CHECK(launch_plda_test_terms(test, n_test, p->dim, p->TT.as<double>(), st));
+  WS_HIP_CHECK(launch_plda_enroll_terms(enroll, n_sessions, n_uniform, n_enroll, p->dim,
+                                        p->psi.as<double>(), p->EA.as<double>(),
+                                        p->rowc.as<double>(), st));
+  ops->A = p->EA.as<double>();
+  if (n_sessions) {
+    WS_HIP_CHECK(launch_plda_test_terms(test, n_test, p->dim, p->TT.as<double>(), st));
+    ops->Bm = p->TT.as<double>(); ops->colc = nullptr; ops->K = 2 * p->dim;
+  } else {
+    WS_HIP_CHECK(launch_plda_test_colc(test, n_test, p->dim, n_uniform, p->psi.as<double>(),
+                                       p->colc.as<double>(), st));
+    ops->Bm = test; ops->colc = p->colc.as<double>(); ops->K = p->dim;
+  }
   return WS_OK;
 }
 
 int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
-                       int n_enroll, const double* test, int n_test, double* out,
+                       int n_uniform, int n_enroll, const double* test, int n_test, double* out,
                        ws_stream stream) {
-  if (!plda || !enroll || !n_sessions || !test || !out || n_enroll < 0 || n_test < 0) {
+  if (!plda || !enroll || (!n_sessions && n_uniform <= 0) || !test || !out || n_enroll < 0 ||
+      n_test < 0) {
     set_error("ws_plda_llr_matrix: invalid argument");
     return WS_ERR_INVALID_ARG;
   }
   if (n_enroll == 0 || n_test == 0) return WS_OK;
   hipStream_t st = (hipStream_t)stream;
-  int r = plda_terms(plda, enroll, n_sessions, n_enroll, test, n_test, st);
+  PldaOps ops;
+  int r = plda_terms(plda, enroll, n_sessions, n_uniform, n_enroll, test, n_test, st, &ops);
   if (r) return r;
-  WS_HIP_CHECK(launch_plda_llr_gemm(plda->EA.as<double>(), plda->rowc.as<double>(), n_enroll,
-                                    plda->TT.as<double>(), n_test, 2 * plda->dim, out, st));
+  WS_HIP_CHECK(launch_plda_llr_gemm(ops.A, plda->rowc.as<double>(), ops.colc, n_enroll, ops.Bm,
+                                    n_test, ops.K, out, st));
   return WS_OK;
 }
 
 int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
-                      int n_enroll, const double* test, int n_test, const int32_t* idx_e,
-                      const int32_t* idx_t, int64_t num_trials, double* out, ws_stream stream) {
+                      int n_uniform, int n_enroll, const double* test, int n_test,
+                      const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
+                      ws_stream stream) {
   if (plda && num_trials == 0) return WS_OK;        // empty trial list: nothing to do
-  if (!plda || !enroll || !n_sessions || !test || !out || !idx_e || !idx_t || n_enroll < 0 ||
-      n_test < 0 || num_trials < 0) {
+  if (!plda || !enroll || (!n_sessions && n_uniform <= 0) || !test || !out || !idx_e || !idx_t ||
+      n_enroll < 0 || n_test < 0 || num_trials < 0) {
     set_error("ws_plda_llr_pairs: invalid argument");
     return WS_ERR_INVALID_ARG;
   }
@@ -412,11 +444,11 @@ int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sess
     return WS_ERR_INVALID_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
-  int r = plda_terms(plda, enroll, n_sessions, n_enroll, test, n_test, st);
+  PldaOps ops;
+  int r = plda_terms(plda, enroll, n_sessions, n_uniform, n_enroll, test, n_test, st, &ops);
   if (r) return r;
-  WS_HIP_CHECK(launch_plda_llr_pairs(plda->EA.as<double>(), plda->rowc.as<double>(),
-                                     plda->TT.as<double>(), 2 * plda->dim, idx_e, idx_t,
-                                     num_trials, out, st));
+  WS_HIP_CHECK(launch_plda_llr_pairs(ops.A, plda->rowc.as<double>(), ops.colc, ops.Bm, ops.K, idx_e,
+                                     idx_t, num_trials, out, st));
   return WS_OK;
 }
 

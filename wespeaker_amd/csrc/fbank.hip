@@ -17,6 +17,7 @@ namespace wsamd {
 constexpr int FFT_N = 512;            // padded window (round_to_power_of_two)
 constexpr int CN = FFT_N / 2;         // complex FFT size
 constexpr int FRAMES_PER_BLOCK = 4;
+constexpr int MEL_W_MAX = 1024;       // packed triangular weights (2 per FFT bin at most: 512)
 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -45,6 +46,15 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     float* __restrict__ feats) {
   __shared__ __attribute__((aligned(16))) float2 bufA[FRAMES_PER_BLOCK][CN];
   __shared__ __attribute__((aligned(16))) float2 bufB[FRAMES_PER_BLOCK][CN + 4];
+  // mel filter table staged once per workgroup (4 frames share it): the per-tap weight reads of
+  // the filterbank loop then come from LDS instead of dependent global loads
+  __shared__ float mel_w_s[MEL_W_MAX];
+  __shared__ int mel_start_s[128], mel_len_s[128], mel_off_s[128];
+  for (int i = threadIdx.x; i < tb.mel_w_total; i += 64 * FRAMES_PER_BLOCK) mel_w_s[i] = tb.mel_w[i];
+  for (int i = threadIdx.x; i < tb.num_bins; i += 64 * FRAMES_PER_BLOCK) {
+    mel_start_s[i] = tb.mel_start[i]; mel_len_s[i] = tb.mel_len[i]; mel_off_s[i] = tb.mel_off[i];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long frame = (long long)blockIdx.x * FRAMES_PER_BLOCK + wave;
   const bool live = frame < total_frames;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
 
   // 5. mel filterbank + log
   for (int bin = lane; bin < tb.num_bins; bin += 64) {
-    const int st = tb.mel_start[bin], len = tb.mel_len[bin];
-    const float* w = tb.mel_w + tb.mel_off[bin];
+    const int st = mel_start_s[bin], len = mel_len_s[bin];
+    const float* w = mel_w_s + mel_off_s[bin];
     float acc = 0.f;
     for (int i = 0; i < len; ++i) acc += w[i] * P[st + i];
     const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
@@ -140,7 +150,8 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream) {
   if (T <= 0 || B <= 0) return hipSuccess;
-  if (t.fft_n != FFT_N || t.frame_len > FFT_N) return hipErrorInvalidValue;
+  if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128)
+    return hipErrorInvalidValue;
   const long long total = (long long)B * T;
   const unsigned blocks = (unsigned)((total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
   const float* window = window_type == 1 ? t.window_povey : t.window_hamming;

@@ -123,6 +123,7 @@ struct FbankTables {
   const int* mel_off;            // [num_bins] offset into mel_w
   const float* mel_w;            // packed weights
   int frame_len, frame_shift, fft_n, num_bins;
+  int mel_w_total;               // number of packed weights
 };
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
@@ -134,19 +135,27 @@ hipError_t launch_plda_prepare(const void* emb, int emb_is_f64, const int32_t* g
                                int n_out, int dim, const double* mean_vec, const double* transform,
                                const double* offset, int pre_norm, int post_norm, double* out,
                                hipStream_t stream);
-// builds the GEMM operands: EA[i] = [g(n_i) * e_i | -0.5 a(n_i)], rowc[i] = K(n_i) - 0.5 sum b e^2
-hipError_t launch_plda_enroll_terms(const double* enroll, const int32_t* n_sessions, int n_enroll,
-                                    int dim, const double* psi, double* EA, double* rowc,
-                                    hipStream_t stream);
+hipError_t launch_plda_rows(const void* emb, int emb_is_f64, const int32_t* group_offsets, int n_out,
+                            int dim, const double* mean_vec, int pre_norm, double* V,
+                            hipStream_t stream);
+hipError_t launch_plda_rownorm(double* Y, int n, int dim, hipStream_t stream);
+// builds the GEMM operands: EA[i] = [g(n_i) * e_i | -0.5 a(n_i)], rowc[i] = K(n_i) - 0.5 sum b e^2.
+// n_sessions == nullptr: uniform n -> EA[i] = g * e_i only (K = dim).
+hipError_t launch_plda_enroll_terms(const double* enroll, const int32_t* n_sessions, int n_uniform,
+                                    int n_enroll, int dim, const double* psi, double* EA,
+                                    double* rowc, hipStream_t stream);
 // TT[j] = [t_j | t_j^2]
 hipError_t launch_plda_test_terms(const double* test, int n_test, int dim, double* TT,
                                   hipStream_t stream);
-// out[i][j] = rowc[i] + sum_k EA[i][k] TT[j][k]   (f64 MFMA)
-hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, int n_enroll,
-                                const double* TT, int n_test, int K, double* out,
+// uniform n: colc[j] = -1/2 sum_d a_d t_jd^2
+hipError_t launch_plda_test_colc(const double* test, int n_test, int dim, int n_uniform,
+                                 const double* psi, double* colc, hipStream_t stream);
+// out[i][j] = rowc[i] + colc[j] + sum_k EA[i][k] TT[j][k]   (f64 MFMA; rowc / colc may be null)
+hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, const double* colc,
+                                int n_enroll, const double* TT, int n_test, int K, double* out,
                                 hipStream_t stream);
-hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* TT, int K,
-                                 const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials,
-                                 double* out, hipStream_t stream);
+hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* colc,
+                                 const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
+                                 int64_t num_trials, double* out, hipStream_t stream);
 
 }  // namespace wsamd

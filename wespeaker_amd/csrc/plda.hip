@@ -93,14 +93,76 @@ hipError_t launch_plda_prepare(const void* emb, int emb_is_f64, const int32_t* g
   return hipGetLastError();
 }
 
+// Large-N form of the same pre-processing: (1) rows -> V (mean-sub, group mean, pre-norm), (2) Y = V
+// transform^T + offset on the f64 MFMA GEMM, (3) optional row re-normalisation.  One workgroup per
+// vector re-reads the D x D transform from L2 N times; the GEMM reads it once per 64-row tile.
+template <typename TIn>
+__global__ __launch_bounds__(256) void plda_rows_kernel(const TIn* __restrict__ emb,
+                                                        const int32_t* __restrict__ group_offsets,
+                                                        int n_out, int dim,
+                                                        const double* __restrict__ mean_vec,
+                                                        int pre_norm, double* __restrict__ V) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= n_out) return;
+  int r0 = g, r1 = g + 1;
+  if (group_offsets) { r0 = group_offsets[g]; r1 = group_offsets[g + 1]; }
+  double ss = 0.0;
+  for (int d = lane; d < dim; d += 64) {
+    double s = 0.0;
+    const double mv = mean_vec ? mean_vec[d] : 0.0;
+    for (int r = r0; r < r1; ++r) s += (double)emb[(long long)r * dim + d] - mv;
+    s /= (double)(r1 - r0);
+    V[(long long)g * dim + d] = s;
+    ss += s * s;
+  }
+  if (pre_norm) {
+    const double f = sqrt((double)dim) / sqrt(wave_sum_d(ss));
+    for (int d = lane; d < dim; d += 64) V[(long long)g * dim + d] *= f;
+  }
+}
+
+__global__ __launch_bounds__(256) void plda_rownorm_kernel(double* __restrict__ Y, int n, int dim) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= n) return;
+  double ss = 0.0;
+  for (int d = lane; d < dim; d += 64) { const double y = Y[(long long)g * dim + d]; ss += y * y; }
+  const double f = sqrt((double)dim) / sqrt(wave_sum_d(ss));
+  for (int d = lane; d < dim; d += 64) Y[(long long)g * dim + d] *= f;
+}
+
+hipError_t launch_plda_rows(const void* emb, int emb_is_f64, const int32_t* group_offsets, int n_out,
+                            int dim, const double* mean_vec, int pre_norm, double* V,
+                            hipStream_t stream) {
+  if (n_out <= 0) return hipSuccess;
+  if (emb_is_f64)
+    hipLaunchKernelGGL(plda_rows_kernel<double>, dim3((n_out + 3) / 4), dim3(256), 0, stream,
+                       reinterpret_cast<const double*>(emb), group_offsets, n_out, dim, mean_vec,
+                       pre_norm, V);
+  else
+    hipLaunchKernelGGL(plda_rows_kernel<float>, dim3((n_out + 3) / 4), dim3(256), 0, stream,
+                       reinterpret_cast<const float*>(emb), group_offsets, n_out, dim, mean_vec,
+                       pre_norm, V);
+  return hipGetLastError();
+}
+
+hipError_t launch_plda_rownorm(double* Y, int n, int dim, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(plda_rownorm_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, Y, n, dim);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------- GEMM operands
 // one wavefront per enrollment row
+// n_sessions == nullptr: every model has n_uniform sessions; then the t^2 coefficients do not depend
+// on the row and only the g*e half is written (K = dim, the a-term becomes a per-test constant).
 __global__ __launch_bounds__(256) void plda_enroll_terms_kernel(
-    const double* __restrict__ enroll, const int32_t* __restrict__ n_sessions, int n_enroll, int dim,
-    const double* __restrict__ psi, double* __restrict__ EA, double* __restrict__ rowc) {
+    const double* __restrict__ enroll, const int32_t* __restrict__ n_sessions, int n_uniform,
+    int n_enroll, int dim, const double* __restrict__ psi, double* __restrict__ EA,
+    double* __restrict__ rowc) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n_enroll) return;
-  const double n = (double)n_sessions[i];
+  const double n = n_sessions ? (double)n_sessions[i] : (double)n_uniform;
+  const int ldo = n_sessions ? 2 * dim : dim;
   double kc = 0.0;
   for (int d = lane; d < dim; d += 64) {
     const double p = psi[d];
@@ -108,20 +170,48 @@ __global__ __launch_bounds__(256) void plda_enroll_terms_kernel(
     const double v = 1.0 + p / (n * p + 1.0);
     const double e = enroll[(long long)i * dim + d];
     const double a = 1.0 / v - 1.0 / (p + 1.0);
-    EA[(long long)i * 2 * dim + d] = (c / v) * e;
-    EA[(long long)i * 2 * dim + dim + d] = -0.5 * a;
+    EA[(long long)i * ldo + d] = (c / v) * e;
+    if (n_sessions) EA[(long long)i * ldo + dim + d] = -0.5 * a;
     kc += -0.5 * (log(v) - log(p + 1.0)) - 0.5 * (c * c / v) * e * e;
   }
   kc = wave_sum_d(kc);
   if (lane == 0) rowc[i] = kc;
 }
 
-hipError_t launch_plda_enroll_terms(const double* enroll, const int32_t* n_sessions, int n_enroll,
-                                    int dim, const double* psi, double* EA, double* rowc,
-                                    hipStream_t stream) {
+hipError_t launch_plda_enroll_terms(const double* enroll, const int32_t* n_sessions, int n_uniform,
+                                    int n_enroll, int dim, const double* psi, double* EA,
+                                    double* rowc, hipStream_t stream) {
   if (n_enroll <= 0) return hipSuccess;
   hipLaunchKernelGGL(plda_enroll_terms_kernel, dim3((n_enroll + 3) / 4), dim3(256), 0, stream,
-                     enroll, n_sessions, n_enroll, dim, psi, EA, rowc);
+                     enroll, n_sessions, n_uniform, n_enroll, dim, psi, EA, rowc);
+  return hipGetLastError();
+}
+
+// uniform n: colc[j] = -1/2 sum_d a_d t_jd^2   (one wavefront per test vector)
+__global__ __launch_bounds__(256) void plda_test_colc_kernel(const double* __restrict__ test,
+                                                             int n_test, int dim, int n_uniform,
+                                                             const double* __restrict__ psi,
+                                                             double* __restrict__ colc) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n_test) return;
+  const double n = (double)n_uniform;
+  double acc = 0.0;
+  for (int d = lane; d < dim; d += 64) {
+    const double p = psi[d];
+    const double v = 1.0 + p / (n * p + 1.0);
+    const double a = 1.0 / v - 1.0 / (p + 1.0);
+    const double t = test[(long long)j * dim + d];
+    acc += -0.5 * a * t * t;
+  }
+  acc = wave_sum_d(acc);
+  if (lane == 0) colc[j] = acc;
+}
+
+hipError_t launch_plda_test_colc(const double* test, int n_test, int dim, int n_uniform,
+                                 const double* psi, double* colc, hipStream_t stream) {
+  if (n_test <= 0) return hipSuccess;
+  hipLaunchKernelGGL(plda_test_colc_kernel, dim3((n_test + 3) / 4), dim3(256), 0, stream, test,
+                     n_test, dim, n_uniform, psi, colc);
   return hipGetLastError();
 }
 
@@ -157,7 +247,8 @@ constexpr int DBK = 16;
 constexpr int DS = DBK + 2;
 
 __global__ __launch_bounds__(256) void plda_gemm_f64_kernel(const double* __restrict__ A,
-                                                            const double* __restrict__ rowc, int M,
+                                                            const double* __restrict__ rowc,
+                                                            const double* __restrict__ colc, int M,
                                                             const double* __restrict__ Bm, int N,
                                                             int K, double* __restrict__ out) {
   __shared__ double As[64 * DS];
@@ -207,16 +298,17 @@ __global__ __launch_bounds__(256) void plda_gemm_f64_kernel(const double* __rest
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 32 + im * 16 + lk + 4 * r;
         const int n = n0 + wn * 32 + in * 16 + li;
-        if (m < M && n < N) out[(long long)m * N + n] = acc[im][in][r] + (rowc ? rowc[m] : 0.0);
+        if (m < M && n < N)
+          out[(long long)m * N + n] = acc[im][in][r] + (rowc ? rowc[m] : 0.0) + (colc ? colc[n] : 0.0);
       }
 }
 
-hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, int n_enroll,
-                                const double* TT, int n_test, int K, double* out,
+hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, const double* colc,
+                                int n_enroll, const double* TT, int n_test, int K, double* out,
                                 hipStream_t stream) {
   if (n_enroll <= 0 || n_test <= 0) return hipSuccess;
   dim3 grid((n_test + 63) / 64, (n_enroll + 63) / 64);
-  hipLaunchKernelGGL(plda_gemm_f64_kernel, grid, dim3(256), 0, stream, EA, rowc, n_enroll, TT,
+  hipLaunchKernelGGL(plda_gemm_f64_kernel, grid, dim3(256), 0, stream, EA, rowc, colc, n_enroll, TT,
                      n_test, K, out);
   return hipGetLastError();
 }
@@ -225,9 +317,9 @@ hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, int n_enro
 // 16 lanes per trial (4 trials per wavefront): gathers two 2D-double rows (L2 / Infinity-Cache
 // resident tables), 16-lane shuffle reduction.
 __global__ __launch_bounds__(256) void plda_llr_pairs_kernel(
-    const double* __restrict__ EA, const double* __restrict__ rowc, const double* __restrict__ TT,
-    int K, const int32_t* __restrict__ idx_e, const int32_t* __restrict__ idx_t,
-    long long num_trials, double* __restrict__ out) {
+    const double* __restrict__ EA, const double* __restrict__ rowc, const double* __restrict__ colc,
+    const double* __restrict__ TT, int K, const int32_t* __restrict__ idx_e,
+    const int32_t* __restrict__ idx_t, long long num_trials, double* __restrict__ out) {
   const int sub = threadIdx.x & 15;
   for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4; p < num_trials;
        p += ((long long)gridDim.x * 256) >> 4) {
@@ -242,18 +334,18 @@ __global__ __launch_bounds__(256) void plda_llr_pairs_kernel(
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (sub == 0) out[p] = s + rowc[i];
+    if (sub == 0) out[p] = s + rowc[i] + (colc ? colc[j] : 0.0);
   }
 }
 
-hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* TT, int K,
-                                 const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials,
-                                 double* out, hipStream_t stream) {
+hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* colc,
+                                 const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
+                                 int64_t num_trials, double* out, hipStream_t stream) {
   if (num_trials <= 0) return hipSuccess;
   long long blocks = (num_trials * 16 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(plda_llr_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, EA, rowc,
-                     TT, K, idx_e, idx_t, (long long)num_trials, out);
+                     colc, TT, K, idx_e, idx_t, (long long)num_trials, out);
   return hipGetLastError();
 }
 

@@ -128,26 +128,35 @@ class TwoCovPLDA:
                 _lib.current_stream_ptr(self.device)), "ws_plda_prepare_enroll")
         return out
 
+    def _sessions(self, n_sessions, n_rows):
+        """-> (device int32 array or None, n_uniform).  A python int / a host array whose entries
+        are all equal selects the uniform-n fast path (the common multisession_avg=True case)."""
+        if isinstance(n_sessions, torch.Tensor):
+            return self._dev(n_sessions, torch.int32), 0
+        arr = np.asarray(n_sessions, dtype=np.int32).reshape(-1)
+        if arr.size == 1 or (arr.size and np.all(arr == arr[0])):
+            return None, int(arr[0])
+        return self._dev(np.broadcast_to(arr, (n_rows,)).copy(), torch.int32), 0
+
     def llr_matrix(self, enroll_t, n_sessions, test_t) -> torch.Tensor:
-        """(Ne, D), (Ne,), (Nt, D) transformed float64 -> (Ne, Nt) float64 LLRs on the GPU."""
+        """(Ne, D), (Ne,) or int, (Nt, D) transformed float64 -> (Ne, Nt) float64 LLRs on the GPU."""
         e = self._dev(enroll_t, torch.float64)
         t = self._dev(test_t, torch.float64)
-        n = self._dev(np.broadcast_to(np.asarray(n_sessions, dtype=np.int32), (e.shape[0],)).copy()
-                      if not isinstance(n_sessions, torch.Tensor) else n_sessions, torch.int32)
+        n, nu = self._sessions(n_sessions, e.shape[0])
         out = torch.empty((e.shape[0], t.shape[0]), dtype=torch.float64, device=self.device)
         if out.numel() == 0:
             return out
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ws_plda_llr_matrix(
-                self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
-                _lib.ptr(out), _lib.current_stream_ptr(self.device)), "ws_plda_llr_matrix")
+                self._handle(), _lib.ptr(e), _lib.ptr(n) if n is not None else None, nu, e.shape[0],
+                _lib.ptr(t), t.shape[0], _lib.ptr(out), _lib.current_stream_ptr(self.device)),
+                "ws_plda_llr_matrix")
         return out
 
     def llr_pairs(self, enroll_t, n_sessions, test_t, idx_e, idx_t) -> torch.Tensor:
         e = self._dev(enroll_t, torch.float64)
         t = self._dev(test_t, torch.float64)
-        n = self._dev(np.broadcast_to(np.asarray(n_sessions, dtype=np.int32), (e.shape[0],)).copy()
-                      if not isinstance(n_sessions, torch.Tensor) else n_sessions, torch.int32)
+        n, nu = self._sessions(n_sessions, e.shape[0])
         ie = self._dev(idx_e, torch.int32)
         it = self._dev(idx_t, torch.int32)
         if ie.shape != it.shape:
@@ -157,8 +166,8 @@ class TwoCovPLDA:
             return out
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ws_plda_llr_pairs(
-                self._handle(), _lib.ptr(e), _lib.ptr(n), e.shape[0], _lib.ptr(t), t.shape[0],
-                _lib.ptr(ie), _lib.ptr(it), ie.shape[0], _lib.ptr(out),
+                self._handle(), _lib.ptr(e), _lib.ptr(n) if n is not None else None, nu, e.shape[0],
+                _lib.ptr(t), t.shape[0], _lib.ptr(ie), _lib.ptr(it), ie.shape[0], _lib.ptr(out),
                 _lib.current_stream_ptr(self.device)), "ws_plda_llr_pairs")
         return out
 
