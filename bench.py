@@ -261,6 +261,16 @@ def main():
             "ms_per_step": odt / osteps * 1e3, "steps": osteps,
             "dominant_kernel_achieved_tflops": o_ach,
             "dominant_kernel_peak_tflops": FP32_MFMA_PEAK_TFLOPS if f16 else F16_MFMA_PEAK_TFLOPS}
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+        # command (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed aggregate is used
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+        if f16 and os.path.exists(pmc_path):
+            with open(pmc_path) as fpmc:
+                pmc = json.load(fpmc)
+            line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            line["roofline"]["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)"
+            line["roofline"]["traffic_source"] = "profiles/r01_pmc_dominant_kernel.json"
+            line["roofline"]["algorithmic_bytes_per_launch"] = g["bytes"] / max(1, g["launches"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, args.cpu_utts)
         assert all_emb.shape == (n_total, 192) and bool(torch.isfinite(all_emb).all())
