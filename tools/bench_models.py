@@ -16,7 +16,7 @@ CASES = [  # (model, embed_dim, batch, chunk)
     ("ECAPA_TDNN_GLOB_c1024", 192, 256, 256),      # BASELINE configs[1]: batch 256 x 2 s
     ("ResNet34", 256, 256, 64),
     ("ResNet221", 256, 128, 32),
-    ("CAMPPlus", 512, 256, 128),
+    ("CAMPPlus", 512, 256, 256),
 ]
 
 def main():

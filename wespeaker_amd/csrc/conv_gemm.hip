@@ -60,7 +60,8 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AROWS = NT / 8, WROWS = NT / 4;       // rows covered per staging pass
   constexpr int A_IT = BM / AROWS;                    // float4 chunks of A per thread per K-tile
-  constexpr int W_IT = PREC == 0 ? BN / AROWS : BN / WROWS;  // W chunks per thread (per plane for PREC 1)
+  // W chunks per thread (per plane for PREC 1); a 32-column tile uses only the first BN weight rows
+  constexpr int W_IT = PREC == 0 ? BN / AROWS : (BN / WROWS > 0 ? BN / WROWS : 1);
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   static_assert(A_IT >= 1 && W_IT >= 1, "tile too small for the thread count");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -141,7 +142,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
       sw_inc[i] = ok ? BK : 0;
     } else {
       const int n = n0 + wr0 + WROWS * i;
-      const bool ok = n < p.N;
+      const bool ok = n < p.N && wr0 + WROWS * i < BN;
       const long long off = (long long)n * p.ldw + (long long)kt_begin * BK + wc * 8;
       swh_ptr[i] = ok ? p.Wh + off : reinterpret_cast<const uint16_t*>(p.zeros);
       swl_ptr[i] = ok ? p.Wl + off : reinterpret_cast<const uint16_t*>(p.zeros);
@@ -240,8 +241,10 @@ void conv_gemm_kernel(const ConvGemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
-        *reinterpret_cast<u32x4*>(&Wh[(wr0 + WROWS * i) * HS + wc * 8]) = rwh[i];
-        *reinterpret_cast<u32x4*>(&Wl[(wr0 + WROWS * i) * HS + wc * 8]) = rwl[i];
+        if (BN >= WROWS || wr0 < BN) {
+          *reinterpret_cast<u32x4*>(&Wh[(wr0 + WROWS * i) * HS + wc * 8]) = rwh[i];
+          *reinterpret_cast<u32x4*>(&Wl[(wr0 + WROWS * i) * HS + wc * 8]) = rwl[i];
+        }
       }
     }
   };
@@ -575,6 +578,20 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
                       p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K % BK == 0 &&
                       p.K == p.Cin;
   const int mode = p.A2 ? 1 : (p.pre_scale ? 2 : (simple ? 3 : 0));
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = 2 * cus;
+  }
+  // Small problems (fewer 128-row tiles than half the chip's block slots): 64x64 tiles put 2-4x
+  // more workgroups in flight (CAM++'s dense layers are [B*T/2 x 32..128] GEMMs).
+  {
+    const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.splitk <= 1 && blocks128 * 2 < slots) return launch_mode<64, 64, 2, 2, PREC>(p, mode, stream);
+  }
+  if (p.N <= 32) return launch_mode<128, 32, 4, 1, PREC>(p, mode, stream);
   if (p.N <= 64) return launch_mode<128, 64, 4, 1, PREC>(p, mode, stream);
   // Tail peeling.  128x128 tiles run two per CU; a last partial round of tiles costs a whole tile
   // time on a mostly idle chip (measured: 94 -> 123 TF at K = 512 when the tile count is a
@@ -584,13 +601,6 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   ConvGemmParams main = p, tail = p;
   bool peel = false;
   if (p.splitk <= 1 && p.m_begin == 0) {
-    static int slots = 0;
-    if (!slots) {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess)
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      slots = 2 * cus;
-    }
     const long long tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
     const long long total = tiles_m * tiles_n, rem = total % slots;
     if (total > slots && rem != 0 && rem * 10 <= slots * 7) {
@@ -620,8 +630,8 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.D2 && ((p.ldd2 | p.d2_off | p.d2_col0) & 3)) return hipErrorInvalidValue;
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
   if (p.pre_scale && p.A2) return hipErrorInvalidValue;
-  if (p.colsum && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
-  if (p.pool_partial && (p.N <= 64 || p.splitk > 1 || p.Hout * p.Wout < 64 || !p.pool_h || (p.ldh & 3)))
+  if (p.colsum && (p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
+  if (p.pool_partial && (p.splitk > 1 || p.Hout * p.Wout < 64 || !p.pool_h || (p.ldh & 3)))
     return hipErrorInvalidValue;
   if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.prec == 1) {
