@@ -389,3 +389,64 @@ def test_speaker_api_resnet_and_campplus_model_dirs(tmp_path):
         r = fwd(sd, feats).numpy()[0]
         assert e.shape == (ed,)
         assert _cos_err(e, r) < COS_TOL and _rel_err(e, r) < 5e-4
+
+
+# ------------------------------------------------ BASELINE-size checks through domain properties
+def test_full_size_batch_properties_ecapa():
+    """configs[1]/[4] sizes (256 x 2 s): the oracle is too slow for every row, so check
+    size-independent properties: utterances are independent (any permutation of the batch permutes
+    the embeddings; a row equals its single-utterance result) plus an oracle spot check."""
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, max_batch=256, max_frames=198)
+    fe = Frontend(16000, 80)
+    wav = device_wavs(256, 32000, model.device, 5)
+    perm = torch.randperm(256, device=model.device)
+    for prec in ("fp32", "f16x3"):
+        model.set_precision(prec)
+        full = model.extract(fe, wav)
+        shuffled = model.extract(fe, wav[perm])
+        assert torch.equal(shuffled, full[perm]) or _rel_err(shuffled.cpu().numpy(), full[perm].cpu().numpy()).max() < 1e-5
+        single = torch.cat([model.extract(fe, wav[i:i + 1]) for i in (0, 131, 255)])
+        assert _rel_err(single.cpu().numpy(), full[[0, 131, 255]].cpu().numpy()).max() < 1e-5
+        rows = [3, 200]
+        ref = oecapa.ecapa_forward(sd, np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])).numpy()
+        assert _rel_err(full[rows].cpu().numpy(), ref).max() < 5e-4
+        assert bool(torch.isfinite(full).all())
+
+
+def test_full_size_plda_one_million_trials():
+    """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
+    code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
+    from wespeaker_amd import TwoCovPLDA
+    p = synth.synth_plda(192, seed=7)
+    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], False)
+    emb, _ = synth.synth_embeddings(4000, 192, seed=21)
+    e_t = plda.prepare_test(emb[:2000])
+    t_t = plda.prepare_test(emb[2000:])
+    ie, it = synth.synth_trial_pairs(1000000, 2000, 2000, seed=99)
+    pairs_u = plda.llr_pairs(e_t, 1, t_t, ie, it)
+    pairs_g = plda.llr_pairs(e_t, torch.ones(2000, dtype=torch.int32), t_t, ie, it)
+    mat = plda.llr_matrix(e_t, 1, t_t)
+    gathered = mat[torch.from_numpy(ie).long().to(mat.device), torch.from_numpy(it).long().to(mat.device)]
+    assert float((pairs_u - gathered).abs().max()) < 1e-9
+    assert float((pairs_u - pairs_g).abs().max()) < 1e-9
+    # spot check 200 trials against the reference's per-trial formula
+    e_np, t_np = e_t.cpu().numpy(), t_t.cpu().numpy()
+    ref = np.array([oplda.log_likelihood_ratio(p, e_np[ie[k]], t_np[it[k]], 1) for k in range(0, 1000000, 5000)])
+    assert np.abs(pairs_u.cpu().numpy()[::5000] - ref).max() < 1e-8
+
+
+def test_full_size_fbank_scale_property(frontend):
+    """log-mel(alpha x) = log-mel(x) + 2 log alpha, so CMN'd features are scale invariant
+    (floor effects aside); checked on a 256-utterance batch."""
+    from bench import device_wavs
+    wav = device_wavs(256, 32000, frontend.device, 9).float()
+    a = frontend.fbank(wav, cmn=False)
+    b = frontend.fbank(wav * 0.25, cmn=False)
+    assert float((b - a - 2.0 * np.log(0.25)).abs().max()) < 2e-3
+    ac = frontend.fbank(wav, cmn=True)
+    bc = frontend.fbank(wav * 0.25, cmn=True)
+    assert float((ac - bc).abs().max()) < 2e-3
+    assert float(ac.mean(dim=1).abs().max()) < 1e-3
