@@ -103,7 +103,9 @@ def main():
 
     rank, world, local_rank = parallel.init_distributed()
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
-    device = torch.device("cuda", local_rank)
+    # WS_SHARE_GPU=1 (debug): all ranks use GPU 0 (with WS_DIST_BACKEND=gloo) so that the N > 1 control
+    # flow can be exercised on a single-GPU box
+    device = torch.device("cuda", 0 if os.environ.get("WS_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
 
     num_samples = int(args.seconds * 16000)
@@ -120,10 +122,22 @@ def main():
         emb = model.extract(fe, wav)                              # (B, 192) on this GPU
         return parallel.gather_rows(emb, n_total) if world > 1 else emb
 
+    nccl = world > 1 and dist.get_backend() == "nccl"
+
     def fence():
         if world > 1:
-            dist.barrier()
+            if nccl:
+                dist.barrier(device_ids=[device.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(device)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -145,10 +159,7 @@ def main():
     breakdown = model.profile_read()
     bsteps = min(args.steps, 5)
     model.profile(False)
-    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
+    dt = max_over_ranks(dt)
 
     # the other contraction back-end, same workload, fewer steps (reported, not the headline)
     other = "fp32" if args.precision == "f16x3" else "f16x3"
@@ -166,10 +177,7 @@ def main():
     oprof = model.profile_read()["conv_gemm_f32_128x128"]
     model.profile(False)
     model.set_precision(args.precision)
-    o_max = torch.tensor([odt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(o_max, op=dist.ReduceOp.MAX)
-    odt = float(o_max.item())
+    odt = max_over_ranks(odt)
 
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
@@ -276,7 +284,7 @@ def main():
         assert all_emb.shape == (n_total, 192) and bool(torch.isfinite(all_emb).all())
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("WS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -58,6 +58,12 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     padded = torch.zeros((per,) + tuple(width), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(width), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        # gloo has no CUDA all_gather_into_tensor: stage through the host (test / debug path only;
+        # the production backend is "nccl" = RCCL over xGMI)
+        host = [torch.empty(padded.shape, dtype=padded.dtype) for _ in range(world)]
+        dist.all_gather(host, padded.cpu(), group=group)
+        return torch.cat(host, 0).to(local.device)[:n_total]
     dist.all_gather_into_tensor(out, padded, group=group)
     return out[:n_total]
 
