@@ -159,6 +159,41 @@ int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sess
                       const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
                       ws_stream stream);
 
+/* ------------------------------------------------------------------ cosine scoring + AS-norm
+ * Stateless device functions replacing the numpy/sklearn back-end of wespeaker/bin/score.py:38-72
+ * (trials_cosine_score) and wespeaker/bin/score_norm.py:26-36,93-115 (get_mean_std + the
+ * normalisation loop).  A "unit table" holds mean-subtracted, L2-normalised embeddings as
+ * (ws_cos_table_rows(n), ws_cos_table_ld(dim)) float32, zero padded on both axes. */
+int ws_cos_table_rows(int n);   /* n rounded up to a multiple of 4 */
+int ws_cos_table_ld(int dim);   /* dim rounded up to a multiple of 32 (floats per row) */
+/* emb DEVICE float32 (n, dim) dense; mean_vec DEVICE float32[dim] or NULL (score.py:44-53:
+ * emb - mean_vec); unit DEVICE table as above (written in full, padding zeroed); mag DEVICE
+ * float32[n] or NULL receives |emb - mean_vec| (the enroll_mag/test_mag columns, score_norm.py:107). */
+int ws_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit, float* mag,
+                   ws_stream stream);
+/* out[p] = <unit_a[idx_a[p]], unit_b[idx_b[p]]> = cosine_similarity (score.py:62-63).
+ * idx_* DEVICE int32[num_trials]; out DEVICE float32[num_trials]. */
+int ws_cos_pairs(const float* unit_a, const float* unit_b, int dim, const int32_t* idx_a,
+                 const int32_t* idx_b, int64_t num_trials, float* out, ws_stream stream);
+/* Dense cosine matrix out[i][j] = <unit_a[i], unit_b[j]> (score_norm.py:29 np.matmul(emb, cohort.T))
+ * on the exact-fp32 MFMA GEMM.  out DEVICE float32 (n_a, ldo), ldo >= ws_cos_table_rows(n_b);
+ * columns n_b..ws_cos_table_rows(n_b)-1 receive zeros. */
+int ws_cos_matrix(const float* unit_a, int n_a, const float* unit_b, int n_b, int dim, float* out,
+                  int ldo, ws_stream stream);
+/* get_mean_std (score_norm.py:26-36): for every row of `unit`, mean and population standard
+ * deviation (np.std) of its min(top_n, n_cohort) largest cosine scores against the cohort
+ * (asnorm: top_n; snorm: top_n >= n_cohort).  scratch DEVICE float32[scratch_floats] holds score
+ * rows in flight; it needs at least 128 * ws_cos_table_rows(n_cohort) floats and the rows are
+ * processed in as few chunks as it allows.  mean, sd DEVICE float32[n]. */
+int ws_cohort_stats(const float* unit, int n, const float* unit_cohort, int n_cohort, int dim,
+                    int top_n, float* scratch, int64_t scratch_floats, float* mean, float* sd,
+                    ws_stream stream);
+/* score_norm.py:100-103: out[p] = 0.5 * ((s[p] - e_mean[ie]) / e_sd[ie] + (s[p] - t_mean[it]) / t_sd[it]).
+ * All DEVICE; score/out float32[num_trials]. */
+int ws_asnorm_pairs(const float* score, const int32_t* idx_e, const int32_t* idx_t,
+                    const float* e_mean, const float* e_sd, const float* t_mean, const float* t_sd,
+                    int64_t num_trials, float* out, ws_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

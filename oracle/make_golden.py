@@ -12,6 +12,9 @@ What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerat
                        CAMPPlus modules (wespeaker/models/resnet.py, campplus.py).
   * plda_ref.npz    -- outputs of the reference's own TwoCovPLDA.transform_embedding /
                        log_likelihood_ratio (wespeaker/utils/plda/two_cov_plda.py:156-184).
+  * score_ref.npz   -- outputs of the reference's own bin/score.py (trials_cosine_score) and
+                       bin/score_norm.py (get_mean_std, main with asnorm and snorm) run on the
+                       synth_scoring_set fixture through real ark/scp/trial files.
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
 The GPU box has no /root/reference; tests there compare against these committed files.
@@ -133,6 +136,36 @@ def make_plda():
     print("plda llr range", float(llr.min()), float(llr.max()))
 
 
+def make_score():
+    import tempfile
+    score_mod = ref_shim.ref_module("wespeaker.bin.score")
+    norm_mod = ref_shim.ref_module("wespeaker.bin.score_norm")
+    fix = synth.synth_scoring_set()
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        paths = synth.write_scoring_files(fix, d)
+        for tag, mean_path in (("nomean", None), ("mean", paths["mean_vec"])):
+            store = os.path.join(d, "scores_" + tag)
+            os.makedirs(store)
+            score_mod.trials_cosine_score(paths["eval_scp"], store, mean_path, [paths["trials"]])
+            score_file = os.path.join(store, "trials.kaldi.score")
+            rows = [l.split() for l in open(score_file)]
+            out[tag + "/cosine"] = np.array([float(r[2]) for r in rows])
+            for method, top_n in (("asnorm", 20), ("snorm", 20)):
+                nf = os.path.join(store, method + ".score")
+                norm_mod.main(method, top_n, score_file, nf, paths["cohort_scp"], paths["eval_scp"],
+                              mean_path)
+                cols = np.array([[float(x) for x in (l.split()[2:3] + l.split()[4:8])]
+                                 for l in open(nf)])
+                out["%s/%s" % (tag, method)] = cols      # normed, e_mag, t_mag, e_mean, t_mean
+        mv = np.load(paths["mean_vec"])
+        m, s = norm_mod.get_mean_std(fix["eval_emb"] - mv, fix["cohort_emb"] - mv, 20)
+        out["get_mean_std/mean"], out["get_mean_std/std"] = m, s
+    np.savez_compressed(os.path.join(GOLD, "score_ref.npz"), **out)
+    print("score: cosine range", out["mean/cosine"].min(), out["mean/cosine"].max(),
+          "asnorm range", out["mean/asnorm"][:, 0].min(), out["mean/asnorm"][:, 0].max())
+
+
 if __name__ == "__main__":
     assert ref_shim.available(), "needs /root/reference"
     os.makedirs(GOLD, exist_ok=True)
@@ -140,4 +173,5 @@ if __name__ == "__main__":
     make_ecapa()
     make_resnet_campplus()
     make_plda()
+    make_score()
     print("golden fixtures written to", GOLD)

@@ -18,13 +18,14 @@ def _seed_packages():
     if "wespeaker" in sys.modules and getattr(sys.modules["wespeaker"], "_oracle_shim", False):
         return
     for name, sub in (("wespeaker", ""), ("wespeaker.models", "models"),
-                      ("wespeaker.utils", "utils"), ("wespeaker.utils.plda", "utils/plda")):
+                      ("wespeaker.utils", "utils"), ("wespeaker.utils.plda", "utils/plda"),
+                      ("wespeaker.bin", "bin")):
         m = types.ModuleType(name)
         m.__path__ = [os.path.join(REF_ROOT, "wespeaker", sub)]
         m._oracle_shim = True
         sys.modules[name] = m
     # third-party modules the PLDA files import at module scope but never use on the numeric path
-    for stub in ("h5py", "kaldiio", "kaldi_io", "kaldi_io.kaldi_io"):
+    for stub in ("h5py", "kaldiio", "kaldi_io", "kaldi_io.kaldi_io", "fire"):
         if stub not in sys.modules:
             try:
                 importlib.import_module(stub)
@@ -34,6 +35,15 @@ def _seed_packages():
                     s.open_or_fd = s.BadSampleSize = s.UnknownMatrixHeader = None
                 if stub == "kaldi_io.kaldi_io":
                     s._read_compressed_mat = s._read_mat_ascii = None
+                if stub == "kaldiio":
+                    # bin/score.py and bin/score_norm.py read embeddings through
+                    # kaldiio.load_scp_sequential: serve the same ark/scp files with our reader
+                    def load_scp_sequential(scp_path):
+                        from wespeaker_amd.kaldi_io import read_vec_scp
+                        return iter(read_vec_scp(scp_path).items())
+                    s.load_scp_sequential = load_scp_sequential
+                if stub == "fire":
+                    s.Fire = lambda *a, **k: None
                 sys.modules[stub] = s
 
 

@@ -450,3 +450,105 @@ def test_full_size_fbank_scale_property(frontend):
     bc = frontend.fbank(wav * 0.25, cmn=True)
     assert float((ac - bc).abs().max()) < 2e-3
     assert float(ac.mean(dim=1).abs().max()) < 1e-3
+
+
+# ============================================================ cosine scoring + AS-norm
+# Tolerances: cosines are float32 dot products of unit vectors (reference: float32 numpy / sklearn)
+# -> 2e-6 absolute; cohort mean / std 2e-6 / 5e-6 absolute (the kernel accumulates in float64, numpy
+# in pairwise float32); normalised scores divide by std ~ 0.05: 1e-3 absolute like the PLDA LLR bar.
+COS_ATOL, STAT_ATOL, NORM_ATOL = 2e-6, 5e-6, 1e-3
+
+
+@pytest.mark.parametrize("n,n_cohort,dim,top_n", [(60, 150, 192, 20), (37, 301, 100, 300),
+                                                   (130, 1000, 256, 1000), (5, 7, 512, 3),
+                                                   (300, 999, 192, 2000)])
+def test_cohort_stats_match_oracle(n, n_cohort, dim, top_n):
+    from oracle import score as oscore
+    from wespeaker_amd import score as wscore
+    emb, _ = synth.synth_embeddings(n, dim, seed=5)
+    cohort, _ = synth.synth_embeddings(n_cohort, dim, seed=6)
+    cohort[3] = cohort[1]                      # exact ties inside the cohort scores
+    if n_cohort > 10:
+        cohort[10] = cohort[1]
+    m_ref, s_ref = oscore.get_mean_std(emb, cohort, top_n)
+    t, c = wscore.UnitTable(emb), wscore.UnitTable(cohort)
+    m, s = wscore.cohort_stats(t, c, top_n)
+    assert np.abs(m.cpu().numpy() - m_ref).max() <= STAT_ATOL
+    assert np.abs(s.cpu().numpy() - s_ref).max() <= STAT_ATOL
+    # chunked path (scratch for 128 rows only) gives the same numbers bit for bit
+    m2, s2 = wscore.cohort_stats(t, c, top_n, scratch_bytes=4 * 128 * ((n_cohort + 3) // 4 * 4))
+    assert torch.equal(m, m2) and torch.equal(s, s2)
+    # dense matrix against numpy
+    unit = lambda x: x / np.sqrt(np.sum(x ** 2, axis=1, keepdims=True))
+    S = wscore.cosine_matrix(t, c).cpu().numpy()
+    assert np.abs(S - unit(emb) @ unit(cohort).T).max() <= COS_ATOL
+
+
+def test_cosine_and_score_norm_files_match_reference_golden(tmp_path, golden_dir):
+    """The file-level tools (bin/score.py main, bin/score_norm.py main) on the same ark / scp /
+    trial files the reference was run on to make tests/golden/score_ref.npz."""
+    from wespeaker_amd import score as wscore
+    g = np.load(os.path.join(golden_dir, "score_ref.npz"))
+    fix = synth.synth_scoring_set()
+    paths = synth.write_scoring_files(fix, str(tmp_path / "emb"))
+    for tag, mean_path in (("nomean", None), ("mean", paths["mean_vec"])):
+        store = str(tmp_path / ("scores_" + tag))
+        os.makedirs(store)
+        wscore.trials_cosine_score(paths["eval_scp"], store, mean_path, [paths["trials"]])
+        score_file = os.path.join(store, "trials.kaldi.score")
+        rows = [l.split() for l in open(score_file)]
+        assert [tuple(r[:2]) + (r[3],) for r in rows] == [tuple(t) for t in fix["trials"]]
+        cos = np.array([float(r[2]) for r in rows])
+        assert np.abs(cos - g[tag + "/cosine"]).max() <= 1.01e-5       # both sides are '%.5f' text
+        for method in ("asnorm", "snorm"):
+            nf = os.path.join(store, method + ".score")
+            wscore.score_norm(method, 20, score_file, nf, paths["cohort_scp"], paths["eval_scp"],
+                              mean_path)
+            lines = [l.split() for l in open(nf)]
+            assert all(len(l) == 8 for l in lines)
+            cols = np.array([[float(x) for x in (l[2:3] + l[4:8])] for l in lines])
+            ref = g["%s/%s" % (tag, method)]
+            assert np.abs(cols[:, 0] - ref[:, 0]).max() <= NORM_ATOL
+            assert np.abs(cols[:, 1:] - ref[:, 1:]).max() <= 1.01e-4   # '%.4f' text on both sides
+
+
+def test_cosine_pairs_match_oracle_and_edge_cases():
+    from oracle import score as oscore
+    from wespeaker_amd import score as wscore
+    emb, _ = synth.synth_embeddings(200, 192, seed=8)
+    mv = emb.mean(0)
+    ia, ib = synth.synth_trial_pairs(5000, 200, 200, seed=3)
+    t = wscore.UnitTable(emb, mv)
+    got = wscore.cosine_pairs(t, t, ia, ib).cpu().numpy()
+    assert np.abs(got - oscore.cosine_pairs(emb, mv, ia, ib)).max() <= COS_ATOL
+    assert np.abs(t.mag.cpu().numpy() - np.linalg.norm(emb - mv, axis=1)).max() <= 1e-4
+    assert wscore.cosine_pairs(t, t, [], []).numel() == 0
+    with pytest.raises(IndexError):
+        wscore.cosine_pairs(t, t, [200], [0])
+    with pytest.raises(ValueError):
+        wscore.score_norm("znorm", 10, "x", "y", "z", "w")
+
+
+def test_full_size_score_norm_properties():
+    """VoxCeleb1-O-sized tables (4874 x 256) against a 20k cohort: size-independent properties."""
+    from wespeaker_amd import score as wscore
+    emb, _ = synth.synth_embeddings(4874, 256, seed=31)
+    cohort, _ = synth.synth_embeddings(20000, 256, seed=32)
+    t, c = wscore.UnitTable(emb), wscore.UnitTable(cohort)
+    m, s = wscore.cohort_stats(t, c, 300)
+    # (1) cohort order does not matter (exact selection -> only float64 summation order changes)
+    perm = np.random.Generator(np.random.PCG64(1)).permutation(20000)
+    m_p, s_p = wscore.cohort_stats(t, wscore.UnitTable(cohort[perm]), 300)
+    assert (m - m_p).abs().max().item() <= 1e-6 and (s - s_p).abs().max().item() <= 1e-6
+    # (2) top_n >= cohort size == plain row statistics of the dense matrix
+    S = wscore.cosine_matrix(t, c).double()
+    m_all, s_all = wscore.cohort_stats(t, c, 10 ** 9)
+    assert (m_all.double() - S.mean(1)).abs().max().item() <= 1e-6
+    assert (s_all.double() - S.std(1, unbiased=False)).abs().max().item() <= 1e-6
+    # (3) top-N against torch.topk on the same matrix
+    top = S.topk(300, dim=1).values
+    assert (m.double() - top.mean(1)).abs().max().item() <= 1e-6
+    assert (s.double() - top.std(1, unbiased=False)).abs().max().item() <= 1e-6
+    # (4) monotone: a larger N can only lower the mean of the top-N
+    m_600, _ = wscore.cohort_stats(t, c, 600)
+    assert bool((m_600 <= m + 1e-7).all())

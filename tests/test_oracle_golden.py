@@ -152,3 +152,34 @@ def test_campplus_restatement_vs_reference_golden(golden_dir):
     assert np.abs(emb_l - g["emb_T328"]).max() <= 2e-4 * np.abs(g["emb_T328"]).max()
     emb_s = ocam.campplus_forward(sd, feats[:, :57]).numpy()
     assert np.abs(emb_s - g["emb_T57"]).max() <= 2e-4 * np.abs(g["emb_T57"]).max()
+
+
+def test_score_restatement_vs_reference_golden(golden_dir):
+    """oracle/score.py vs the outputs of the reference's own bin/score.py + bin/score_norm.py
+    (tests/golden/score_ref.npz, oracle/make_golden.py:make_score)."""
+    from oracle import score as oscore
+    g = np.load(os.path.join(golden_dir, "score_ref.npz"))
+    fix = synth.synth_scoring_set()
+    mean_vec = fix["cohort_emb"].mean(0)
+    names = fix["eval_names"]
+    enroll_list = sorted(set(t[0] for t in fix["trials"]))
+    test_list = sorted(set(t[1] for t in fix["trials"]))
+    idx = {k: i for i, k in enumerate(names)}
+    e_emb = fix["eval_emb"][[idx[u] for u in enroll_list]]
+    t_emb = fix["eval_emb"][[idx[u] for u in test_list]]
+    ie = np.array([enroll_list.index(t[0]) for t in fix["trials"]])
+    it = np.array([test_list.index(t[1]) for t in fix["trials"]])
+    for tag, mv in (("nomean", None), ("mean", mean_vec)):
+        cos = oscore.cosine_pairs(fix["eval_emb"], mv, fix["idx_a"], fix["idx_b"])
+        # the golden scores went through the '%.5f' text of the score file
+        assert np.abs(cos - g[tag + "/cosine"]).max() <= 5.1e-6 + 1e-6
+        for method in ("asnorm", "snorm"):
+            cols = oscore.score_norm(method, 20, g[tag + "/cosine"], ie, it, e_emb, t_emb,
+                                     fix["cohort_emb"], mv)
+            ref = g["%s/%s" % (tag, method)]
+            assert np.abs(cols["normed"] - ref[:, 0]).max() <= 5.1e-6 + 1e-4
+            for j, key in enumerate(("enroll_mag", "test_mag", "enroll_mean", "test_mean")):
+                assert np.abs(cols[key] - ref[:, 1 + j]).max() <= 5.1e-5 + 1e-5, key
+    m, s = oscore.get_mean_std(fix["eval_emb"] - mean_vec, fix["cohort_emb"] - mean_vec, 20)
+    np.testing.assert_allclose(m, g["get_mean_std/mean"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s, g["get_mean_std/std"], rtol=0, atol=1e-6)

@@ -452,4 +452,131 @@ int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sess
   return WS_OK;
 }
 
+// ============================================================================= cosine scoring
+namespace {
+// 256 B of zeros per device for the GEMM's masked loads (lives for the life of the process)
+const float* scoring_zero_page(int device) {
+  static float* pages[64] = {nullptr};
+  if (device < 0 || device >= 64) return nullptr;
+  if (!pages[device]) {
+    float* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    pages[device] = p;
+  }
+  return pages[device];
+}
+int pointer_device(const void* ptr, int* device) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("pointer %p is not HIP device memory", ptr);
+    return WS_ERR_INVALID_ARG;
+  }
+  *device = attr.device;
+  return WS_OK;
+}
+// out[i][j] = <ua[i], ub[j]>, N = ws_cos_table_rows(n_b) columns
+int cos_gemm(const float* ua, int n_a, const float* ub, int n_b, int ld, float* out, int ldo,
+             hipStream_t st) {
+  int dev = 0;
+  int r = pointer_device(ua, &dev);
+  if (r) return r;
+  WS_HIP_CHECK(hipSetDevice(dev));
+  const float* zeros = scoring_zero_page(dev);
+  if (!zeros) { set_error("cosine scoring: zero page allocation failed"); return WS_ERR_HIP; }
+  ConvGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.A = ua; p.lda = ld;
+  p.W = ub; p.ldw = ld;
+  p.prec = 0;                                  // exact fp32 products (the reference is float32 numpy)
+  p.D = out; p.ldd = ldo;
+  p.Hin = p.Win = p.Hout = p.Wout = 1;
+  p.M = n_a; p.N = (n_b + 3) & ~3; p.K = ld; p.Cin = ld;
+  p.stride_h = p.stride_w = p.kh = p.kw = p.dil_h = p.dil_w = 1;
+  p.splitk = 1;
+  p.zeros = zeros;
+  WS_HIP_CHECK(launch_conv_gemm(p, st));
+  return WS_OK;
+}
+}  // namespace
+
+int ws_cos_table_rows(int n) { return n < 0 ? 0 : (n + 3) & ~3; }
+int ws_cos_table_ld(int dim) { return dim < 0 ? 0 : (dim + 31) & ~31; }
+
+int ws_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit, float* mag,
+                   ws_stream stream) {
+  if (n == 0) return WS_OK;
+  if (!emb || !unit || n < 0 || dim <= 0) {
+    set_error("ws_cos_prepare: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_cos_prepare(emb, mean_vec, n, dim, unit, mag, (hipStream_t)stream));
+  return WS_OK;
+}
+
+int ws_cos_pairs(const float* unit_a, const float* unit_b, int dim, const int32_t* idx_a,
+                 const int32_t* idx_b, int64_t num_trials, float* out, ws_stream stream) {
+  if (num_trials == 0) return WS_OK;
+  if (!unit_a || !unit_b || !idx_a || !idx_b || !out || dim <= 0 || num_trials < 0) {
+    set_error("ws_cos_pairs: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_cos_pairs(unit_a, unit_b, ws_cos_table_ld(dim), idx_a, idx_b, num_trials, out,
+                                (hipStream_t)stream));
+  return WS_OK;
+}
+
+int ws_cos_matrix(const float* unit_a, int n_a, const float* unit_b, int n_b, int dim, float* out,
+                  int ldo, ws_stream stream) {
+  if (n_a == 0 || n_b == 0) return WS_OK;
+  if (!unit_a || !unit_b || !out || n_a < 0 || n_b < 0 || dim <= 0 ||
+      ldo < ws_cos_table_rows(n_b) || (ldo & 3)) {
+    set_error("ws_cos_matrix: invalid argument (ldo must be a multiple of 4, >= ws_cos_table_rows(n_b))");
+    return WS_ERR_INVALID_ARG;
+  }
+  return cos_gemm(unit_a, n_a, unit_b, n_b, ws_cos_table_ld(dim), out, ldo, (hipStream_t)stream);
+}
+
+int ws_cohort_stats(const float* unit, int n, const float* unit_cohort, int n_cohort, int dim,
+                    int top_n, float* scratch, int64_t scratch_floats, float* mean, float* sd,
+                    ws_stream stream) {
+  if (n == 0) return WS_OK;
+  if (!unit || !unit_cohort || !scratch || !mean || !sd || n < 0 || n_cohort <= 0 || dim <= 0 ||
+      top_n <= 0) {
+    set_error("ws_cohort_stats: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  const int ld = ws_cos_table_ld(dim), lds = ws_cos_table_rows(n_cohort);
+  int64_t rows_fit = scratch_floats / lds;
+  if (rows_fit >= n) rows_fit = n;
+  else rows_fit &= ~(int64_t)127;
+  if (rows_fit < 128 && rows_fit < n) {
+    set_error("ws_cohort_stats: scratch of %lld floats is too small (need >= %lld)",
+              (long long)scratch_floats, (long long)128 * lds);
+    return WS_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t r0 = 0; r0 < n; r0 += rows_fit) {
+    const int rows = (int)((n - r0) < rows_fit ? (n - r0) : rows_fit);
+    int r = cos_gemm(unit + r0 * ld, rows, unit_cohort, n_cohort, ld, scratch, lds, st);
+    if (r) return r;
+    WS_HIP_CHECK(launch_topn_stats(scratch, lds, rows, n_cohort, top_n, mean + r0, sd + r0, st));
+  }
+  return WS_OK;
+}
+
+int ws_asnorm_pairs(const float* score, const int32_t* idx_e, const int32_t* idx_t,
+                    const float* e_mean, const float* e_sd, const float* t_mean, const float* t_sd,
+                    int64_t num_trials, float* out, ws_stream stream) {
+  if (num_trials == 0) return WS_OK;
+  if (!score || !idx_e || !idx_t || !e_mean || !e_sd || !t_mean || !t_sd || !out || num_trials < 0) {
+    set_error("ws_asnorm_pairs: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_asnorm_pairs(score, idx_e, idx_t, e_mean, e_sd, t_mean, t_sd, num_trials, out,
+                                   (hipStream_t)stream));
+  return WS_OK;
+}
+
 }  // extern "C"

@@ -158,4 +158,15 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
                                  const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
                                  int64_t num_trials, double* out, hipStream_t stream);
 
+// -------- cosine scoring + score normalisation (score.hip; bin/score.py, bin/score_norm.py)
+hipError_t launch_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit,
+                              float* mag, hipStream_t stream);
+hipError_t launch_cos_pairs(const float* ua, const float* ub, int ld, const int32_t* idx_a,
+                            const int32_t* idx_b, long long num, float* out, hipStream_t stream);
+hipError_t launch_topn_stats(const float* S, int ld, int n_rows, int n_cols, int top_n, float* mean,
+                             float* sd, hipStream_t stream);
+hipError_t launch_asnorm_pairs(const float* score, const int32_t* idx_e, const int32_t* idx_t,
+                               const float* e_mean, const float* e_sd, const float* t_mean,
+                               const float* t_sd, long long num, float* out, hipStream_t stream);
+
 }  // namespace wsamd

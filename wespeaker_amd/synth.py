@@ -271,3 +271,44 @@ def synth_trial_pairs(num_trials, n_enroll, n_test, seed=99):
     rng = np.random.Generator(np.random.PCG64(seed))
     return (rng.integers(0, n_enroll, num_trials).astype(np.int32),
             rng.integers(0, n_test, num_trials).astype(np.int32))
+
+
+def synth_scoring_set(n_eval=60, n_cohort=150, dim=192, num_trials=300, seed=21):
+    """Cosine-scoring / score-norm fixture: eval + cohort embeddings (a shared offset makes the
+    mean subtraction matter), utterance names and a labelled trial list."""
+    eval_emb, spk = synth_embeddings(n_eval, dim, seed=seed, num_speakers=max(2, n_eval // 6))
+    cohort_emb, _ = synth_embeddings(n_cohort, dim, seed=seed + 1, num_speakers=max(2, n_cohort // 4))
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    offset = (0.5 * rng.standard_normal(dim)).astype(np.float32)
+    eval_emb, cohort_emb = eval_emb + offset, cohort_emb + offset
+    eval_names = ["utt%04d" % i for i in range(n_eval)]
+    cohort_names = ["coh%05d" % i for i in range(n_cohort)]
+    ia = rng.integers(0, n_eval, num_trials)
+    ib = rng.integers(0, n_eval, num_trials)
+    trials = [(eval_names[a], eval_names[b], "target" if spk[a] == spk[b] else "nontarget")
+              for a, b in zip(ia, ib)]
+    return {"eval_emb": eval_emb, "cohort_emb": cohort_emb, "eval_names": eval_names,
+            "cohort_names": cohort_names, "trials": trials,
+            "idx_a": ia.astype(np.int32), "idx_b": ib.astype(np.int32)}
+
+
+def write_scoring_files(fix, out_dir):
+    """Write the fixture as the files the reference's score.py / score_norm.py consume."""
+    import os
+    from .kaldi_io import VectorWriter
+    os.makedirs(out_dir, exist_ok=True)
+    paths = {"eval_scp": os.path.join(out_dir, "xvector.scp"),
+             "cohort_scp": os.path.join(out_dir, "cohort.scp"),
+             "trials": os.path.join(out_dir, "trials.kaldi"),
+             "mean_vec": os.path.join(out_dir, "mean_vec.npy")}
+    with VectorWriter(os.path.join(out_dir, "xvector.ark"), paths["eval_scp"]) as w:
+        for k, v in zip(fix["eval_names"], fix["eval_emb"]):
+            w(k, v)
+    with VectorWriter(os.path.join(out_dir, "cohort.ark"), paths["cohort_scp"]) as w:
+        for k, v in zip(fix["cohort_names"], fix["cohort_emb"]):
+            w(k, v)
+    with open(paths["trials"], "w") as f:
+        for t in fix["trials"]:
+            f.write("%s %s %s\n" % t)
+    np.save(paths["mean_vec"], fix["cohort_emb"].mean(0))
+    return paths
