@@ -97,6 +97,20 @@ int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, fl
 int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
                ws_stream stream);
+/* Chunk-and-average extraction of ONE utterance, the native runtime's
+ * SpeakerEngine::ExtractEmbedding(const int16_t*, int, std::vector<float>* avg_emb)
+ * (runtime/core/speaker/speaker_engine.cc:83-159; SamplesPerChunk ctor argument speaker_engine.h:29-31).
+ * fbank over the whole waveform; frames cut into chunks of 1 + (samples_per_chunk - 25 ms) / 10 ms
+ * frames; a trailing partial chunk is completed with the head frames of the first chunk, an utterance
+ * shorter than one chunk is tiled cyclically; per-chunk CMN (ApplyMean); all chunks go through the
+ * model as one batch; emb = mean of the chunk embeddings.  samples_per_chunk <= 0 = "full mode" (one
+ * chunk holding every frame).  wav DEVICE (num_samples) int16 or float32 as in ws_fbank;
+ * emb DEVICE float32[embed_dim].  Returns the number of chunks (>= 1) or a negative WS_ERR_*.
+ * Grows an engine-owned scratch on first use / larger input (synchronises then). */
+int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
+                       int num_samples, int samples_per_chunk, float scale, int window_type,
+                       float* emb, ws_stream stream);
+
 /* Contraction back-end of every conv/linear GEMM (the reference computes them in fp32):
  *   WS_PREC_FP32    exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TF peak)
  *   WS_PREC_F16X3   each fp32 operand split x = hi + lo into two binary16 values (22 significant

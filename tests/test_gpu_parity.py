@@ -552,3 +552,29 @@ def test_full_size_score_norm_properties():
     # (4) monotone: a larger N can only lower the mean of the top-N
     m_600, _ = wscore.cohort_stats(t, c, 600)
     assert bool((m_600 <= m + 1e-7).all())
+
+
+# ============================================== chunk-and-average mode (native runtime)
+@pytest.mark.parametrize("seconds,samples_per_chunk", [(5.0, 32000), (1.0, 32000), (3.975, 32000),
+                                                       (2.5, 0), (6.3, 24000)])
+def test_extract_chunked_matches_oracle(frontend, seconds, samples_per_chunk):
+    from oracle import chunked
+    sd, model = _engine("ECAPA_TDNN_GLOB_c512")
+    wav = synth.synth_wav(3, int(round(seconds * 16000)))
+    emb, n_chunks = model.extract_chunked(frontend, torch.from_numpy(wav), samples_per_chunk)
+    feats = ofbank.speaker_features(wav, cmn=False)           # no CMN: the rule applies it per chunk
+    ref, n_ref = chunked.extract_chunked(
+        feats, 16000, samples_per_chunk,
+        lambda b: oecapa.ecapa_forward(sd, torch.from_numpy(b)).numpy())
+    assert n_chunks == n_ref
+    assert _cos_err(emb.cpu().numpy()[None], ref[None]) <= 1e-4
+    assert _rel_err(emb.cpu().numpy(), ref) <= 2e-3
+
+
+def test_extract_chunked_errors(frontend):
+    from wespeaker_amd._lib import NativeError
+    _, model = _engine("ECAPA_TDNN_GLOB_c512")
+    with pytest.raises(NativeError):
+        model.extract_chunked(frontend, torch.zeros(100, dtype=torch.int16), 32000)   # < 1 frame
+    with pytest.raises(NativeError):
+        model.extract_chunked(frontend, torch.zeros(32000, dtype=torch.int16), 100)   # chunk < frame

@@ -183,3 +183,21 @@ def test_score_restatement_vs_reference_golden(golden_dir):
     m, s = oscore.get_mean_std(fix["eval_emb"] - mean_vec, fix["cohort_emb"] - mean_vec, 20)
     np.testing.assert_allclose(m, g["get_mean_std/mean"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(s, g["get_mean_std/std"], rtol=0, atol=1e-6)
+
+
+def test_chunk_rule_known_answers():
+    """oracle/chunked.py against hand-worked cases of speaker_engine.cc:96-131 (2 s chunks =
+    198 frames, runtime/server/x86_gpu/README.md:35-53)."""
+    from oracle import chunked
+    cf, ch = chunked.chunk_frames(498, 16000, 32000)          # 5 s
+    assert cf == 198 and len(ch) == 3
+    assert ch[0][0] == 0 and ch[1][0] == 198 and ch[1][-1] == 395
+    assert list(ch[2][:102]) == list(range(396, 498)) and list(ch[2][102:]) == list(range(0, 96))
+    cf, ch = chunked.chunk_frames(98, 16000, 32000)           # 1 s: cyclic tiling
+    assert len(ch) == 1 and list(ch[0]) == [i % 98 for i in range(198)]
+    cf, ch = chunked.chunk_frames(396, 16000, 32000)          # exact multiple: no partial chunk
+    assert len(ch) == 2 and ch[1][-1] == 395
+    cf, ch = chunked.chunk_frames(498, 16000, 0)              # full mode
+    assert cf == 498 and len(ch) == 1 and len(ch[0]) == 498
+    cf, ch = chunked.chunk_frames(199, 16000, 32000)          # one full chunk + 1 frame
+    assert len(ch) == 2 and list(ch[1]) == [198] + list(range(0, 197))

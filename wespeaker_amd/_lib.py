@@ -30,6 +30,8 @@ SIGNATURES = {
     "ws_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ws_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float,
                            c_int, c_void_p, c_void_p]),
+    "ws_extract_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                   c_void_p, c_void_p]),
     "ws_engine_set_precision": (c_int, [c_void_p, c_int]),
     "ws_engine_profile_enable": (c_int, [c_void_p, c_int]),
     "ws_engine_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -265,6 +265,66 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
   return WS_OK;
 }
 
+int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
+                       int num_samples, int samples_per_chunk, float scale, int window_type,
+                       float* emb, ws_stream stream) {
+  if (!eng || !fe || !wav || !emb) {
+    set_error("ws_extract_chunked: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_extract_chunked: engine not finalized"); return WS_ERR_STATE; }
+  if (fe->num_bins != eng->feat_dim) {
+    set_error("ws_extract_chunked: frontend has %d mel bins, model expects %d", fe->num_bins,
+              eng->feat_dim);
+    return WS_ERR_SHAPE;
+  }
+  const int F = fe->num_bins, E = eng->embed_dim;
+  const int total = ws_num_frames(num_samples, fe->sample_rate);
+  if (total <= 0) {
+    set_error("ws_extract_chunked: utterance shorter than one frame");
+    return WS_ERR_INVALID_ARG;
+  }
+  // speaker_engine.cc:101-103 (integer arithmetic as written there)
+  int cf = total, n_full = 1, n_chunks = 1;
+  if (samples_per_chunk > 0) {
+    const int ms = fe->sample_rate / 1000;
+    cf = 1 + (samples_per_chunk - ms * 25) / (ms * 10);
+    if (samples_per_chunk < ms * 25 || cf <= 0) {
+      set_error("ws_extract_chunked: samples_per_chunk %d is shorter than one frame", samples_per_chunk);
+      return WS_ERR_INVALID_ARG;
+    }
+    n_full = total / cf;
+    n_chunks = n_full + (total % cf ? 1 : 0);
+  }
+  if (cf > eng->model->max_frames()) {
+    set_error("ws_extract_chunked: %d frames per chunk exceed the finalized capacity %d", cf,
+              eng->model->max_frames());
+    return WS_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  // scratch: [total][F] utterance feats | [n_chunks][cf][F] chunk tensor | [n_chunks][E] embeddings
+  const size_t n_feats = ((size_t)total * F + 3) & ~size_t(3);
+  const size_t n_chunk = (size_t)n_chunks * cf * F;
+  const size_t need = (n_feats + n_chunk + (size_t)n_chunks * E) * sizeof(float);
+  if (eng->chunk_scratch.bytes < need) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));       // earlier calls may still read the old buffer
+    WS_HIP_CHECK(eng->chunk_scratch.alloc(need + need / 2));
+  }
+  float* feats = eng->chunk_scratch.as<float>();
+  float* chunks = feats + n_feats;
+  float* cemb = chunks + n_chunk;
+  int r = ws_fbank(fe, wav, wav_dtype, 1, num_samples, num_samples, scale, window_type, 0, feats, stream);
+  if (r) return r;
+  WS_HIP_CHECK(launch_chunk_gather(feats, total, F, cf, samples_per_chunk > 0 ? n_full : 1, n_chunks,
+                                   chunks, st));
+  WS_HIP_CHECK(launch_cmn(chunks, n_chunks, cf, F, st));
+  r = eng->model->forward(chunks, n_chunks, cf, cemb, st);
+  if (r) return r;
+  WS_HIP_CHECK(launch_chunk_average(cemb, n_chunks, E, emb, st));
+  return n_chunks;
+}
+
 int ws_engine_set_precision(ws_engine* eng, int mode) {
   if (!eng) { set_error("ws_engine_set_precision: invalid argument"); return WS_ERR_INVALID_ARG; }
   int r = eng->model->set_precision(mode);

@@ -200,4 +200,5 @@ struct ws_engine {
   bool finalized = false;
   std::map<std::string, wsamd::HostTensor> sd;
   wsamd::Model* model = nullptr;
+  wsamd::DevBuf chunk_scratch;   // ws_extract_chunked: utterance feats | chunk tensor | chunk embeddings
 };

@@ -197,4 +197,54 @@ hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ chunk-and-average mode
+// SpeakerEngine::ExtractFeature, chunk-by-chunk branch (runtime/core/speaker/speaker_engine.cc:96-131):
+// the utterance's frames [total][F] are cut into consecutive chunks of `cf` frames; a trailing
+// partial chunk is completed with the HEAD frames of the first chunk, and an utterance shorter than
+// one chunk is tiled cyclically.  dst [n_chunks][cf][F].  One float4 per thread.
+__global__ __launch_bounds__(256) void chunk_gather_kernel(
+    const float* __restrict__ feats, int total, int F, int cf, int n_full, int n_chunks,
+    float* __restrict__ dst) {
+  const int f4 = F >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_chunks * cf * f4) return;
+  const int c4 = (int)(i % f4);
+  const long long rowi = i / f4;
+  const int fr = (int)(rowi % cf), c = (int)(rowi / cf);
+  int src;
+  if (c < n_full) {
+    src = c * cf + fr;
+  } else {
+    const int last = total - n_full * cf;
+    if (n_full == 0) src = fr % last;
+    else src = fr < last ? n_full * cf + fr : fr - last;
+  }
+  reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(feats)[(long long)src * f4 + c4];
+}
+
+hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int n_full, int n_chunks,
+                               float* dst, hipStream_t stream) {
+  if (F & 3) return hipErrorInvalidValue;
+  const long long n = (long long)n_chunks * cf * (F >> 2);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chunk_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     feats, total, F, cf, n_full, n_chunks, dst);
+  return hipGetLastError();
+}
+
+// avg[e] = (1/n) sum_c emb[c][e]   (speaker_engine.cc:147-158; summed in chunk order like the loop)
+__global__ __launch_bounds__(256) void chunk_average_kernel(const float* __restrict__ emb, int n,
+                                                            int E, float* __restrict__ avg) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  for (int c = 0; c < n; ++c) s += emb[(long long)c * E + e];
+  avg[e] = s / (float)n;
+}
+
+hipError_t launch_chunk_average(const float* emb, int n, int E, float* avg, hipStream_t stream) {
+  hipLaunchKernelGGL(chunk_average_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, emb, n, E, avg);
+  return hipGetLastError();
+}
+
 }  // namespace wsamd

@@ -129,6 +129,10 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream);
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream);
+// chunk-and-average mode of the native runtime (speaker_engine.cc:83-159)
+hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int n_full, int n_chunks,
+                               float* dst, hipStream_t stream);
+hipError_t launch_chunk_average(const float* emb, int n, int E, float* avg, hipStream_t stream);
 
 // ---- PLDA (float64)
 hipError_t launch_plda_prepare(const void* emb, int emb_is_f64, const int32_t* group_offsets,

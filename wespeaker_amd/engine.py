@@ -211,3 +211,30 @@ class NativeSpeakerModel:
                                                  WINDOW_TYPES[window_type], _lib.ptr(emb),
                                                  _lib.current_stream_ptr(self.device)), "ws_extract")
         return emb
+
+    def extract_chunked(self, frontend: Frontend, wav: torch.Tensor, samples_per_chunk: int,
+                        window_type="hamming", scale=1.0):
+        """Chunk-and-average extraction of ONE utterance: the native runtime's
+        SpeakerEngine::ExtractEmbedding (runtime/core/speaker/speaker_engine.cc:83-159) via
+        ws_extract_chunked.  samples_per_chunk <= 0 = full mode.  Returns ((E,) tensor, n_chunks)."""
+        wav = wav.reshape(-1)
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device).contiguous()
+        n = int(wav.shape[0])
+        total = frontend.num_frames(n)
+        if samples_per_chunk > 0:
+            ms = frontend.sample_rate // 1000
+            self._ensure_capacity(max(1, 1 + (samples_per_chunk - ms * 25) // (ms * 10)))
+        else:
+            self._ensure_capacity(total)
+        emb = torch.empty((self.embed_dim,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            n_chunks = _lib.check(_lib.lib().ws_extract_chunked(
+                self._h, frontend._h, _lib.ptr(wav), dt, n, int(samples_per_chunk), float(scale),
+                WINDOW_TYPES[window_type], _lib.ptr(emb), _lib.current_stream_ptr(self.device)),
+                "ws_extract_chunked")
+        return emb, n_chunks
