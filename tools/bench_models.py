@@ -14,15 +14,16 @@ CASES = [  # (model, embed_dim, batch, chunk)
     ("ECAPA_TDNN_GLOB_c512", 192, 256, 256),
     ("ECAPA_TDNN_c512", 192, 256, 256),
     ("ECAPA_TDNN_GLOB_c1024", 192, 256, 256),      # BASELINE configs[1]: batch 256 x 2 s
-    ("ResNet34", 256, 256, 64),
-    ("ResNet221", 256, 128, 32),
-    ("CAMPPlus", 512, 256, 256),
+    ("ResNet34", 256, 512, 512),
+    ("ResNet221", 256, 128, 64),
+    ("CAMPPlus", 512, 512, 512),                   # its GEMMs have M = B*T/2 rows: batch 512 fills the chip
 ]
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=0, help="override batch and engine chunk")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     fe = Frontend(16000, 80, device=dev)
@@ -30,6 +31,8 @@ def main():
     for name, ed, batch, chunk in CASES:
         if args.only and args.only not in name:
             continue
+        if args.batch:
+            batch = chunk = args.batch
         sd = synth.synth_state_dict(name, 80, ed, seed=42)
         model = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=ed, device=dev, max_batch=chunk,
                                    max_frames=T)

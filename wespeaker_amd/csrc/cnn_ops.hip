@@ -139,9 +139,16 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
   if (grp < groups) {
     for (int s = 0; s < segs; ++s) {
       const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
-      float acc = 0.f;
-      for (int t = t0 + grp; t < t1; t += groups) acc += base[(long long)t * ldh];
-      segsum[(grp * segs + s) * C + c] = acc;
+      // 8 independent loads in flight per lane: the serial form was latency-bound (~0.5 us per
+      // dependent strided load, 50 of them per lane at T' = 99)
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int t = t0 + grp;
+      for (; t + 7 * groups < t1; t += 8 * groups) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += base[(long long)(t + u * groups) * ldh];
+      }
+      for (; t < t1; t += groups) a[0] += base[(long long)t * ldh];
+      segsum[(grp * segs + s) * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
   }
   __syncthreads();
