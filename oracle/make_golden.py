@@ -15,6 +15,9 @@ What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerat
   * score_ref.npz   -- outputs of the reference's own bin/score.py (trials_cosine_score) and
                        bin/score_norm.py (get_mean_std, main with asnorm and snorm) run on the
                        synth_scoring_set fixture through real ark/scp/trial files.
+  * plda_train_ref.npz -- the reference's own TwoCovPLDA(scp_file, utt2spk_file, ...).train(3) and
+                       .adapt(adapt_scp) run on ark/scp files of the synth_plda_training_set
+                       fixture: B, W, mu, psi and LLRs of fixed pairs under the trained / adapted model.
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
 The GPU box has no /root/reference; tests there compare against these committed files.
@@ -136,6 +139,35 @@ def make_plda():
     print("plda llr range", float(llr.min()), float(llr.max()))
 
 
+def make_plda_train():
+    import tempfile
+    mod = ref_shim.ref_module("wespeaker.utils.plda.two_cov_plda")
+    utils = ref_shim.ref_module("wespeaker.utils.plda.plda_utils")
+    fix = synth.synth_plda_training_set()
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        paths = synth.write_plda_training_files(fix, d)
+        for tag, sub, nl in (("plain", False, False), ("sub_nl", True, True)):
+            plda = mod.TwoCovPLDA(scp_file=paths["scp"], utt2spk_file=paths["utt2spk"], embed_dim=64,
+                                  subtract_train_set_mean=sub, normalize_length=nl)
+            plda.train(3)
+            for k in ("B", "W", "mu", "psi", "transform", "offset"):
+                out["%s/%s" % (tag, k)] = np.array(getattr(plda, k))
+            out[tag + "/offset_scatter"] = plda.stats.offset_scatter
+            tr = np.stack([plda.transform_embedding(e.astype(np.float64)) for e in probe])
+            out[tag + "/llr"] = np.array([[plda.log_likelihood_ratio(tr[i], tr[12 + j], 2)
+                                           for j in range(12)] for i in range(12)])
+            adp = plda.adapt(paths["adapt_scp"], 0.5, 0.5)
+            adp.dim = adp.mu.shape[0]
+            out[tag + "/adapt_mu"], out[tag + "/adapt_psi"] = adp.mu, adp.psi
+            tr = np.stack([adp.transform_embedding(e.astype(np.float64)) for e in probe])
+            out[tag + "/adapt_llr"] = np.array([[adp.log_likelihood_ratio(tr[i], tr[12 + j], 1)
+                                                 for j in range(12)] for i in range(12)])
+    np.savez_compressed(os.path.join(GOLD, "plda_train_ref.npz"), **out)
+    print("plda train: psi[:4]", out["plain/psi"][:4], "adapt psi[:4]", out["plain/adapt_psi"][:4])
+
+
 def make_score():
     import tempfile
     score_mod = ref_shim.ref_module("wespeaker.bin.score")
@@ -174,4 +206,5 @@ if __name__ == "__main__":
     make_resnet_campplus()
     make_plda()
     make_score()
+    make_plda_train()
     print("golden fixtures written to", GOLD)

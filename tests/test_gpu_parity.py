@@ -578,3 +578,75 @@ def test_extract_chunked_errors(frontend):
         model.extract_chunked(frontend, torch.zeros(100, dtype=torch.int16), 32000)   # < 1 frame
     with pytest.raises(NativeError):
         model.extract_chunked(frontend, torch.zeros(32000, dtype=torch.int16), 100)   # chunk < frame
+
+
+# ================================================= PLDA training / adaptation
+def test_plda_stats_kernel_matches_numpy_float64():
+    from wespeaker_amd import plda_train
+    rng = np.random.Generator(np.random.PCG64(3))
+    for n, dim, n_cls, norm, use_mean in [(1000, 192, 37, False, False), (777, 100, 50, True, True),
+                                          (5000, 256, 300, True, False), (64, 512, 1, False, True)]:
+        x = rng.standard_normal((n, dim)).astype(np.float32) + 0.3
+        cuts = np.sort(rng.choice(np.arange(1, n), n_cls - 1, replace=False)) if n_cls > 1 else []
+        offs = np.concatenate([[0], cuts, [n]]).astype(np.int32)
+        mv = x.astype(np.float64).mean(0) if use_mean else None
+        cm, sc = plda_train.gpu_stats(x, offs, mv, norm)
+        y = x.astype(np.float64) - (mv if use_mean else 0.0)
+        if norm:
+            y = np.sqrt(dim) * y / np.linalg.norm(y, axis=1, keepdims=True)
+        ref_cm = np.stack([y[a:b].mean(0) for a, b in zip(offs[:-1], offs[1:])])
+        ref_sc = sum((y[a:b] - m).T @ (y[a:b] - m) for a, b, m in zip(offs[:-1], offs[1:], ref_cm))
+        assert np.abs(cm - ref_cm).max() <= 1e-12 * max(1.0, np.abs(ref_cm).max())
+        assert np.abs(sc - ref_sc).max() <= 1e-11 * np.abs(ref_sc).max()
+        assert np.abs(sc - sc.T).max() <= 1e-11 * np.abs(ref_sc).max()
+
+
+@pytest.mark.parametrize("tag,sub,nl", [("plain", False, False), ("sub_nl", True, True)])
+def test_plda_train_and_adapt_match_oracle_and_reference_golden(tmp_path, golden_dir, tag, sub, nl):
+    """TwoCovPLDA(scp_file, utt2spk_file, ...).train(3) / .adapt(scp) on the same ark/scp files the
+    reference was trained on.  The reference keeps per-speaker statistics in float32; ours are
+    float64, hence 2e-5 relative on B / W / psi; LLRs at the north-star 1e-3."""
+    from wespeaker_amd import TwoCovPLDA
+    g = np.load(os.path.join(golden_dir, "plda_train_ref.npz"))
+    fix = synth.synth_plda_training_set()
+    paths = synth.write_plda_training_files(fix, str(tmp_path))
+    plda = TwoCovPLDA(scp_file=paths["scp"], utt2spk_file=paths["utt2spk"], embed_dim=64,
+                      subtract_train_set_mean=sub, normalize_length=nl)
+    np.testing.assert_allclose(plda.stats.offset_scatter, g[tag + "/offset_scatter"], rtol=0,
+                               atol=2e-5 * np.abs(g[tag + "/offset_scatter"]).max())
+    plda.train(3)
+    for k in ("B", "W"):
+        ref = g["%s/%s" % (tag, k)]
+        assert np.abs(getattr(plda, k) - ref).max() <= 2e-5 * np.abs(ref).max(), k
+    np.testing.assert_allclose(plda.psi, g[tag + "/psi"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(plda.mu, g[tag + "/mu"], rtol=0, atol=1e-6)
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+
+    def llr(model, n):
+        tr = model.transform_rows(probe.astype(np.float64))
+        return model.llr_matrix(tr[:12], np.full(12, n, dtype=np.int32), tr[12:]).cpu().numpy()
+    assert np.abs(llr(plda, 2) - g[tag + "/llr"]).max() <= LLR_TOL
+    adapted = plda.adapt(paths["adapt_scp"], 0.5, 0.5)
+    assert adapted.normalize_length is False                  # reference quirk: not inherited
+    np.testing.assert_allclose(np.sort(adapted.psi), np.sort(g[tag + "/adapt_psi"]), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(adapted.mu, g[tag + "/adapt_mu"], rtol=0, atol=1e-5)
+    assert np.abs(llr(adapted, 1) - g[tag + "/adapt_llr"]).max() <= LLR_TOL
+
+
+def test_full_size_plda_stats_properties():
+    """200k x 256 training set, 5000 speakers: identities that do not need a CPU reference."""
+    from wespeaker_amd import plda_train
+    n, dim, n_cls = 200000, 256, 5000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((n, dim), generator=g, dtype=torch.float32)
+    offs = np.linspace(0, n, n_cls + 1).astype(np.int32)
+    cm, sc = plda_train.gpu_stats(x.numpy(), offs, None, False)
+    xd = x.double().cuda()
+    cls = torch.from_numpy(np.repeat(np.arange(n_cls), np.diff(offs))).cuda()
+    cm_t = torch.zeros((n_cls, dim), dtype=torch.float64, device="cuda").index_add_(0, cls, xd)
+    cm_t /= torch.from_numpy(np.diff(offs)).double().cuda()[:, None]
+    assert np.abs(cm - cm_t.cpu().numpy()).max() <= 1e-12
+    yc = xd - cm_t[cls]
+    # trace identity and a full check through torch's float64 matmul
+    assert abs(np.trace(sc) - float((yc * yc).sum())) <= 1e-9 * np.trace(sc)
+    assert np.abs(sc - (yc.T @ yc).cpu().numpy()).max() <= 1e-10 * np.abs(sc).max()

@@ -201,3 +201,33 @@ def test_chunk_rule_known_answers():
     assert cf == 498 and len(ch) == 1 and len(ch[0]) == 498
     cf, ch = chunked.chunk_frames(199, 16000, 32000)          # one full chunk + 1 frame
     assert len(ch) == 2 and list(ch[1]) == [198] + list(range(0, 197))
+
+
+@pytest.mark.parametrize("tag,sub,nl", [("plain", False, False), ("sub_nl", True, True)])
+def test_plda_training_restatement_vs_reference_golden(golden_dir, tag, sub, nl):
+    """oracle/plda_train.py vs the reference's own TwoCovPLDA.train(3) / .adapt() outputs
+    (tests/golden/plda_train_ref.npz).  Eigenvector signs are arbitrary, so the transforms are
+    compared through psi and through LLRs of fixed pairs."""
+    from oracle import plda_train as otrain
+    g = np.load(os.path.join(golden_dir, "plda_train_ref.npz"))
+    fix = synth.synth_plda_training_set()
+    mats = {}
+    for e, s in zip(fix["emb"], fix["spk"]):
+        mats.setdefault(int(s), []).append(e)
+    # class order of the reference = first appearance in the scp
+    class_mats = [np.vstack(v) for v in mats.values()]
+    p = otrain.train(class_mats, 3, subtract_train_set_mean=sub, normalize_length=nl,
+                     samples=fix["emb"])
+    for k in ("B", "W", "mu", "psi"):
+        np.testing.assert_allclose(p[k], g["%s/%s" % (tag, k)], rtol=1e-9, atol=1e-11, err_msg=k)
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+
+    def llr(params, n):
+        tr = np.stack([oplda.transform_embedding(params, e) for e in probe])
+        return np.array([[oplda.log_likelihood_ratio(params, tr[i], tr[12 + j], n)
+                          for j in range(12)] for i in range(12)])
+    np.testing.assert_allclose(llr(p, 2), g[tag + "/llr"], rtol=0, atol=1e-8)
+    a = otrain.adapt(p, fix["adapt"])
+    np.testing.assert_allclose(np.sort(a["psi"]), np.sort(g[tag + "/adapt_psi"]), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(a["mu"], g[tag + "/adapt_mu"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(llr(a, 1), g[tag + "/adapt_llr"], rtol=0, atol=1e-6)

@@ -47,6 +47,9 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "ws_plda_llr_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ws_plda_stats_scratch": (c_int64, [c_int, c_int]),
+    "ws_plda_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                              c_void_p, c_void_p, c_int64, c_void_p]),
     "ws_cos_table_rows": (c_int, [c_int]),
     "ws_cos_table_ld": (c_int, [c_int]),
     "ws_cos_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -512,6 +512,30 @@ int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sess
   return WS_OK;
 }
 
+// ======================================================================= PLDA training statistics
+int64_t ws_plda_stats_scratch(int n, int dim) {
+  if (n <= 0 || dim <= 0) return 0;
+  return plda_stats_scratch_doubles(n, dim);
+}
+
+int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets, int n_groups,
+                  const double* mean_vec, int normalize_length, double* class_mean, double* scatter,
+                  double* scratch, int64_t scratch_doubles, ws_stream stream) {
+  if (!emb || !group_offsets || !class_mean || !scatter || !scratch || n <= 0 || dim <= 0 ||
+      n_groups <= 0) {
+    set_error("ws_plda_stats: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (scratch_doubles < plda_stats_scratch_doubles(n, dim)) {
+    set_error("ws_plda_stats: scratch of %lld doubles is too small (need %lld)",
+              (long long)scratch_doubles, (long long)plda_stats_scratch_doubles(n, dim));
+    return WS_ERR_CAPACITY;
+  }
+  WS_HIP_CHECK(launch_plda_stats(emb, n, dim, group_offsets, n_groups, mean_vec, normalize_length,
+                                 class_mean, scatter, scratch, (hipStream_t)stream));
+  return WS_OK;
+}
+
 // ============================================================================= cosine scoring
 namespace {
 // 256 B of zeros per device for the GEMM's masked loads (lives for the life of the process)

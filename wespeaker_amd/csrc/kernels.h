@@ -162,6 +162,13 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
                                  const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
                                  int64_t num_trials, double* out, hipStream_t stream);
 
+// -------- PLDA training statistics (plda_train.hip; two_cov_plda.py:48-66,95-107,261-275)
+int64_t plda_stats_scratch_doubles(int n, int dim);
+hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets,
+                             int n_groups, const double* mean_vec, int normalize_length,
+                             double* class_mean, double* scatter, double* scratch,
+                             hipStream_t stream);
+
 // -------- cosine scoring + score normalisation (score.hip; bin/score.py, bin/score_norm.py)
 hipError_t launch_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit,
                               float* mag, hipStream_t stream);

@@ -9,7 +9,9 @@ plus the matrix / pair APIs and the new in-memory entry point `score_plda(...)` 
 `eval_sv`; the reference only has it as bin/eval_plda.py + local/score_plda.sh).
 All arithmetic runs in float64 in the HIP library (the reference computes in numpy float64);
 numpy/torch are used here only for plumbing (name -> row index maps, device buffers).
-EM training / adaptation (two_cov_plda.py:106-154,258-309) are not on this path.
+EM training / adaptation (two_cov_plda.py:38-154,258-309): `TwoCovPLDA(scp_file=..., utt2spk_file=...)`,
+`.train(iters)`, `.adapt(scp)` -- the utterance-level statistics run on the GPU (ws_plda_stats), the
+D x D algebra in numpy float64 (wespeaker_amd/plda_train.py).
 """
 import ctypes
 import struct
@@ -31,7 +33,8 @@ def _f64(x):
 class TwoCovPLDA:
 
     def __init__(self, mu=None, transform=None, psi=None, offset=None, normalize_length=False,
-                 subtract_train_set_mean=False, embed_dim=256, device=None):
+                 subtract_train_set_mean=False, embed_dim=256, device=None, scp_file=None,
+                 utt2spk_file=None):
         self.normalize_length = bool(normalize_length)
         self.subtract_train_set_mean = bool(subtract_train_set_mean)
         self.dim = int(embed_dim if mu is None else np.asarray(mu).shape[0])
@@ -41,6 +44,43 @@ class TwoCovPLDA:
         self.offset = _f64(-self.transform @ self.mu if offset is None else offset)
         self._device = device
         self._h = None
+        self.stats = None
+        self.B, self.W = np.eye(self.dim), np.eye(self.dim)
+        if scp_file is not None:                      # training constructor, two_cov_plda.py:95-107
+            from . import plda_train
+            samples, embeddings_dict = plda_train.get_data_for_plda(scp_file, utt2spk_file)
+            train_mean = samples.mean(0) if self.subtract_train_set_mean else None
+            self.stats = plda_train.collect_stats(embeddings_dict, train_mean, self.normalize_length,
+                                                  device)
+            self.dim = self.stats.dim
+            self.B, self.W = np.eye(self.dim), np.eye(self.dim)
+            self.mu = self.stats.sum_ / self.stats.class_weight
+
+    # ---------------------------------------------------------------- training (host f64 on GPU stats)
+    def em_one_iter(self):
+        from . import plda_train
+        self.B, self.W = plda_train.em_one_iter(self.stats, self.B, self.W)
+
+    def get_output(self):
+        from . import plda_train
+        self.mu, self.transform, self.psi, self.offset = plda_train.get_output(self.stats, self.B, self.W)
+        self._invalidate()
+
+    def train(self, num_em_iters):
+        for i in range(num_em_iters):
+            print("Plda estimation %d of %d" % (i, num_em_iters))
+            self.em_one_iter()
+        self.get_output()
+
+    def adapt(self, adapt_scp, ac_scale=0.5, wc_scale=0.5):
+        """two_cov_plda.py:258-309.  Like the reference, the returned model does NOT inherit
+        normalize_length / subtract_train_set_mean (it is built by a bare TwoCovPLDA())."""
+        from . import plda_train
+        rows = np.array(list(read_vec_scp(adapt_scp).values()))
+        mu, tr, psi, off = plda_train.adapt_parameters(self.mu, self.transform, self.psi, rows,
+                                                       self.normalize_length, ac_scale, wc_scale,
+                                                       self._device)
+        return TwoCovPLDA(mu, tr, psi, off, device=self._device)
 
     # ------------------------------------------------------------------------------ native handle
     @property

@@ -312,3 +312,34 @@ def write_scoring_files(fix, out_dir):
             f.write("%s %s %s\n" % t)
     np.save(paths["mean_vec"], fix["cohort_emb"].mean(0))
     return paths
+
+
+def synth_plda_training_set(n=400, dim=64, num_speakers=40, n_adapt=300, seed=41):
+    """PLDA training / adaptation fixture: labelled training embeddings (variable utterances per
+    speaker) and an unlabelled, shifted and rescaled adaptation set."""
+    emb, spk = synth_embeddings(n, dim, seed=seed, num_speakers=num_speakers)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    emb = emb + (0.3 * rng.standard_normal(dim)).astype(np.float32)
+    adp, _ = synth_embeddings(n_adapt, dim, seed=seed + 2, num_speakers=max(2, n_adapt // 10))
+    adp = (1.3 * adp + (0.5 * rng.standard_normal(dim))).astype(np.float32)
+    names = ["trn%05d" % i for i in range(n)]
+    return {"emb": emb, "spk": spk, "names": names, "adapt": adp,
+            "adapt_names": ["adp%05d" % i for i in range(n_adapt)]}
+
+
+def write_plda_training_files(fix, out_dir):
+    import os
+    from .kaldi_io import VectorWriter
+    os.makedirs(out_dir, exist_ok=True)
+    paths = {"scp": os.path.join(out_dir, "train.scp"), "utt2spk": os.path.join(out_dir, "utt2spk"),
+             "adapt_scp": os.path.join(out_dir, "adapt.scp")}
+    with VectorWriter(os.path.join(out_dir, "train.ark"), paths["scp"]) as w:
+        for k, v in zip(fix["names"], fix["emb"]):
+            w(k, v)
+    with open(paths["utt2spk"], "w") as f:
+        for k, s in zip(fix["names"], fix["spk"]):
+            f.write("%s spk%03d\n" % (k, s))
+    with VectorWriter(os.path.join(out_dir, "adapt.ark"), paths["adapt_scp"]) as w:
+        for k, v in zip(fix["adapt_names"], fix["adapt"]):
+            w(k, v)
+    return paths
