@@ -105,7 +105,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
-           o_colsum = take(((M + 63) / 64 + 2) * 2 * C), o_feats = take(M * feat_dim);
+           o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
@@ -171,13 +171,20 @@ struct EcapaModel : ModelBase {
       }));
     }
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
-    WS_LAUNCH(gemm(conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU), st));
+    // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
+    const bool stats_from_colsum = glob && T >= 64;
+    {
+      ConvGemmParams pc = conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU);
+      if (stats_from_colsum) pc.colsum = colsum;
+      WS_LAUNCH(gemm(pc, st));
+    }
     // ASTP
     ConvGemmParams a1 = conv1d(pool1, h, 1536, 0, att, 128, 0, B, T, 1, ACT_TANH);
     a1.K = 1536; a1.Cin = 1536;                      // GLOB: only the first 1536 columns multiply h
     if (glob) {
       // [mean; std] statistics, then bias_img = W1[:, C:3C] [mean; std] + b1 as a split-K GEMM
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
+        if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st);
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st);
       }));
       ConvGemmParams cb = conv1d(pool1, stats, 3072, 0, bias_img, 128, 0, B, 1, 1, ACT_NONE);

@@ -243,6 +243,61 @@ __global__ __launch_bounds__(256) void astp_context_bias_kernel(const float* __r
   }
 }
 
+// Same statistics when the producing GEMM already left per-64-row-tile column sums (catconv with
+// `colsum`): the mean comes from those, so h is read ONCE (centred squares, still two-pass exact).
+// grid = (B, C/256), block = 256: lane = 4 channels (16-B loads), the 4 wavefronts split T,
+// 8 independent row loads in flight per lane.
+__global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
+    const float* __restrict__ h, int ldh, int T, int C, const float* __restrict__ colsum,
+    float* __restrict__ stats) {
+  __shared__ f32x4 red[4][64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + lane * 4;
+  const long long r0 = (long long)b * T, r1 = r0 + T - 1;
+  const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+  for (int tm = t_first; tm <= t_last; ++tm) {
+    const int first_img = (int)(((long long)tm * 64) / T);
+    const int which = (first_img == b) ? 0 : 1;
+    mean += *reinterpret_cast<const f32x4*>(colsum + ((long long)tm * 2 + which) * C + c);
+  }
+  mean *= 1.f / (float)T;
+  const float* base = h + r0 * ldh + c;
+  f32x4 q[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int t = wave;
+  for (; t + 28 < T; t += 32) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (long long)(t + 4 * u) * ldh);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const f32x4 d = v[u] - mean; q[u] += d * d; }
+  }
+  for (; t < T; t += 4) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(base + (long long)t * ldh) - mean;
+    q[0] += d * d;
+  }
+  red[wave][lane] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 var = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * (1.f / (float)(T - 1));
+    f32x4 sd;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sd[k] = sqrtf(var[k] + 1e-7f);
+    *reinterpret_cast<f32x4*>(stats + (long long)b * 2 * C + c) = mean;
+    *reinterpret_cast<f32x4*>(stats + (long long)b * 2 * C + C + c) = sd;
+  }
+}
+
+hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
+                                       const float* colsum, float* stats, hipStream_t stream) {
+  if ((C & 255) || T < 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(astp_std_from_colsum_kernel, dim3(B, C / 256), dim3(256), 0, stream, h, ldh, T,
+                     C, colsum, stats);
+  return hipGetLastError();
+}
+
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
                              hipStream_t stream) {
   hipLaunchKernelGGL(astp_stats_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, h, ldh, T,

@@ -135,14 +135,21 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
   }
   wave_sync();
 
-  // 5. mel filterbank + log
-  for (int bin = lane; bin < tb.num_bins; bin += 64) {
-    const int st = mel_start_s[bin], len = mel_len_s[bin];
-    const float* w = mel_w_s + mel_off_s[bin];
+  // 5. mel filterbank + log.  Four lanes per mel bin (16 bins per pass): the triangular filters grow
+  // from 2 to ~37 taps, so one lane per bin left the longest filter on the critical path
+  // (~55 dependent LDS round trips per frame); split taps + two shuffles need ~28.
+  for (int b0 = 0; b0 < tb.num_bins; b0 += 16) {
+    const int bin = b0 + (lane >> 2), sub = lane & 3;
+    const bool has = bin < tb.num_bins;
+    const int bb = has ? bin : 0;
+    const int st = mel_start_s[bb], len = has ? mel_len_s[bb] : 0;
+    const float* w = mel_w_s + mel_off_s[bb];
     float acc = 0.f;
-    for (int i = 0; i < len; ++i) acc += w[i] * P[st + i];
+    for (int i = sub; i < len; i += 4) acc += w[i] * P[st + i];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
     const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
-    if (live) feats[frame * tb.num_bins + bin] = v;
+    if (live && has && sub == 0) feats[frame * tb.num_bins + bin] = v;
   }
 }
 

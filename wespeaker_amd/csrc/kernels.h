@@ -84,6 +84,8 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
                                     int C, hipStream_t stream);
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
+hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
+                                       const float* colsum, float* stats, hipStream_t stream);
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
                              hipStream_t stream);
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
