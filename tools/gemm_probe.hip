@@ -29,6 +29,21 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(A, h.data(), maxA * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W, h.data(), maxW * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(bias, h.data(), 1536 * 4, hipMemcpyHostToDevice));
+  // data mode (argv[2]): 0 random A, constant weight halves; 1 all zeros; 2 random A and random
+  // weight halves (what a real model looks like).  DVFS makes the run time data dependent.
+  const int data_mode = argc > 2 ? atoi(argv[2]) : 0;
+  if (data_mode == 1) {
+    CK(hipMemset(A, 0, maxA * 4)); CK(hipMemset(W, 0, maxW * 4));
+    CK(hipMemset(Wh, 0, maxW * 2)); CK(hipMemset(Wl, 0, maxW * 2));
+  } else if (data_mode == 2) {
+    std::vector<uint16_t> hh(maxW), hl(maxW);
+    for (size_t i = 0; i < maxW; ++i) {
+      hh[i] = (uint16_t)(0x3000 + (rand() % 0x0c00) + ((rand() & 1) << 15));   // |x| in [0.125, 1)
+      hl[i] = (uint16_t)(0x1000 + (rand() % 0x0c00) + ((rand() & 1) << 15));
+    }
+    CK(hipMemcpy(Wh, hh.data(), maxW * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(Wl, hl.data(), maxW * 2, hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& s : shapes) {
     ConvGemmParams p; memset(&p, 0, sizeof(p));
