@@ -117,9 +117,15 @@ int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav
  *                   bits) and the product formed as hi*hi + hi*lo + lo*hi on
  *                   v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative product error,
  *                   i.e. fp32-grade results at 3/16 of the fp32-MFMA issue cost.
+ *   WS_PREC_F16     operands rounded to binary16, ONE MFMA pass, fp32 accumulation -- the arithmetic
+ *                   of the reference's own GPU deployment (TensorRT fp16, runtime/server/x86_gpu):
+ *                   ~5e-4 relative on the embedding, 1 - cos ~ 4e-7 against the fp32 reference
+ *                   (the 1e-4 bar holds with > 100x margin); inputs must stay inside the binary16
+ *                   range (65504), which int16-scale fbank + CMN features do.
  * May be switched at any time between forwards. */
 #define WS_PREC_FP32 0
 #define WS_PREC_F16X3 1
+#define WS_PREC_F16 2
 int ws_engine_set_precision(ws_engine* eng, int mode);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);

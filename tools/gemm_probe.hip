@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include "../wespeaker_amd/csrc/kernels.h"
 using namespace wsamd;
@@ -54,6 +55,16 @@ int main(int argc, char** argv) {
     p.Hin = p.Hout = 1; p.Win = p.Wout = 198; p.stride_h = p.stride_w = 1; p.kh = 1; p.kw = s.taps;
     p.dil_h = 1; p.dil_w = s.taps == 3 ? 2 : 1; p.pad_w = p.dil_w * (s.taps / 2);
     p.bias = bias; p.act = ACT_RELU; p.post_scale = bias; p.post_shift = bias; p.splitk = 1; p.zeros = Z;
+    static uint16_t* A16 = nullptr;
+    if (getenv("PROBE_A16") && prec == 2 && s.taps == 1) {
+      if (!A16) {
+        CK(hipMalloc(&A16, maxA * 2));
+        std::vector<uint16_t> h16(maxA);
+        for (size_t i = 0; i < maxA; ++i) { _Float16 v = (_Float16)h[i]; memcpy(&h16[i], &v, 2); }
+        CK(hipMemcpy(A16, h16.data(), maxA * 2, hipMemcpyHostToDevice));
+      }
+      p.A16 = A16; p.lda16 = Cin;
+    }
     for (int i = 0; i < 3; ++i) CK(launch_conv_gemm(p, 0));
     CK(hipDeviceSynchronize());
     const int iters = 20;
@@ -63,7 +74,36 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
-    printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF\n", s.name, s.M, s.N, s.K, s.taps, us, tf);
+    // spot check of 64 outputs against a host evaluation (1x1 shapes only; bias/BN epilogue included)
+    double max_err = -1.0;
+    if (s.taps == 1 && argc > 3) {
+      std::vector<float> hd((size_t)s.M * s.N);
+      CK(hipMemcpy(hd.data(), D, hd.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<uint16_t> wh((size_t)s.N * p.ldw), wl((size_t)s.N * p.ldw);
+      CK(hipMemcpy(wh.data(), Wh, wh.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(wl.data(), Wl, wl.size() * 2, hipMemcpyDeviceToHost));
+      auto h2f = [](uint16_t b) { _Float16 v; memcpy(&v, &b, 2); return (double)(float)v; };
+      max_err = 0.0;
+      for (int t = 0; t < 64; ++t) {
+        const int m = (int)(((long long)t * 7919 + 13) % s.M), n = (t * 131 + 7) % s.N;
+        double acc = 0.0;
+        for (int k = 0; k < s.K; ++k) {
+          const float a = h[(size_t)m * Cin + k];
+          double av = a, wv;
+          if (prec == 2) { av = (double)(float)(_Float16)a; wv = h2f(wh[(size_t)n * p.ldw + k]); }
+          else if (prec == 1) wv = h2f(wh[(size_t)n * p.ldw + k]) + h2f(wl[(size_t)n * p.ldw + k]);
+          else wv = h[(size_t)n * p.ldw + k];
+          acc += av * wv;
+        }
+        double v = acc + h[n];
+        v = v > 0 ? v : 0;
+        v = v * h[n] + h[n];
+        const double e = fabs(v - hd[(size_t)m * s.N + n]) / (fabs(v) + 1.0);
+        if (e > max_err) max_err = e;
+      }
+    }
+    printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e\n", s.name, s.M, s.N, s.K,
+           s.taps, us, tf, max_err);
   }
   return 0;
 }

@@ -328,7 +328,7 @@ int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav
 int ws_engine_set_precision(ws_engine* eng, int mode) {
   if (!eng) { set_error("ws_engine_set_precision: invalid argument"); return WS_ERR_INVALID_ARG; }
   int r = eng->model->set_precision(mode);
-  if (r) set_error("ws_engine_set_precision: unknown mode %d (0 = fp32 MFMA, 1 = split-f16 x3)", mode);
+  if (r) set_error("ws_engine_set_precision: unknown mode %d (0 = fp32 MFMA, 1 = split-f16 x3, 2 = f16)", mode);
   return r;
 }
 

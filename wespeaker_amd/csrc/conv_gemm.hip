@@ -11,6 +11,8 @@
 //  * two contraction back-ends behind one tiling (template PREC):
 //      PREC 0  v_mfma_f32_32x32x2_f32: exact fp32 products (bit-identical to an fmaf chain),
 //              157 TF peak.  One ds_read_b128 feeds 4 MFMAs per tile (k-permuted lanes).
+//      PREC 2  "f16": operands rounded to binary16 (hi planes only), ONE MFMA pass, fp32 accumulation
+//              -- the arithmetic of the reference's own TensorRT-fp16 GPU runtime;
 //      PREC 1  "f16x3": every fp32 operand is split x = hi + lo (hi = half(x), lo = half(x - hi),
 //              22 significant bits) and the product is formed as hi*hi + hi*lo + lo*hi on
 //              v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative product error
@@ -47,7 +49,8 @@ constexpr int HS = BK + 8;           // f16x3 path: halfs per LDS row (80 B)
 template <int BM, int BN, int PREC>
 constexpr size_t tile_lds_bytes() {
   // per buffer: A and W tiles; PREC 1 keeps a hi and a lo half plane per tile (same bytes as fp32)
-  const size_t stage = PREC == 0 ? (size_t)(BM + BN) * LDS_STRIDE * 4 : (size_t)(BM + BN) * HS * 2 * 2;
+  const size_t stage = PREC == 0 ? (size_t)(BM + BN) * LDS_STRIDE * 4
+                                  : (size_t)(BM + BN) * HS * 2 * (PREC == 1 ? 2 : 1);
   const size_t epi = (size_t)BM * (BN + 4) * 4;
   return 2 * stage > epi ? 2 * stage : epi;
 }
@@ -152,7 +155,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
 
   f32x4 ra[A_IT];
   f32x4 rw[PREC == 0 ? W_IT : 1];
-  u32x4 rwh[PREC == 1 ? W_IT : 1], rwl[PREC == 1 ? W_IT : 1];
+  u32x4 rwh[PREC >= 1 ? W_IT : 1], rwl[PREC == 1 ? W_IT : 1];
   auto load_tile = [&](int kt) {
     // ---- weights
 #pragma unroll
@@ -162,9 +165,11 @@ void conv_gemm_kernel(const ConvGemmParams p) {
         sw_ptr[i] += sw_inc[i];
       } else {
         rwh[i] = *reinterpret_cast<const u32x4*>(swh_ptr[i]);
-        rwl[i] = *reinterpret_cast<const u32x4*>(swl_ptr[i]);
         swh_ptr[i] += sw_inc[i];
-        swl_ptr[i] += sw_inc[i];
+        if (PREC == 1) {
+          rwl[i] = *reinterpret_cast<const u32x4*>(swl_ptr[i]);
+          swl_ptr[i] += sw_inc[i];
+        }
       }
     }
     // ---- activations
@@ -210,7 +215,8 @@ void conv_gemm_kernel(const ConvGemmParams p) {
 
   // LDS map.  PREC 0: [buf][A rows | W rows][36 floats].
   //           PREC 1: [buf][A_hi | A_lo | W_hi | W_lo] planes of [rows][40 halfs].
-  constexpr int STAGE_FLOATS = PREC == 0 ? (BM + BN) * S : (BM + BN) * HS;   // floats per buffer
+  constexpr int STAGE_FLOATS =
+      PREC == 0 ? (BM + BN) * S : (PREC == 1 ? (BM + BN) * HS : (BM + BN) * HS / 2);   // floats per buffer
   auto store_tile = [&](int buf) {
     if (PREC == 0) {
       float* As = lds + buf * STAGE_FLOATS;
@@ -223,9 +229,10 @@ void conv_gemm_kernel(const ConvGemmParams p) {
         *reinterpret_cast<f32x4*>(&Ws[(r0 + AROWS * i) * S + kc * 4]) = rw[i];
     } else {
       _Float16* base = reinterpret_cast<_Float16*>(lds + buf * STAGE_FLOATS);
+      // PREC 1: [A_hi | A_lo | W_hi | W_lo]; PREC 2 (plain binary16 operands): [A_hi | W_hi]
       _Float16* Ah = base;
       _Float16* Al = Ah + BM * HS;
-      _Float16* Wh = Al + BM * HS;
+      _Float16* Wh = PREC == 1 ? Al + BM * HS : Ah + BM * HS;
       _Float16* Wl = Wh + BN * HS;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
@@ -234,16 +241,16 @@ void conv_gemm_kernel(const ConvGemmParams p) {
         for (int q = 0; q < 4; ++q) {
           const _Float16 h = (_Float16)ra[i][q];
           hi[q] = h;
-          lo[q] = (_Float16)(ra[i][q] - (float)h);
+          if (PREC == 1) lo[q] = (_Float16)(ra[i][q] - (float)h);
         }
         *reinterpret_cast<f16x4*>(&Ah[(r0 + AROWS * i) * HS + kc * 4]) = hi;
-        *reinterpret_cast<f16x4*>(&Al[(r0 + AROWS * i) * HS + kc * 4]) = lo;
+        if (PREC == 1) *reinterpret_cast<f16x4*>(&Al[(r0 + AROWS * i) * HS + kc * 4]) = lo;
       }
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
         if (BN >= WROWS || wr0 < BN) {
           *reinterpret_cast<u32x4*>(&Wh[(wr0 + WROWS * i) * HS + wc * 8]) = rwh[i];
-          *reinterpret_cast<u32x4*>(&Wl[(wr0 + WROWS * i) * HS + wc * 8]) = rwl[i];
+          if (PREC == 1) *reinterpret_cast<u32x4*>(&Wl[(wr0 + WROWS * i) * HS + wc * 8]) = rwl[i];
         }
       }
     }
@@ -294,7 +301,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
       const _Float16* base = reinterpret_cast<const _Float16*>(lds + buf * STAGE_FLOATS);
       const _Float16* Ah = base + (wm * TM * 32 + li) * HS + lh * 8;
       const _Float16* Al = Ah + BM * HS;
-      const _Float16* Wh = base + 2 * BM * HS + (wn * TN * 32 + li) * HS + lh * 8;
+      const _Float16* Wh = base + (PREC == 1 ? 2 : 1) * BM * HS + (wn * TN * 32 + li) * HS + lh * 8;
       const _Float16* Wl = Wh + BN * HS;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
@@ -302,24 +309,26 @@ void conv_gemm_kernel(const ConvGemmParams p) {
 #pragma unroll
         for (int im = 0; im < TM; ++im) {
           ah[im] = *reinterpret_cast<const f16x8*>(&Ah[im * 32 * HS + ks * 16]);
-          al[im] = *reinterpret_cast<const f16x8*>(&Al[im * 32 * HS + ks * 16]);
+          if (PREC == 1) al[im] = *reinterpret_cast<const f16x8*>(&Al[im * 32 * HS + ks * 16]);
         }
 #pragma unroll
         for (int in = 0; in < TN; ++in) {
           bh[in] = *reinterpret_cast<const f16x8*>(&Wh[in * 32 * HS + ks * 16]);
-          bl[in] = *reinterpret_cast<const f16x8*>(&Wl[in * 32 * HS + ks * 16]);
+          if (PREC == 1) bl[in] = *reinterpret_cast<const f16x8*>(&Wl[in * 32 * HS + ks * 16]);
         }
-        // small cross terms first, the hi*hi term last
+        if (PREC == 1) {
+          // small cross terms first, the hi*hi term last
 #pragma unroll
-        for (int im = 0; im < TM; ++im)
+          for (int im = 0; im < TM; ++im)
 #pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], bh[in], acc[im][in], 0, 0, 0);
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], bh[in], acc[im][in], 0, 0, 0);
 #pragma unroll
-        for (int im = 0; im < TM; ++im)
+          for (int im = 0; im < TM; ++im)
 #pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+        }
 #pragma unroll
         for (int im = 0; im < TM; ++im)
 #pragma unroll
@@ -545,12 +554,18 @@ void conv_gemm_kernel(const ConvGemmParams p) {
 
 template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
 static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
-  constexpr size_t lds_bytes = tile_lds_bytes<BM, BN, PREC>();
+  // staging buffers / epilogue transpose tile, and -- only for the fused-pooling epilogue -- its
+  // [NH*2][RPP][4][BN] reduction array (= BM * threads / 2 floats), which exceeds the former for the
+  // single-plane f16 back-end on small tiles
+  constexpr size_t base_bytes = tile_lds_bytes<BM, BN, PREC>();
+  constexpr size_t pool_bytes = (size_t)BM * (64 * WM * WN) * 2;
+  constexpr size_t max_bytes = base_bytes > pool_bytes ? base_bytes : pool_bytes;
+  const size_t lds_bytes = p.pool_partial ? max_bytes : base_bytes;
   static bool attr_set = false;
   auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE, PREC>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -637,6 +652,10 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.prec == 1) {
     if (!p.Wh || !p.Wl) return hipErrorInvalidValue;
     return launch_prec<1>(p, stream);
+  }
+  if (p.prec == 2) {
+    if (!p.Wh) return hipErrorInvalidValue;
+    return launch_prec<2>(p, stream);
   }
   return launch_prec<0>(p, stream);
 }

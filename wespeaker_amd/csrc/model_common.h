@@ -44,7 +44,7 @@ struct ModelBase : Model {
     zeros_off = arena.add(nullptr, 64);
   }
   int set_precision(int mode) override {
-    if (mode != 0 && mode != 1) return WS_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 2) return WS_ERR_INVALID_ARG;
     gemm_precision = mode;
     return WS_OK;
   }
@@ -66,7 +66,7 @@ struct ModelBase : Model {
     cw->wl = arena.add(nullptr, n / 2);
     std::memcpy(arena.host.data() + cw->wl, lo.data(), n * 2);
   }
-  int gemm_precision = 0;     // 0: exact fp32 MFMA, 1: 3-pass split-f16 MFMA (fp32 accumulate)
+  int gemm_precision = 0;     // 0: exact fp32 MFMA, 1: 3-pass split-f16 MFMA, 2: 1-pass f16 (fp32 accumulate)
 
   // ------------------------------------------------------------------------- tensor lookup
   const HostTensor* get(const SD& sd, const std::string& key, std::vector<int64_t> want, int* err) {

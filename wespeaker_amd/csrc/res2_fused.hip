@@ -322,7 +322,7 @@ bool res2_chain_supported(int W, int T, int dil) {
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
-  if (p.prec == 1) {
+  if (p.prec >= 1) {   // (the f16 mode reuses the split kernel: more precise, same launch count)
     if (p.W == 64) {
       if (p.T <= 2 * 7 * 16) return launch_res2_f16_variant<64, 7>(p, stream);
       if (p.T <= 2 * 13 * 16) return launch_res2_f16_variant<64, 13>(p, stream);

@@ -129,7 +129,7 @@ class NativeSpeakerModel:
             return self          # outputs are returned wherever the caller asks; compute stays on the GPU
         raise _lib.NativeError("engine was created on %s; create a new one for %s" % (self.device, dev))
 
-    PRECISIONS = {"fp32": 0, "f16x3": 1}
+    PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2}
 
     def set_precision(self, mode):
         """'fp32' (exact fp32 MFMA, default) or 'f16x3' (3-pass split-binary16 MFMA with fp32
