@@ -55,6 +55,227 @@ constexpr size_t tile_lds_bytes() {
   return 2 * stage > epi ? 2 * stage : epi;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared epilogue of the MFMA GEMM kernels: takes the 32x32 accumulator blocks of the workgroup's
+// BM x BN tile, returns after all global stores (it ends on code every thread executes).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                              float* lds, int m0, int n0) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int HW = p.Hout * p.Wout;
+
+  // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int n = n0 + (wn * TN + in) * 32 + li;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = acc[im][in][r];
+        }
+    }
+    return;
+  }
+  // Transpose the accumulators through LDS (the staging buffers are free now) so that every lane
+  // finishes 4 consecutive output channels of one row: 16-B global stores, 512 B contiguous per
+  // output row, instead of 4-B stores (which are ~6x slower per byte on gfx950).
+  constexpr int ES = BN + 4;
+  {
+    float* Es = lds;
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          Es[row * ES + (wn * TN + in) * 32 + li] = acc[im][in][r];
+        }
+  }
+  __syncthreads();
+  {
+    constexpr int C4 = BN / 4;                 // float4 columns per tile row
+    constexpr int RPP = NT / C4;               // rows per pass
+    const int c4 = tid % C4, rr = tid / C4;
+    const int n = n0 + c4 * 4;
+    constexpr int NH = BM / 64;                // 64-row halves (column-sum granularity)
+    f32x4 cs[NH][2];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) cs[hf][0] = cs[hf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // softmax-pooling partials (ASTP fused into the logit GEMM): running max + 3 weighted sums
+    f32x4 pm[NH][2], p0[NH][2], p1[NH][2], p2[NH][2];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh) {
+        pm[hf][wh] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+        p0[hf][wh] = p1[hf][wh] = p2[hf][wh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    if (p.pool_partial) {
+      // ASTP fused into the logit GEMM: the logits are never written to HBM.  All h rows of a
+      // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
+      // online-softmax tuples of the (half, image part) groups.
+      if (n < p.N) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+          const int mh = m0 + hf * 64;
+          const int rb = (mh / HW + 1) * HW - mh;
+          constexpr int RI = 64 / RPP;
+          f32x4 hv[RI];
+#pragma unroll
+          for (int i = 0; i < RI; ++i) {
+            const int m = mh + rr + RPP * i;
+            const int mc = m < p.M ? m : p.M - 1;
+            hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+          }
+#pragma unroll
+          for (int i = 0; i < RI; ++i) {
+            const int rl = rr + RPP * i;
+            if (mh + rl < p.M) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
+              const bool second = rl >= rb;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float mo = second ? pm[hf][1][q] : pm[hf][0][q];
+                const float mn = fmaxf(mo, v[q]);
+                const float sc = __expf(mo - mn), pe = __expf(v[q] - mn);
+                const float h1 = pe * hv[i][q], h2 = h1 * hv[i][q];
+                if (second) {
+                  pm[hf][1][q] = mn;
+                  p0[hf][1][q] = p0[hf][1][q] * sc + pe;
+                  p1[hf][1][q] = p1[hf][1][q] * sc + h1;
+                  p2[hf][1][q] = p2[hf][1][q] * sc + h2;
+                } else {
+                  pm[hf][0][q] = mn;
+                  p0[hf][0][q] = p0[hf][0][q] * sc + pe;
+                  p1[hf][0][q] = p1[hf][0][q] * sc + h1;
+                  p2[hf][0][q] = p2[hf][0][q] * sc + h2;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else
+    if (n < p.N) {                             // N % 4 == 0 (checked on the host)
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.post_scale) {
+        ps = *reinterpret_cast<const f32x4*>(p.post_scale + n);
+        pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
+      }
+      const bool to_d2 = p.D2 && n >= p.d2_col0;
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf) {
+        // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
+        const int mh = m0 + hf * 64;
+        const int rb = (mh / HW + 1) * HW - mh;
+#pragma unroll 4
+        for (int rl = rr; rl < 64; rl += RPP) {
+          const int row = hf * 64 + rl;
+          const int m = m0 + row;
+          if (m >= p.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
+          if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
+          if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          } else if (p.act == ACT_TANH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+          }
+          if (p.post_scale) v = v * ps + pb;
+          if (p.seg_scale) {
+            const int img = m / HW, ox = (m - img * HW) % p.Wout;
+            v *= *reinterpret_cast<const f32x4*>(
+                p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
+          }
+          *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
+          if (p.D16) {
+            f16x4 hv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+            *reinterpret_cast<f16x4*>(p.D16 + (long long)m * p.ldd16 + p.d_off + n) = hv;
+          }
+          if (to_d2)
+            *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
+          if (p.colsum) {
+            if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
+          }
+        }
+      }
+    }
+    if (p.colsum) {
+      // Deterministic per-(64-row tile, image) column sums of the stored values (SE / statistics
+      // pooling without re-reading the tensor): fold the RPP row phases through LDS, then one
+      // plain store per column -> colsum[(tile64*2 + which)][N].
+      __syncthreads();                                  // everyone is done reading the E tile
+      float* red = lds;                                 // [NH][2][RPP][BN]
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh)
+          *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
+      __syncthreads();
+      for (int o = tid; o < NH * 2 * BN; o += NT) {
+        const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) sacc += red[(hw * RPP + q) * BN + col];
+        if (n0 + col < p.N)
+          p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
+      }
+    }
+    if (p.pool_partial) {
+      // fold the RPP row phases: (max, s0, s1, s2) tuples combined with the usual rescaling;
+      // one [4]-tuple per (64-row tile, image part, column) -> pool_partial[tile64*2 + which][N][4]
+      __syncthreads();
+      float* red = lds;                                 // [NH*2][RPP][4][BN]
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh) {
+          float* r0p = &red[(((hf * 2 + wh) * RPP + rr) * 4) * BN + c4 * 4];
+          *reinterpret_cast<f32x4*>(r0p) = pm[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + BN) = p0[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + 2 * BN) = p1[hf][wh];
+          *reinterpret_cast<f32x4*>(r0p + 3 * BN) = p2[hf][wh];
+        }
+      __syncthreads();
+      for (int o = tid; o < NH * 2 * BN; o += NT) {
+        const int hw = o / BN, col = o - hw * BN;
+        float mx = -1e30f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) mx = fmaxf(mx, red[((hw * RPP + q) * 4) * BN + col]);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) {
+          const float* e = &red[((hw * RPP + q) * 4) * BN + col];
+          const float sc = __expf(e[0] - mx);
+          a0 += e[BN] * sc; a1 += e[2 * BN] * sc; a2 += e[3 * BN] * sc;
+        }
+        if (n0 + col < p.N) {
+          f32x4 outv = {mx, a0, a1, a2};
+          *reinterpret_cast<f32x4*>(
+              p.pool_partial + (((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col) * 4) = outv;
+        }
+      }
+    }
+  }
+}
 template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2))
 void conv_gemm_kernel(const ConvGemmParams p) {
@@ -351,205 +572,176 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   if (kt_begin < kt_end) compute_tile(buf);
   __syncthreads();
 
-  // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
-  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  if (p.splitk > 1) {
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const int n = n0 + (wn * TN + in) * 32 + li;
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < p.M && n < p.N) p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = acc[im][in][r];
-        }
-    }
-    return;
-  }
-  // Transpose the accumulators through LDS (the staging buffers are free now) so that every lane
-  // finishes 4 consecutive output channels of one row: 16-B global stores, 512 B contiguous per
-  // output row, instead of 4-B stores (which are ~6x slower per byte on gfx950).
-  constexpr int ES = BN + 4;
+  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 fast path (PREC 2, 1x1 layers with K % 64 == 0): K-tile of 64, single binary16 plane per
+// operand, 16-B staging chunks of 8 halfs.  The 3-pass kernel above spends ~770 MFMA cycles per
+// K-tile and wave; one pass leaves 256, far less than an L2 round trip, so this variant doubles the
+// work per barrier and (AF32 = false) reads activations that the producing layer already stored as
+// binary16 (ConvGemmParams::A16): no conversion, half the activation bytes.
+constexpr int FBK = 64;
+constexpr int FHS = FBK + 8;     // halfs per LDS row: 144 B = 36 dwords, the conflict-free stride of
+                                 // the fp32 layout (ds_read_b128) with whole rows per store group
+
+template <int BM, int BN>
+constexpr size_t f16_lds_bytes() {
+  const size_t stage = (size_t)(BM + BN) * FHS * 2;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  const size_t pool = (size_t)BM * 256 * 2;
+  size_t m = 2 * stage > epi ? 2 * stage : epi;
+  return m > pool ? m : pool;
+}
+
+template <int BM, int BN, int WM, int WN, bool AF32>
+__global__ __launch_bounds__(64 * WM * WN, 2)
+void gemm_f16_kernel(const ConvGemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  static_assert(NT == 256, "4 wavefronts");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int SROWS = NT / 8;                  // rows per staging pass (8 chunks of 16 B per row)
+  constexpr int A_IT = BM / SROWS, W_IT = BN / SROWS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int work;
   {
-    float* Es = lds;
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    work = xcd * q + (xcd < r ? xcd : r) + local;
+  }
+  const int tile_m = work / tiles_n;
+  const int tile_n = work - tile_m * tiles_n;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
+  const int c8 = tid & 7, sr = tid >> 3;
+  const int nk = p.K / FBK;
+
+  const uint16_t* a16_ptr[A_IT];
+  const float* a32_ptr[A_IT];
+  int a_inc[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + sr + SROWS * i;
+    const bool ok = m < p.M;
+    if (AF32) a32_ptr[i] = ok ? p.A + (long long)m * p.lda + p.a_off + c8 * 8 : p.zeros;
+    else a16_ptr[i] = ok ? p.A16 + (long long)m * p.lda16 + p.a_off + c8 * 8
+                         : reinterpret_cast<const uint16_t*>(p.zeros);
+    a_inc[i] = ok ? FBK : 0;
+  }
+  const uint16_t* w_ptr[W_IT];
+  int w_inc[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    const int n = n0 + sr + SROWS * i;
+    const bool ok = n < p.N;
+    w_ptr[i] = ok ? p.Wh + (long long)n * p.ldw + c8 * 8 : reinterpret_cast<const uint16_t*>(p.zeros);
+    w_inc[i] = ok ? FBK : 0;
+  }
+  u32x4 ra[A_IT], rw[W_IT];
+  f32x4 rf[AF32 ? A_IT : 1][2];
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      rw[i] = *reinterpret_cast<const u32x4*>(w_ptr[i]);
+      w_ptr[i] += w_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      if (AF32) {
+        rf[i][0] = *reinterpret_cast<const f32x4*>(a32_ptr[i]);
+        rf[i][1] = *reinterpret_cast<const f32x4*>(a32_ptr[i] + 4);
+        a32_ptr[i] += a_inc[i];
+      } else {
+        ra[i] = *reinterpret_cast<const u32x4*>(a16_ptr[i]);
+        a16_ptr[i] += a_inc[i];
+      }
+    }
+  };
+  constexpr int STAGE_HALFS = (BM + BN) * FHS;
+  auto store_tile = [&](int buf) {
+    _Float16* As = reinterpret_cast<_Float16*>(lds) + buf * STAGE_HALFS;
+    _Float16* Ws = As + BM * FHS;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      if (AF32) {
+        f16x8 h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)rf[i][0][q]; h[4 + q] = (_Float16)rf[i][1][q]; }
+        *reinterpret_cast<f16x8*>(&As[(sr + SROWS * i) * FHS + c8 * 8]) = h;
+      } else {
+        *reinterpret_cast<u32x4*>(&As[(sr + SROWS * i) * FHS + c8 * 8]) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i)
+      *reinterpret_cast<u32x4*>(&Ws[(sr + SROWS * i) * FHS + c8 * 8]) = rw[i];
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
 #pragma unroll
     for (int in = 0; in < TN; ++in)
 #pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+  auto compute_tile = [&](int buf) {
+    __builtin_amdgcn_s_setprio(1);
+    const _Float16* As = reinterpret_cast<const _Float16*>(lds) + buf * STAGE_HALFS +
+                         (wm * TM * 32 + li) * FHS + lh * 8;
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(lds) + buf * STAGE_HALFS + BM * FHS +
+                         (wn * TN * 32 + li) * FHS + lh * 8;
+#pragma unroll
+    for (int ks = 0; ks < FBK / 16; ++ks) {
+      f16x8 a[TM], b[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) a[im] = *reinterpret_cast<const f16x8*>(&As[im * 32 * FHS + ks * 16]);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) b[in] = *reinterpret_cast<const f16x8*>(&Ws[in * 32 * FHS + ks * 16]);
+#pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          Es[row * ES + (wn * TN + in) * 32 + li] = acc[im][in][r];
-        }
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[im], b[in], acc[im][in], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
   }
   __syncthreads();
-  {
-    constexpr int C4 = BN / 4;                 // float4 columns per tile row
-    constexpr int RPP = NT / C4;               // rows per pass
-    const int c4 = tid % C4, rr = tid / C4;
-    const int n = n0 + c4 * 4;
-    constexpr int NH = BM / 64;                // 64-row halves (column-sum granularity)
-    f32x4 cs[NH][2];
-#pragma unroll
-    for (int hf = 0; hf < NH; ++hf) cs[hf][0] = cs[hf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // softmax-pooling partials (ASTP fused into the logit GEMM): running max + 3 weighted sums
-    f32x4 pm[NH][2], p0[NH][2], p1[NH][2], p2[NH][2];
-#pragma unroll
-    for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-      for (int wh = 0; wh < 2; ++wh) {
-        pm[hf][wh] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
-        p0[hf][wh] = p1[hf][wh] = p2[hf][wh] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    if (p.pool_partial) {
-      // ASTP fused into the logit GEMM: the logits are never written to HBM.  All h rows of a
-      // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
-      // online-softmax tuples of the (half, image part) groups.
-      if (n < p.N) {
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int hf = 0; hf < NH; ++hf) {
-          const int mh = m0 + hf * 64;
-          const int rb = (mh / HW + 1) * HW - mh;
-          constexpr int RI = 64 / RPP;
-          f32x4 hv[RI];
-#pragma unroll
-          for (int i = 0; i < RI; ++i) {
-            const int m = mh + rr + RPP * i;
-            const int mc = m < p.M ? m : p.M - 1;
-            hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
-          }
-#pragma unroll
-          for (int i = 0; i < RI; ++i) {
-            const int rl = rr + RPP * i;
-            if (mh + rl < p.M) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
-              const bool second = rl >= rb;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float mo = second ? pm[hf][1][q] : pm[hf][0][q];
-                const float mn = fmaxf(mo, v[q]);
-                const float sc = __expf(mo - mn), pe = __expf(v[q] - mn);
-                const float h1 = pe * hv[i][q], h2 = h1 * hv[i][q];
-                if (second) {
-                  pm[hf][1][q] = mn;
-                  p0[hf][1][q] = p0[hf][1][q] * sc + pe;
-                  p1[hf][1][q] = p1[hf][1][q] * sc + h1;
-                  p2[hf][1][q] = p2[hf][1][q] * sc + h2;
-                } else {
-                  pm[hf][0][q] = mn;
-                  p0[hf][0][q] = p0[hf][0][q] * sc + pe;
-                  p1[hf][0][q] = p1[hf][0][q] * sc + h1;
-                  p2[hf][0][q] = p2[hf][0][q] * sc + h2;
-                }
-              }
-            }
-          }
-        }
-      }
-    } else
-    if (n < p.N) {                             // N % 4 == 0 (checked on the host)
-      f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (p.post_scale) {
-        ps = *reinterpret_cast<const f32x4*>(p.post_scale + n);
-        pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
-      }
-      const bool to_d2 = p.D2 && n >= p.d2_col0;
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf) {
-        // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
-        const int mh = m0 + hf * 64;
-        const int rb = (mh / HW + 1) * HW - mh;
-#pragma unroll 4
-        for (int rl = rr; rl < 64; rl += RPP) {
-          const int row = hf * 64 + rl;
-          const int m = m0 + row;
-          if (m >= p.M) break;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
-          if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
-          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
-          if (p.act == ACT_RELU) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-          } else if (p.act == ACT_TANH) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
-          }
-          if (p.post_scale) v = v * ps + pb;
-          if (p.seg_scale) {
-            const int img = m / HW, ox = (m - img * HW) % p.Wout;
-            v *= *reinterpret_cast<const f32x4*>(
-                p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
-          }
-          *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
-          if (to_d2)
-            *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
-          if (p.colsum) {
-            if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
-          }
-        }
-      }
-    }
-    if (p.colsum) {
-      // Deterministic per-(64-row tile, image) column sums of the stored values (SE / statistics
-      // pooling without re-reading the tensor): fold the RPP row phases through LDS, then one
-      // plain store per column -> colsum[(tile64*2 + which)][N].
-      __syncthreads();                                  // everyone is done reading the E tile
-      float* red = lds;                                 // [NH][2][RPP][BN]
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-        for (int wh = 0; wh < 2; ++wh)
-          *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
-      __syncthreads();
-      for (int o = tid; o < NH * 2 * BN; o += NT) {
-        const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
-        float sacc = 0.f;
-#pragma unroll
-        for (int q = 0; q < RPP; ++q) sacc += red[(hw * RPP + q) * BN + col];
-        if (n0 + col < p.N)
-          p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
-      }
-    }
-    if (p.pool_partial) {
-      // fold the RPP row phases: (max, s0, s1, s2) tuples combined with the usual rescaling;
-      // one [4]-tuple per (64-row tile, image part, column) -> pool_partial[tile64*2 + which][N][4]
-      __syncthreads();
-      float* red = lds;                                 // [NH*2][RPP][4][BN]
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-        for (int wh = 0; wh < 2; ++wh) {
-          float* r0p = &red[(((hf * 2 + wh) * RPP + rr) * 4) * BN + c4 * 4];
-          *reinterpret_cast<f32x4*>(r0p) = pm[hf][wh];
-          *reinterpret_cast<f32x4*>(r0p + BN) = p0[hf][wh];
-          *reinterpret_cast<f32x4*>(r0p + 2 * BN) = p1[hf][wh];
-          *reinterpret_cast<f32x4*>(r0p + 3 * BN) = p2[hf][wh];
-        }
-      __syncthreads();
-      for (int o = tid; o < NH * 2 * BN; o += NT) {
-        const int hw = o / BN, col = o - hw * BN;
-        float mx = -1e30f;
-#pragma unroll
-        for (int q = 0; q < RPP; ++q) mx = fmaxf(mx, red[((hw * RPP + q) * 4) * BN + col]);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < RPP; ++q) {
-          const float* e = &red[((hw * RPP + q) * 4) * BN + col];
-          const float sc = __expf(e[0] - mx);
-          a0 += e[BN] * sc; a1 += e[2 * BN] * sc; a2 += e[3 * BN] * sc;
-        }
-        if (n0 + col < p.N) {
-          f32x4 outv = {mx, a0, a1, a2};
-          *reinterpret_cast<f32x4*>(
-              p.pool_partial + (((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col) * 4) = outv;
-        }
-      }
-    }
+  int buf = 0;
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    load_tile();
+    compute_tile(buf);
+    store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
+  if (nk > 0) compute_tile(buf);
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+}
+
+template <int BM, int BN, bool AF32>
+static hipError_t launch_f16_fast(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr size_t lds_bytes = f16_lds_bytes<BM, BN>();
+  static bool attr_set = false;
+  auto kern = gemm_f16_kernel<BM, BN, 2, 2, AF32>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  if (tiles_m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds_bytes, stream, p);
+  return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
@@ -606,6 +798,9 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (p.splitk <= 1 && blocks128 * 2 < slots) return launch_mode<64, 64, 2, 2, PREC>(p, mode, stream);
   }
+  // f16 back-end, plain 1x1 layer: the K-tile-64 kernel (binary16 activations when the producer left them)
+  const bool fast16 = PREC == 2 && mode == 3 && p.splitk <= 1 && p.K % FBK == 0 && p.N > 64 &&
+                      (!p.A16 || (p.lda16 & 7) == 0) && (p.a_off & 7) == 0 && (p.lda & 7) == 0;
   if (p.N <= 32) return launch_mode<128, 32, 4, 1, PREC>(p, mode, stream);
   if (p.N <= 64) return launch_mode<128, 64, 4, 1, PREC>(p, mode, stream);
   // Tail peeling.  128x128 tiles run two per CU; a last partial round of tiles costs a whole tile
@@ -630,9 +825,13 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
 #ifdef WS_EIGHT_WAVES
   hipError_t e = launch_mode<128, 128, 2, 4, PREC>(main, mode, stream);
 #else
-  hipError_t e = launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
+  hipError_t e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
+                                    : launch_f16_fast<128, 128, true>(main, stream))
+                        : launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
 #endif
   if (e != hipSuccess || !peel) return e;
+  if (fast16)
+    return tail.A16 ? launch_f16_fast<64, 64, false>(tail, stream) : launch_f16_fast<64, 64, true>(tail, stream);
   return launch_mode<64, 64, 2, 2, PREC>(tail, mode, stream);
 }
 

@@ -15,6 +15,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 // Conv1d over time is the H=1 case (time on the W axis); a Linear layer is 1x1 with Hout=Wout=1.
 struct ConvGemmParams {
   const float* A;  int lda;  int a_off;       // input rows: lda floats per pixel
+  const uint16_t* A16; int lda16;             // optional binary16 copy of A (same a_off), read instead of A
+                                              // by the f16 back-end on 1x1 layers (no conversion, half the bytes)
   const float* A2; int lda2; int a2_off;      // optional second input, added element-wise to A
   const float* pre_scale; const float* pre_shift;   // optional pre-activation on A (CAM++ BN-ReLU
                                               // before the conv): a = relu(A*pre_scale[ci] + pre_shift[ci]),
@@ -24,6 +26,7 @@ struct ConvGemmParams {
   int prec;                                   // 0: v_mfma_f32_32x32x2_f32 (exact fp32)
                                               // 1: 3 x v_mfma_f32_32x32x16_f16 on hi/lo splits
   float* D;  int ldd;  int d_off;             // output rows
+  uint16_t* D16; int ldd16;                   // optional binary16 copy of the stored values: D16[m][d_off + n]
   float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
   int M, N, K;                                // M output pixels, N output channels, K = taps*Cin
   int m_begin;                                // first output pixel of this launch (multiple of 64;
