@@ -139,6 +139,64 @@ def test_ecapa_f16x3_split_precision_matches_oracle(name, golden_dir):
     assert np.array_equal(back, exact)
 
 
+F16_REL_TOL = 5e-3      # binary16 operands (11-bit significand): ~5e-4 measured on the embeddings
+
+
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512", "ECAPA_TDNN_GLOB_c1024",
+                                  "ECAPA_TDNN_c1024"])
+def test_ecapa_f16_backend_meets_the_cosine_bar(name, golden_dir):
+    """WS_PREC_F16 (binary16 MFMA operands, fp32 accumulation, binary16 activation copies between
+    the 1x1 layers): the north-star bar 1 - cos <= 1e-4 against the oracle AND the reference golden,
+    at the golden shapes, ragged lengths (K-tile-64 kernel tails, T < 64 fallbacks) and scales."""
+    sd, model = _engine(name)
+    model.set_precision("f16")
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(3)])
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    ref = oecapa.ecapa_forward(sd, feats).numpy()
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < F16_REL_TOL
+    g = np.load(os.path.join(golden_dir, "ecapa_ref.npz"))
+    assert _cos_err(got[:2], g[name + "/emb"]).max() < COS_TOL
+    assert _rel_err(got[:2], g[name + "/emb"]).max() < F16_REL_TOL
+    for T in (5, 57, 64, 201, 333):
+        f = np.random.RandomState(T).randn(3, T, 80).astype(np.float32)
+        e = model(torch.from_numpy(f))[-1].cpu().numpy()
+        r = oecapa.ecapa_forward(sd, f).numpy()
+        assert _cos_err(e, r).max() < COS_TOL and _rel_err(e, r).max() < F16_REL_TOL, T
+    for scale in (1e-2, 30.0):
+        f = (np.random.RandomState(7).randn(2, 100, 80) * scale).astype(np.float32)
+        e = model(torch.from_numpy(f))[-1].cpu().numpy()
+        r = oecapa.ecapa_forward(sd, f).numpy()
+        assert _cos_err(e, r).max() < COS_TOL and _rel_err(e, r).max() < F16_REL_TOL, scale
+    # batch invariance: row tiles never mix utterances, but the position of an utterance inside the
+    # 64-row tiles moves the fp32 summation order of the SE / context statistics by ~1e-7, which a
+    # binary16 rounding downstream can turn into one half-ulp (5e-4) on single activations
+    one = model(torch.from_numpy(feats[1:2]))[-1].cpu().numpy()
+    assert _rel_err(one, got[1:2]).max() < F16_REL_TOL
+
+
+def test_resnet_and_campplus_f16_backend_meet_the_cosine_bar(golden_dir):
+    from oracle import campplus as ocam
+    from oracle import resnet as oresnet
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    sd = synth.synth_resnet_state_dict("ResNet34", 80, 256, seed=42)
+    model = _native("ResNet34", sd, 256)
+    model.set_precision("f16")
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    ref = oresnet.resnet_forward(sd, feats, "ResNet34").numpy()
+    assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < F16_REL_TOL
+    g = np.load(os.path.join(golden_dir, "resnet_ref.npz"))
+    assert _cos_err(got, g["ResNet34/emb"]).max() < COS_TOL
+    sd = synth.synth_campplus_state_dict(80, 512, seed=42)
+    model = _native("CAMPPlus", sd, 512, max_batch=4, max_frames=400)
+    model.set_precision("f16")
+    got = model(torch.from_numpy(feats)).cpu().numpy()
+    ref = ocam.campplus_forward(sd, feats).numpy()
+    assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < F16_REL_TOL
+    g = np.load(os.path.join(golden_dir, "campplus_ref.npz"))
+    assert _cos_err(got, g["emb"]).max() < COS_TOL
+
+
 def test_ecapa_emb_bn_and_shapes(golden_dir):
     sd, model = _engine("ECAPA_TDNN_c512", embed_dim=256, seed=5, emb_bn=True)
     feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])

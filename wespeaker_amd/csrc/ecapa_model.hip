@@ -27,6 +27,7 @@ struct EcapaModel : ModelBase {
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
         *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
+  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr;
   static constexpr int kSplitK = 16;
 
   EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
@@ -105,6 +106,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
+           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128) + 1) / 2),   // binary16 copies (f16 back-end)
            o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
@@ -112,12 +114,21 @@ struct EcapaModel : ModelBase {
     h = base + o_h; att = base + o_att; e = base + o_e; se_s = base + o_s; stats = base + o_stats;
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
     colsum = base + o_colsum; feats_ws = base + o_feats;
+    h16 = reinterpret_cast<uint16_t*>(base + o_h16);
+    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C;
     return 0;
   }
 
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
     // layer1: Conv1d(F -> C, k5, p2) -> ReLU -> BN
-    WS_LAUNCH(gemm(conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU), st));
+    // f16 back-end: the layers that feed 1x1 GEMMs also leave a binary16 copy of their output, which
+    // those GEMMs read instead of the fp32 tensor (half the bytes, no conversion while staging)
+    const bool f16io = gemm_precision == 2;
+    {
+      ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
+      if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
+      WS_LAUNCH(gemm(p0, st));
+    }
     for (int L = 0; L < 3; ++L) {
       const int d = L + 2;
       const float* x = L == 0 ? out1 : cat;
@@ -126,6 +137,7 @@ struct EcapaModel : ModelBase {
       // 1x1 conv -> ReLU -> BN; the last Res2 split is passed through untouched: dual store
       ConvGemmParams p = conv1d(blk0[L], x, ldx, x_off, y1, C, 0, B, T, 1, ACT_RELU);
       p.D2 = y2; p.ldd2 = C; p.d2_off = 7 * w; p.d2_col0 = 7 * w;
+      if (f16io) { p.A16 = L == 0 ? out1_16 : cat16; p.lda16 = ldx; }
       WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
       if (res2_chain_supported(w, T, d)) {       // one launch, running activation kept in LDS
@@ -167,7 +179,8 @@ struct EcapaModel : ModelBase {
         }));
       }
       WS_LAUNCH(other(3 * mc, st, [&] {
-        return launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st);
+        return launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st,
+                                        f16io ? cat16 : nullptr);
       }));
     }
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
@@ -176,11 +189,13 @@ struct EcapaModel : ModelBase {
     {
       ConvGemmParams pc = conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU);
       if (stats_from_colsum) pc.colsum = colsum;
+      if (f16io) { pc.A16 = cat16; pc.lda16 = 3 * C; pc.D16 = h16; pc.ldd16 = 1536; }
       WS_LAUNCH(gemm(pc, st));
     }
     // ASTP
     ConvGemmParams a1 = conv1d(pool1, h, 1536, 0, att, 128, 0, B, T, 1, ACT_TANH);
     a1.K = 1536; a1.Cin = 1536;                      // GLOB: only the first 1536 columns multiply h
+    if (f16io) { a1.A16 = h16; a1.lda16 = 1536; a1.D16 = att16; a1.ldd16 = 128; }
     if (glob) {
       // [mean; std] statistics, then bias_img = W1[:, C:3C] [mean; std] + b1 as a split-K GEMM
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
@@ -199,6 +214,7 @@ struct EcapaModel : ModelBase {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
       ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
       l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer
+      if (f16io) { l2.A16 = att16; l2.lda16 = 128; }
       WS_LAUNCH(gemm(l2, st));
       WS_LAUNCH(other(0.0, st, [&] {
         return launch_astp_pool_from_partials(e, B, T, 1536, pooled, st);

@@ -164,7 +164,7 @@ hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, co
 __global__ __launch_bounds__(256) void se_scale_residual_kernel(
     const float* __restrict__ x, int ldx, int x_off, const float* __restrict__ y, int ldy,
     const float* __restrict__ s, float* __restrict__ out, int ldo, int o_off, int T, int C,
-    long long total4) {
+    long long total4, uint16_t* __restrict__ out16) {
   const int cols4 = C >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4;
        i += (long long)gridDim.x * 256) {
@@ -174,18 +174,26 @@ __global__ __launch_bounds__(256) void se_scale_residual_kernel(
     f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * ldx + x_off + c);
     f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ldy + c);
     f32x4 sv = *reinterpret_cast<const f32x4*>(s + (long long)b * C + c);
-    *reinterpret_cast<f32x4*>(out + m * ldo + o_off + c) = xv + yv * sv;
+    const f32x4 v = xv + yv * sv;
+    *reinterpret_cast<f32x4*>(out + m * ldo + o_off + c) = v;
+    if (out16) {                                   // binary16 copy for the f16 GEMM back-end
+      typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+      f16x4e hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+      *reinterpret_cast<f16x4e*>(out16 + m * ldo + o_off + c) = hv;
+    }
   }
 }
 
 hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
                                     const float* s, float* out, int ldo, int o_off, int B, int T,
-                                    int C, hipStream_t stream) {
+                                    int C, hipStream_t stream, uint16_t* out16) {
   const long long total4 = (long long)B * T * (C >> 2);
   long long blocks = (total4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx,
-                     x_off, y, ldy, s, out, ldo, o_off, T, C, total4);
+                     x_off, y, ldy, s, out, ldo, o_off, T, C, total4, out16);
   return hipGetLastError();
 }
 

@@ -84,7 +84,7 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
 // out[m][o_off + c] = x[m][x_off + c] + y[m][c] * s[b][c]      (SE scale + residual)
 hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
                                     const float* s, float* out, int ldo, int o_off, int B, int T,
-                                    int C, hipStream_t stream);
+                                    int C, hipStream_t stream, uint16_t* out16 = nullptr);
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
