@@ -8,6 +8,9 @@
 #include <vector>
 #include "../wespeaker_amd/csrc/kernels.h"
 using namespace wsamd;
+#ifdef WS_TRACE
+namespace wsamd { unsigned long long* trace_buffer_address(); }
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -102,6 +105,17 @@ int main(int argc, char** argv) {
         if (e > max_err) max_err = e;
       }
     }
+#ifdef WS_TRACE
+    if (s.K == 1536 && s.N == 1536) {
+      unsigned long long tr[64 * 8];
+      CK(hipMemcpy(tr, trace_buffer_address(), sizeof(tr), hipMemcpyDeviceToHost));
+      for (int k = 2; k < 12; ++k) {
+        printf("  it %2d:", k);
+        for (int j = 1; j < 6; ++j) printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));
+        printf("  | loop %6lld\n", (long long)(tr[(k + 1) * 8] - tr[k * 8]));
+      }
+    }
+#endif
     printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e\n", s.name, s.M, s.N, s.K,
            s.taps, us, tf, max_err);
   }

@@ -585,6 +585,20 @@ constexpr int FBK = 64;
 constexpr int FHS = FBK + 8;     // halfs per LDS row: 144 B = 36 dwords, the conflict-free stride of
                                  // the fp32 layout (ds_read_b128) with whole rows per store group
 
+#ifdef WS_TRACE
+// phase stamps (s_memtime) of wavefront 0 of workgroup 0: [iteration][6]
+__device__ unsigned long long g_trace[64 * 8];
+unsigned long long* trace_buffer_address() {
+  unsigned long long* p = nullptr;
+  (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_trace));
+  return p;
+}
+#define WS_STAMP(slot)                                                              \
+  if (blockIdx.x == 8 && tid == 0 && kt < 64) g_trace[kt * 8 + (slot)] = __builtin_readcyclecounter();
+#else
+#define WS_STAMP(slot)
+#endif
+
 template <int BM, int BN>
 constexpr size_t f16_lds_bytes() {
   const size_t stage = (size_t)(BM + BN) * FHS * 2;
@@ -716,15 +730,202 @@ void gemm_f16_kernel(const ConvGemmParams p) {
   __syncthreads();
   int buf = 0;
   for (int kt = 0; kt + 1 < nk; ++kt) {
+    WS_STAMP(0)
     load_tile();
+    WS_STAMP(1)
     compute_tile(buf);
+    WS_STAMP(2)
+#ifdef WS_TRACE
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) only (lgkmcnt/expcnt untouched)
+    WS_STAMP(3)
+#endif
     store_tile(buf ^ 1);
+    WS_STAMP(4)
     __syncthreads();
+    WS_STAMP(5)
     buf ^= 1;
   }
   if (nk > 0) compute_tile(buf);
   __syncthreads();
   gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 path with LDS-DMA staging (`global_load_lds_dwordx4`): both operands are binary16 in HBM, so
+// no register round trip, no conversion and -- the point -- no ds_write: s_memtime stamps on the
+// register-staged kernel above show each K-tile spending ~900 of ~3300 cycles ISSUING its eight
+// ds_write_b128 (the VGPR->LDS transfer path, MI355X_MICROARCH.md) and another ~900 waiting for
+// loads behind them.  A DMA instruction fills 1 KiB of LDS lane-linearly, so the tile is stored
+// unpadded ([rows][BKT] halfs) and the bank spread comes from an XOR swizzle of the 16-B chunk index
+// applied on the SOURCE address and again on the fragment reads: chunk ^= (row >> s) & (CH - 1),
+// s = 1 for 128-B rows (CH = 8), 2 for 64-B rows (CH = 4) -- conflict-free for every ds_read_b128
+// lane group {0-3,12-15,20-27}, ...  NSTAGE LDS stages keep NSTAGE-1 K-tiles in flight across the
+// per-tile barrier (counted vmcnt, raw s_barrier: __syncthreads would drain the queue).
+template <int BM, int BN, int BKT, int NSTAGE>
+constexpr size_t f16_dma_lds_bytes() {
+  const size_t stages = (size_t)NSTAGE * (BM + BN) * BKT * 2;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  const size_t pool = (size_t)BM * 256 * 2;
+  size_t m = stages > epi ? stages : epi;
+  return m > pool ? m : pool;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // vmcnt(N) then barrier; "memory" keeps LDS accesses on their side of it
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes at g land at lds_base + 16 l (lds_base wave-uniform)
+__device__ __forceinline__ void dma_16B(const void* g, void* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+#endif
+}
+
+template <int BM, int BN, int BKT, int NSTAGE>
+__global__ __launch_bounds__(256, 2)
+void gemm_f16_dma_kernel(const ConvGemmParams p) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int CH = BKT / 8;                    // 16-B chunks per row
+  constexpr int RPD = 64 / CH;                   // rows covered by one 1-KiB DMA instruction
+  constexpr int SWS = CH == 8 ? 1 : 2;           // swizzle key = (row >> SWS) & (CH - 1)
+  constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_DMA = A_BYTES / 1024 / 4, W_DMA = W_BYTES / 1024 / 4;   // per wavefront and K-tile
+  constexpr int LPT = A_DMA + W_DMA;
+  constexpr int D = NSTAGE - 1;                  // K-tiles in flight
+  static_assert(A_DMA >= 1 && W_DMA >= 1 && (CH == 8 || CH == 4), "tile / K-tile combination");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int work;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    work = xcd * q + (xcd < r ? xcd : r) + local;
+  }
+  const int tile_m = work / tiles_n;
+  const int tile_n = work - tile_m * tiles_n;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = p.K / BKT;
+
+  // per-lane DMA sources: slot (row rr, physical chunk pc) of a 1-KiB piece <- logical chunk pc ^ key(row)
+  const uint16_t* a_src[A_DMA];
+  const uint16_t* w_src[W_DMA];
+  int a_inc[A_DMA], w_inc[W_DMA];
+  {
+    const int rr = lane / CH, pc = lane % CH;
+#pragma unroll
+    for (int j = 0; j < A_DMA; ++j) {
+      const int row = (wave * A_DMA + j) * RPD + rr;
+      const int c = pc ^ ((row >> SWS) & (CH - 1));
+      const bool ok = m0 + row < p.M;
+      a_src[j] = ok ? p.A16 + (long long)(m0 + row) * p.lda16 + p.a_off + c * 8
+                    : reinterpret_cast<const uint16_t*>(p.zeros);
+      a_inc[j] = ok ? BKT : 0;
+
+    }
+#pragma unroll
+    for (int j = 0; j < W_DMA; ++j) {
+      const int row = (wave * W_DMA + j) * RPD + rr;
+      const int c = pc ^ ((row >> SWS) & (CH - 1));
+      const bool ok = n0 + row < p.N;
+      w_src[j] = ok ? p.Wh + (long long)(n0 + row) * p.ldw + c * 8
+                    : reinterpret_cast<const uint16_t*>(p.zeros);
+      w_inc[j] = ok ? BKT : 0;
+
+    }
+  }
+  auto issue = [&](int stage) {
+    char* base = ldsb + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_DMA; ++j) {
+      dma_16B(a_src[j], base + (wave * A_DMA + j) * 1024);
+      a_src[j] += a_inc[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W_DMA; ++j) {
+      dma_16B(w_src[j], base + A_BYTES + (wave * W_DMA + j) * 1024);
+      w_src[j] += w_inc[j];
+    }
+  };
+
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int sw = (li >> SWS) & (CH - 1);
+  int koff[BKT / 16];
+#pragma unroll
+  for (int ks = 0; ks < BKT / 16; ++ks) koff[ks] = (((ks << 1) | lh) ^ sw) << 3;   // halfs
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+  auto compute_tile = [&](int stage) {
+    const _Float16* As = reinterpret_cast<const _Float16*>(ldsb + stage * STAGE_BYTES) +
+                         (wm * TM * 32 + li) * BKT;
+    const _Float16* Ws = reinterpret_cast<const _Float16*>(ldsb + stage * STAGE_BYTES + A_BYTES) +
+                         (wn * TN * 32 + li) * BKT;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      f16x8 a[TM], b[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) a[im] = *reinterpret_cast<const f16x8*>(&As[im * 32 * BKT + koff[ks]]);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) b[in] = *reinterpret_cast<const f16x8*>(&Ws[in * 32 * BKT + koff[ks]]);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[im], b[in], acc[im][in], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: D tiles in flight, tile 0 landed
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s);
+  if (nk >= D) wait_vmcnt_barrier<LPT*(D - 1)>();
+  else wait_vmcnt_barrier<0>();
+  int st_c = 0, st_i = D % NSTAGE;              // stage computed on / stage the next issue fills
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + D < nk;
+    if (more) issue(st_i);
+    compute_tile(st_c);
+    // tile kt+1 must have landed in every wavefront before anyone reads it; tiles kt+2.. stay in flight
+    if (more) wait_vmcnt_barrier<LPT*(D - 1)>();
+    else wait_vmcnt_barrier<0>();
+    st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+    st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+  }
+  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+}
+
+template <int BM, int BN, int BKT, int NSTAGE>
+static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr size_t lds_bytes = f16_dma_lds_bytes<BM, BN, BKT, NSTAGE>();
+  static bool attr_set = false;
+  auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  if (tiles_m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds_bytes, stream, p);
+  return hipGetLastError();
 }
 
 template <int BM, int BN, bool AF32>
@@ -825,11 +1026,19 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
 #ifdef WS_EIGHT_WAVES
   hipError_t e = launch_mode<128, 128, 2, 4, PREC>(main, mode, stream);
 #else
-  hipError_t e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
-                                    : launch_f16_fast<128, 128, true>(main, stream))
-                        : launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
+  static int dma = -1;
+  if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
+  const bool use_dma = fast16 && p.A16 && dma;
+  hipError_t e;
+  if (use_dma)
+    e = launch_f16_dma<128, 128, 64, 2>(main, stream);   // (4 stages of K-tile 32: measured 5 % slower)
+  else
+    e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
+                           : launch_f16_fast<128, 128, true>(main, stream))
+               : launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
 #endif
   if (e != hipSuccess || !peel) return e;
+  if (use_dma) return launch_f16_dma<64, 64, 64, 2>(tail, stream);
   if (fast16)
     return tail.A16 ? launch_f16_fast<64, 64, false>(tail, stream) : launch_f16_fast<64, 64, true>(tail, stream);
   return launch_mode<64, 64, 2, 2, PREC>(tail, mode, stream);
