@@ -210,8 +210,15 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
             for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
             *reinterpret_cast<f16x4*>(p.D16 + (long long)m * p.ldd16 + p.d_off + n) = hv;
           }
-          if (to_d2)
+          if (to_d2) {
             *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
+            if (p.D2_16) {
+              f16x4 hv;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+              *reinterpret_cast<f16x4*>(p.D2_16 + (long long)m * p.ldd2_16 + p.d2_off + (n - p.d2_col0)) = hv;
+            }
+          }
           if (p.colsum) {
             if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
           }
@@ -993,15 +1000,23 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots = 2 * cus;
   }
+  // f16 back-end, plain 1x1 layer: the K-tile-64 kernels (binary16 activations when the producer left
+  // them -- then the fp32 tensor may not even exist, so every tile size must take this route)
+  const bool fast16 = PREC == 2 && mode == 3 && p.splitk <= 1 && p.K % FBK == 0 && p.N > 64 &&
+                      (!p.A16 || (p.lda16 & 7) == 0) && (p.a_off & 7) == 0 && (p.lda & 7) == 0;
+  static int dma = -1;
+  if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
+  const bool use_dma = fast16 && p.A16 && dma;
   // Small problems (fewer 128-row tiles than half the chip's block slots): 64x64 tiles put 2-4x
   // more workgroups in flight (CAM++'s dense layers are [B*T/2 x 32..128] GEMMs).
   {
     const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (p.splitk <= 1 && blocks128 * 2 < slots) return launch_mode<64, 64, 2, 2, PREC>(p, mode, stream);
+    if (p.splitk <= 1 && blocks128 * 2 < slots) {
+      if (use_dma) return launch_f16_dma<64, 64, 64, 2>(p, stream);
+      if (fast16) return p.A16 ? launch_f16_fast<64, 64, false>(p, stream) : launch_f16_fast<64, 64, true>(p, stream);
+      return launch_mode<64, 64, 2, 2, PREC>(p, mode, stream);
+    }
   }
-  // f16 back-end, plain 1x1 layer: the K-tile-64 kernel (binary16 activations when the producer left them)
-  const bool fast16 = PREC == 2 && mode == 3 && p.splitk <= 1 && p.K % FBK == 0 && p.N > 64 &&
-                      (!p.A16 || (p.lda16 & 7) == 0) && (p.a_off & 7) == 0 && (p.lda & 7) == 0;
   if (p.N <= 32) return launch_mode<128, 32, 4, 1, PREC>(p, mode, stream);
   if (p.N <= 64) return launch_mode<128, 64, 4, 1, PREC>(p, mode, stream);
   // Tail peeling.  128x128 tiles run two per CU; a last partial round of tiles costs a whole tile
@@ -1026,9 +1041,6 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
 #ifdef WS_EIGHT_WAVES
   hipError_t e = launch_mode<128, 128, 2, 4, PREC>(main, mode, stream);
 #else
-  static int dma = -1;
-  if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
-  const bool use_dma = fast16 && p.A16 && dma;
   hipError_t e;
   if (use_dma)
     e = launch_f16_dma<128, 128, 64, 2>(main, stream);   // (4 stages of K-tile 32: measured 5 % slower)

@@ -27,7 +27,7 @@ struct EcapaModel : ModelBase {
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
         *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
-  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr;
+  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr;
   static constexpr int kSplitK = 16;
 
   EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
@@ -106,7 +106,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
-           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128) + 1) / 2),   // binary16 copies (f16 back-end)
+           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C) + 1) / 2),   // binary16 copies (f16 back-end)
            o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
@@ -115,7 +115,7 @@ struct EcapaModel : ModelBase {
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
     colsum = base + o_colsum; feats_ws = base + o_feats;
     h16 = reinterpret_cast<uint16_t*>(base + o_h16);
-    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C;
+    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128;
     return 0;
   }
 
@@ -137,7 +137,10 @@ struct EcapaModel : ModelBase {
       // 1x1 conv -> ReLU -> BN; the last Res2 split is passed through untouched: dual store
       ConvGemmParams p = conv1d(blk0[L], x, ldx, x_off, y1, C, 0, B, T, 1, ACT_RELU);
       p.D2 = y2; p.ldd2 = C; p.d2_off = 7 * w; p.d2_col0 = 7 * w;
+      // f16 back-end + fused Res2 chain: y2 exists only as binary16 (conv3 reads it by LDS-DMA)
+      const bool y2_half = f16io && res2_half_out_supported(w, T, d);
       if (f16io) { p.A16 = L == 0 ? out1_16 : cat16; p.lda16 = ldx; }
+      if (y2_half) { p.D2_16 = y2_16; p.ldd2_16 = C; }
       WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
       if (res2_chain_supported(w, T, d)) {       // one launch, running activation kept in LDS
@@ -150,6 +153,7 @@ struct EcapaModel : ModelBase {
           r.scale[i] = arena.at(res2[L][i].scale); r.shift[i] = arena.at(res2[L][i].shift);
         }
         r.B = B; r.T = T; r.W = w; r.dil = d; r.prec = gemm_precision;
+        r.y2h = y2_half ? y2_16 : nullptr; r.ldy2h = C;
         if (prof.enabled) prof.begin(1, 2.0 * B * (double)T * w * 3 * w * 7, 4.0 * B * (double)T * C * 2, st);
         hipError_t re = launch_res2_chain(r, st);
         prof.end(st);
@@ -163,6 +167,7 @@ struct EcapaModel : ModelBase {
       }
       const double mc = 4.0 * B * (double)T * C;
       ConvGemmParams p3 = conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU);
+      if (y2_half) { p3.A16 = y2_16; p3.lda16 = C; }
       if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;

@@ -27,7 +27,8 @@ struct ConvGemmParams {
                                               // 1: 3 x v_mfma_f32_32x32x16_f16 on hi/lo splits
   float* D;  int ldd;  int d_off;             // output rows
   uint16_t* D16; int ldd16;                   // optional binary16 copy of the stored values: D16[m][d_off + n]
-  float* D2; int ldd2; int d2_off; int d2_col0;  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
+  float* D2; int ldd2; int d2_off; int d2_col0;
+  uint16_t* D2_16; int ldd2_16;               // optional binary16 twin of D2 (same d2_off / d2_col0)  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
   int M, N, K;                                // M output pixels, N output channels, K = taps*Cin
   int m_begin;                                // first output pixel of this launch (multiple of 64;
                                               // used by the launcher's tail peeling)
@@ -63,6 +64,8 @@ hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
 struct Res2ChainParams {
   const float* y1; int ldy1;
   float* y2; int ldy2;
+  uint16_t* y2h; int ldy2h;                 // optional: write the splits as binary16 HERE INSTEAD of y2
+                                            // (f16 back-end: the following 1x1 conv reads them by LDS-DMA)
   const float* w[7]; int ldw;               // packed [W][tap*W + ci], ldw = 3W
   const uint16_t* wh[7]; const uint16_t* wl[7];   // hi / lo binary16 planes of w (prec == 1)
   const float* bias[7]; const float* scale[7]; const float* shift[7];
@@ -70,6 +73,7 @@ struct Res2ChainParams {
   int prec;                                 // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
 };
 bool res2_chain_supported(int W, int T, int dil);
+bool res2_half_out_supported(int W, int T, int dil);   // Res2ChainParams::y2h allowed
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
 
 // SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 64 rows):

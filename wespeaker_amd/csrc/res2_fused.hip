@@ -160,6 +160,10 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   const int rows_total = MW * MTW * 16 + 2 * d;
   _Float16* Xh = Xs;
   _Float16* Xl = Xs + rows_total * XS;
+  // binary16 output staging [T][W] (only when p.y2h is set): the step results leave the chip as
+  // coalesced 16-B stores of halfs instead of 4*MTW scalar 4-B stores per lane
+  _Float16* Y16 = Xs + 2 * rows_total * XS;
+  const bool half_out = p.y2h != nullptr;
   const long long m_base = (long long)b * T;
 
   for (int i = tid * 8; i < 2 * rows_total * XS; i += 512 * 8)
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
         const int t = t0 + mt * 16 + r;
         if (t < T) {
           const float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
-          y2u[(mt * 16 + r) * ld2] = v;
+          if (half_out) Y16[t * W + co] = (_Float16)v;
+          else y2u[(mt * 16 + r) * ld2] = v;
           if (step < 6) {
             const float x = v + (PF ? y1n[PF ? mt : 0][r] : y1e[(mt * 16 + r) * ld1]);
             const _Float16 h = (_Float16)x;
@@ -278,13 +283,24 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
       }
     }
     __syncthreads();
+    if (half_out) {
+      // (the next write to Y16 happens after the next step's mid barrier, i.e. after this copy)
+      constexpr int C8 = W / 8;
+      uint16_t* dst = p.y2h + m_base * p.ldy2h + step * W;
+      for (int i = tid; i < T * C8; i += 512) {
+        const int t = i / C8, c = (i - t * C8) * 8;
+        *reinterpret_cast<f16x8*>(dst + (long long)t * p.ldy2h + c) =
+            *reinterpret_cast<const f16x8*>(&Y16[t * W + c]);
+      }
+    }
   }
 }
 
 template <int W, int MTW>
 static hipError_t launch_res2_f16_variant(const Res2ChainParams& p, hipStream_t stream) {
   constexpr int MW = 8 / (W / 16);
-  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16);
+  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
+                     (p.y2h ? (size_t)p.T * W * sizeof(_Float16) : 0);
   auto kern = res2_chain_f16x3_kernel<W, MTW>;
   static size_t attr_bytes = 0;
   if (lds > attr_bytes) {
@@ -313,6 +329,15 @@ static hipError_t launch_res2_variant(const Res2ChainParams& p, hipStream_t stre
   return hipGetLastError();
 }
 
+// binary16 output staging ([T][W] halfs on top of the hi/lo activation planes) must fit the 160 KB LDS
+bool res2_half_out_supported(int W, int T, int dil) {
+  if (!res2_chain_supported(W, T, dil)) return false;
+  const int mtw = W == 64 ? (T <= 2 * 7 * 16 ? 7 : 13) : 13;
+  const int mw = 8 / (W / 16);
+  const size_t lds = (size_t)(mw * mtw * 16 + 2 * dil) * (W + 16) * 2 * 2 + (size_t)T * W * 2;
+  return lds <= 160 * 1024;
+}
+
 bool res2_chain_supported(int W, int T, int dil) {
   if (W == 64) return T <= 2 * 13 * 16 && (size_t)(2 * 13 * 16 + 2 * dil) * 72 * 4 <= 160 * 1024;
   if (W == 128) return T <= 13 * 16;
@@ -322,6 +347,7 @@ bool res2_chain_supported(int W, int T, int dil) {
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
+  if (p.y2h && (p.prec < 1 || (p.ldy2h & 7))) return hipErrorInvalidValue;
   if (p.prec >= 1) {   // (the f16 mode reuses the split kernel: more precise, same launch count)
     if (p.W == 64) {
       if (p.T <= 2 * 7 * 16) return launch_res2_f16_variant<64, 7>(p, stream);
