@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
             v *= *reinterpret_cast<const f32x4*>(
                 p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
           }
-          *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
+          if (p.D) *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
           if (p.D16) {
             f16x4 hv;
 #pragma unroll

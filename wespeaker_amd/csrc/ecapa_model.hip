@@ -27,7 +27,7 @@ struct EcapaModel : ModelBase {
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
         *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
-  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr;
+  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr, *y3_16 = nullptr;
   static constexpr int kSplitK = 16;
 
   EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
@@ -106,7 +106,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
-           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C) + 1) / 2),   // binary16 copies (f16 back-end)
+           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C + C) + 1) / 2),   // binary16 copies (f16 back-end)
            o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
@@ -115,7 +115,7 @@ struct EcapaModel : ModelBase {
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
     colsum = base + o_colsum; feats_ws = base + o_feats;
     h16 = reinterpret_cast<uint16_t*>(base + o_h16);
-    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128;
+    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128; y3_16 = y2_16 + M * C;
     return 0;
   }
 
@@ -124,9 +124,13 @@ struct EcapaModel : ModelBase {
     // f16 back-end: the layers that feed 1x1 GEMMs also leave a binary16 copy of their output, which
     // those GEMMs read instead of the fp32 tensor (half the bytes, no conversion while staging)
     const bool f16io = gemm_precision == 2;
+    // ... and with T >= 64 (SE statistics from the epilogue) the block chain out1 -> y3 -> cat lives in
+    // binary16 only: the residual stream is rounded once per block like in any fp16 inference engine
+    const bool allf16 = f16io && T >= 64;
     {
       ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
       if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
+      if (allf16) p0.D = nullptr;
       WS_LAUNCH(gemm(p0, st));
     }
     for (int L = 0; L < 3; ++L) {
@@ -168,6 +172,7 @@ struct EcapaModel : ModelBase {
       const double mc = 4.0 * B * (double)T * C;
       ConvGemmParams p3 = conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU);
       if (y2_half) { p3.A16 = y2_16; p3.lda16 = C; }
+      if (allf16) { p3.D = nullptr; p3.D16 = y3_16; p3.ldd16 = C; }
       if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;
@@ -183,7 +188,10 @@ struct EcapaModel : ModelBase {
                                    arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
         }));
       }
-      WS_LAUNCH(other(3 * mc, st, [&] {
+      WS_LAUNCH(other(allf16 ? 1.5 * mc : 3 * mc, st, [&] {
+        if (allf16)
+          return launch_se_scale_residual_f16(L == 0 ? out1_16 : cat16, ldx, x_off, y3_16, C, se_s, cat16,
+                                              3 * C, L * C, B, T, C, st);
         return launch_se_scale_residual(x, ldx, x_off, y3, C, se_s, cat, 3 * C, L * C, B, T, C, st,
                                         f16io ? cat16 : nullptr);
       }));

@@ -25,7 +25,7 @@ struct ConvGemmParams {
   const uint16_t* Wh; const uint16_t* Wl;     // hi / lo binary16 planes of W (same layout), prec == 1
   int prec;                                   // 0: v_mfma_f32_32x32x2_f32 (exact fp32)
                                               // 1: 3 x v_mfma_f32_32x32x16_f16 on hi/lo splits
-  float* D;  int ldd;  int d_off;             // output rows
+  float* D;  int ldd;  int d_off;             // output rows (may be null when only D16 is wanted)
   uint16_t* D16; int ldd16;                   // optional binary16 copy of the stored values: D16[m][d_off + n]
   float* D2; int ldd2; int d2_off; int d2_col0;
   uint16_t* D2_16; int ldd2_16;               // optional binary16 twin of D2 (same d2_off / d2_col0)  // optional: columns n >= d2_col0 also go to D2[m][d2_off + n - d2_col0]
@@ -86,6 +86,10 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
                              const float* b1, const float* w2, const float* b2, int bottleneck,
                              float* s, hipStream_t stream);
 // out[m][o_off + c] = x[m][x_off + c] + y[m][c] * s[b][c]      (SE scale + residual)
+// all-binary16 form (f16 back-end): out16 = x16 + y16 * s, 8 halfs per thread
+hipError_t launch_se_scale_residual_f16(const uint16_t* x16, int ldx, int x_off, const uint16_t* y16,
+                                        int ldy, const float* s, uint16_t* out16, int ldo, int o_off,
+                                        int B, int T, int C, hipStream_t stream);
 hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
                                     const float* s, float* out, int ldo, int o_off, int B, int T,
                                     int C, hipStream_t stream, uint16_t* out16 = nullptr);
