@@ -138,7 +138,13 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           for (int i = 0; i < RI; ++i) {
             const int m = mh + rr + RPP * i;
             const int mc = m < p.M ? m : p.M - 1;
-            hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+            if (p.pool_h16) {
+              const f16x4 h4 = *reinterpret_cast<const f16x4*>(p.pool_h16 + (long long)mc * p.ldh + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) hv[i][q] = (float)h4[q];
+            } else {
+              hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+            }
           }
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
@@ -1066,7 +1072,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.residual && ((p.ldr | p.r_off) & 3)) return hipErrorInvalidValue;
   if (p.pre_scale && p.A2) return hipErrorInvalidValue;
   if (p.colsum && (p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
-  if (p.pool_partial && (p.splitk > 1 || p.Hout * p.Wout < 64 || !p.pool_h || (p.ldh & 3)))
+  if (p.pool_partial && (p.splitk > 1 || p.Hout * p.Wout < 64 || (!p.pool_h && !p.pool_h16) || (p.ldh & 3)))
     return hipErrorInvalidValue;
   if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.prec == 1) {

@@ -199,10 +199,13 @@ struct EcapaModel : ModelBase {
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
     // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
     const bool stats_from_colsum = glob && T >= 64;
+    static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
+    const bool h_half = allf16 && !no_fuse;
     {
       ConvGemmParams pc = conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU);
       if (stats_from_colsum) pc.colsum = colsum;
       if (f16io) { pc.A16 = cat16; pc.lda16 = 3 * C; pc.D16 = h16; pc.ldd16 = 1536; }
+      if (h_half) pc.D = nullptr;              // h exists as binary16 only
       WS_LAUNCH(gemm(pc, st));
     }
     // ASTP
@@ -212,6 +215,8 @@ struct EcapaModel : ModelBase {
     if (glob) {
       // [mean; std] statistics, then bias_img = W1[:, C:3C] [mean; std] + b1 as a split-K GEMM
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
+        if (stats_from_colsum && h_half)
+          return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st);
         if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st);
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st);
       }));
@@ -222,11 +227,11 @@ struct EcapaModel : ModelBase {
       a1.bias_img = bias_img;
     }
     WS_LAUNCH(gemm(a1, st));
-    static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
     if (T >= 64 && !no_fuse) {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
       ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
       l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer
+      if (h_half) { l2.pool_h = nullptr; l2.pool_h16 = h16; }
       if (f16io) { l2.A16 = att16; l2.lda16 = 128; }
       WS_LAUNCH(gemm(l2, st));
       WS_LAUNCH(other(0.0, st, [&] {

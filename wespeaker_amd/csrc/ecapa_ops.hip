@@ -293,8 +293,22 @@ __global__ __launch_bounds__(256) void astp_context_bias_kernel(const float* __r
 // `colsum`): the mean comes from those, so h is read ONCE (centred squares, still two-pass exact).
 // grid = (B, C/256), block = 256: lane = 4 channels (16-B loads), the 4 wavefronts split T,
 // 8 independent row loads in flight per lane.
+template <typename TH>
+__device__ __forceinline__ f32x4 load4_as_f32(const TH* p);
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<uint16_t>(const uint16_t* p) {
+  typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+  const f16x4e v = *reinterpret_cast<const f16x4e*>(p);
+  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+template <typename TH>
 __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
-    const float* __restrict__ h, int ldh, int T, int C, const float* __restrict__ colsum,
+    const TH* __restrict__ h, int ldh, int T, int C, const float* __restrict__ colsum,
     float* __restrict__ stats) {
   __shared__ f32x4 red[4][64];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
     mean += *reinterpret_cast<const f32x4*>(colsum + ((long long)tm * 2 + which) * C + c);
   }
   mean *= 1.f / (float)T;
-  const float* base = h + r0 * ldh + c;
+  const TH* base = h + r0 * ldh + c;
   f32x4 q[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -316,12 +330,12 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
   for (; t + 28 < T; t += 32) {
     f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (long long)(t + 4 * u) * ldh);
+    for (int u = 0; u < 8; ++u) v[u] = load4_as_f32<TH>(base + (long long)(t + 4 * u) * ldh);
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const f32x4 d = v[u] - mean; q[u] += d * d; }
   }
   for (; t < T; t += 4) {
-    const f32x4 d = *reinterpret_cast<const f32x4*>(base + (long long)t * ldh) - mean;
+    const f32x4 d = load4_as_f32<TH>(base + (long long)t * ldh) - mean;
     q[0] += d * d;
   }
   red[wave][lane] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
@@ -339,8 +353,16 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
                                        const float* colsum, float* stats, hipStream_t stream) {
   if ((C & 255) || T < 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(astp_std_from_colsum_kernel, dim3(B, C / 256), dim3(256), 0, stream, h, ldh, T,
-                     C, colsum, stats);
+  hipLaunchKernelGGL(astp_std_from_colsum_kernel<float>, dim3(B, C / 256), dim3(256), 0, stream, h, ldh,
+                     T, C, colsum, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
+                                           const float* colsum, float* stats, hipStream_t stream) {
+  if ((C & 255) || T < 64 || (ldh & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(astp_std_from_colsum_kernel<uint16_t>, dim3(B, C / 256), dim3(256), 0, stream, h16,
+                     ldh, T, C, colsum, stats);
   return hipGetLastError();
 }
 

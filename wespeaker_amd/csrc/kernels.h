@@ -45,6 +45,7 @@ struct ConvGemmParams {
   float* colsum;                              // optional [ceil(M/64)][2][N]: column sums of the stored
                                               // values per 64-row tile, split at the image boundary
                                               // inside the tile (needs Hout*Wout >= 64 rows per image)
+  const uint16_t* pool_h16;                   // binary16 twin of pool_h (same ldh), used instead when set
   const float* pool_h; int ldh;               // optional fused attentive-statistics pooling: the GEMM
   float* pool_partial;                        // output is the LOGIT tensor e; instead of storing it,
                                               // online-softmax partials over rows of (max, sum w,
@@ -97,6 +98,8 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
                                        const float* colsum, float* stats, hipStream_t stream);
+hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
+                                           const float* colsum, float* stats, hipStream_t stream);
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
                              hipStream_t stream);
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
