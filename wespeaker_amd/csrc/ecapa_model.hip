@@ -27,7 +27,7 @@ struct EcapaModel : ModelBase {
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
         *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
-  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr, *y3_16 = nullptr;
+  uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr, *y3_16 = nullptr, *col16 = nullptr;
   static constexpr int kSplitK = 16;
 
   EcapaModel(const std::string& n, int fd, int ed) : ModelBase(n, fd, ed) {
@@ -106,7 +106,7 @@ struct EcapaModel : ModelBase {
            o_e = take(M * 1536), o_s = take((size_t)maxB * C), o_stats = take((size_t)maxB * 3072),
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
-           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C + C) + 1) / 2),   // binary16 copies (f16 back-end)
+           o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C + C + 512) + 1) / 2),   // binary16 copies (f16 back-end)
            o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
@@ -115,7 +115,7 @@ struct EcapaModel : ModelBase {
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
     colsum = base + o_colsum; feats_ws = base + o_feats;
     h16 = reinterpret_cast<uint16_t*>(base + o_h16);
-    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128; y3_16 = y2_16 + M * C;
+    cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128; y3_16 = y2_16 + M * C; col16 = y3_16 + M * C;
     return 0;
   }
 
@@ -131,6 +131,15 @@ struct EcapaModel : ModelBase {
       ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
       if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
       if (allf16) p0.D = nullptr;
+      static const bool no_im2col = getenv("WS_NO_IM2COL") != nullptr;
+      if (f16io && !no_im2col && layer1.ldw <= 512 && feat_dim % 4 == 0) {
+        // k5 conv as a plain GEMM over a binary16 im2col image (K = ldw = taps*F rounded up to 64)
+        WS_LAUNCH(other(2.0 * B * (double)T * layer1.ldw, st, [&] {
+          return launch_im2col_f16(feats, B, T, feat_dim, 5, 2, col16, layer1.ldw, st);
+        }));
+        p0.A16 = col16; p0.lda16 = layer1.ldw; p0.lda = layer1.ldw;
+        p0.K = layer1.ldw; p0.Cin = layer1.ldw; p0.kw = 1; p0.pad_w = 0; p0.dil_w = 1;
+      }
       WS_LAUNCH(gemm(p0, st));
     }
     for (int L = 0; L < 3; ++L) {

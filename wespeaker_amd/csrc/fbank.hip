@@ -204,6 +204,46 @@ hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ binary16 im2col (layer 1)
+// one thread per 8 output halfs (16-B store); F % 4 == 0 and ld % 8 == 0
+__global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict__ feats, int T, int F,
+                                                         int taps, int pad, uint16_t* __restrict__ out,
+                                                         int ld, long long total8) {
+  typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+  const int c8n = ld >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8;
+       i += (long long)gridDim.x * 256) {
+    const long long m = i / c8n;
+    const int k0 = (int)(i - m * c8n) * 8;
+    const int b = (int)(m / T), t = (int)(m - (long long)b * T);
+    f16x8e o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                   // two float4 halves; a half never straddles a tap
+      const int k = k0 + 4 * h;
+      const int tap = k / F, f = k - tap * F;
+      const int ts = t + tap - pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tap < taps && ts >= 0 && ts < T)
+        v = *reinterpret_cast<const float4*>(feats + ((long long)b * T + ts) * F + f);
+      o[4 * h + 0] = (_Float16)v.x; o[4 * h + 1] = (_Float16)v.y;
+      o[4 * h + 2] = (_Float16)v.z; o[4 * h + 3] = (_Float16)v.w;
+    }
+    *reinterpret_cast<f16x8e*>(out + m * ld + k0) = o;
+  }
+}
+
+hipError_t launch_im2col_f16(const float* feats, int B, int T, int F, int taps, int pad, uint16_t* out,
+                             int ld, hipStream_t stream) {
+  if ((F & 3) || (ld & 7) || ld < taps * F) return hipErrorInvalidValue;
+  const long long total8 = (long long)B * T * (ld >> 3);
+  if (total8 <= 0) return hipSuccess;
+  long long blocks = (total8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(im2col_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feats, T, F, taps,
+                     pad, out, ld, total8);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ chunk-and-average mode
 // SpeakerEngine::ExtractFeature, chunk-by-chunk branch (runtime/core/speaker/speaker_engine.cc:96-131):
 // the utterance's frames [total][F] are cut into consecutive chunks of `cf` frames; a trailing

@@ -145,6 +145,11 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream);
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream);
+// binary16 im2col of a k-tap "same" Conv1d over time: out[(b,t)][tap*F + f] = feats[b][t + tap - pad][f]
+// (0 outside the utterance), row length ld (>= taps*F, tail zero filled) -- turns the first TDNN layer
+// into a plain GEMM for the LDS-DMA kernel
+hipError_t launch_im2col_f16(const float* feats, int B, int T, int F, int taps, int pad, uint16_t* out,
+                             int ld, hipStream_t stream);
 // chunk-and-average mode of the native runtime (speaker_engine.cc:83-159)
 hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int n_full, int n_chunks,
                                float* dst, hipStream_t stream);

@@ -151,7 +151,7 @@ struct ModelBase : Model {
     if (!fold_bn.empty() && (err = bn_affine(sd, fold_bn, N, &fsc, &fsh, fold_affine))) return err;
     out->N = N; out->Cin = Cin; out->kh = kh; out->kw = kw;
     const int taps = kh * kw;
-    out->ldw = round_up(Cin * taps, 32);
+    out->ldw = round_up(Cin * taps, 64);      // 64: the K-tile of the f16 kernels (zero padded)
     std::vector<float> packed((size_t)N * out->ldw, 0.f);
     for (int n = 0; n < N; ++n)
       for (int tp = 0; tp < taps; ++tp)
