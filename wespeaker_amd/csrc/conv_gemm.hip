@@ -1049,7 +1049,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
 #else
   hipError_t e;
   if (use_dma)
-    e = launch_f16_dma<128, 128, 64, 2>(main, stream);   // (4 stages of K-tile 32: measured 5 % slower)
+    e = dma == 3 ? launch_f16_dma<128, 128, 64, 3>(main, stream)
+                 : launch_f16_dma<128, 128, 64, 2>(main, stream);   // (4 stages of K-tile 32: measured 5 % slower)
   else
     e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
                            : launch_f16_fast<128, 128, true>(main, stream))
