@@ -58,13 +58,16 @@ constexpr size_t tile_lds_bytes() {
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA GEMM kernels: takes the 32x32 accumulator blocks of the workgroup's
 // BM x BN tile, returns after all global stores (it ends on code every thread executes).
-template <int BM, int BN, int WM, int WN>
+// `tid` is the thread's index inside the group of 64*WM*WN threads that owns this tile (= threadIdx.x
+// for the one-tile kernels; the 256x256 kernel runs four such groups).  Every thread of the
+// WORKGROUP must call it the same number of times (the barriers are workgroup-wide); a group whose
+// `active` is false only keeps the barriers company.  POOL = false compiles the fused-pooling path out.
+template <int BM, int BN, int WM, int WN, bool POOL = true>
 __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                              float* lds, int m0, int n0) {
+                                              float* lds, int m0, int n0, int tid, bool active = true) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int li = lane & 31, lh = lane >> 5;
@@ -73,6 +76,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
   // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   if (p.splitk > 1) {
+    if (!active) return;
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
       const int n = n0 + (wn * TN + in) * 32 + li;
@@ -90,7 +94,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
   // finishes 4 consecutive output channels of one row: 16-B global stores, 512 B contiguous per
   // output row, instead of 4-B stores (which are ~6x slower per byte on gfx950).
   constexpr int ES = BN + 4;
-  {
+  if (active) {
     float* Es = lds;
 #pragma unroll
     for (int in = 0; in < TN; ++in)
@@ -121,11 +125,11 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         pm[hf][wh] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
         p0[hf][wh] = p1[hf][wh] = p2[hf][wh] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-    if (p.pool_partial) {
+    if (POOL && p.pool_partial) {
       // ASTP fused into the logit GEMM: the logits are never written to HBM.  All h rows of a
       // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
       // online-softmax tuples of the (half, image part) groups.
-      if (n < p.N) {
+      if (active && n < p.N) {
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -175,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         }
       }
     } else
-    if (n < p.N) {                             // N % 4 == 0 (checked on the host)
+    if (active && n < p.N) {                   // N % 4 == 0 (checked on the host)
       f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
       if (p.post_scale) {
@@ -237,13 +241,15 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
       // plain store per column -> colsum[(tile64*2 + which)][N].
       __syncthreads();                                  // everyone is done reading the E tile
       float* red = lds;                                 // [NH][2][RPP][BN]
+      if (active) {
 #pragma unroll
-      for (int hf = 0; hf < NH; ++hf)
+        for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-        for (int wh = 0; wh < 2; ++wh)
-          *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
+          for (int wh = 0; wh < 2; ++wh)
+            *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
+      }
       __syncthreads();
-      for (int o = tid; o < NH * 2 * BN; o += NT) {
+      for (int o = active ? tid : NH * 2 * BN; o < NH * 2 * BN; o += NT) {
         const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
         float sacc = 0.f;
 #pragma unroll
@@ -252,7 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
       }
     }
-    if (p.pool_partial) {
+    if (POOL && p.pool_partial) {
       // fold the RPP row phases: (max, s0, s1, s2) tuples combined with the usual rescaling;
       // one [4]-tuple per (64-row tile, image part, column) -> pool_partial[tile64*2 + which][N][4]
       __syncthreads();
@@ -585,7 +591,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   if (kt_begin < kt_end) compute_tile(buf);
   __syncthreads();
 
-  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,7 +766,7 @@ void gemm_f16_kernel(const ConvGemmParams p) {
   }
   if (nk > 0) compute_tile(buf);
   __syncthreads();
-  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -777,8 +783,9 @@ void gemm_f16_kernel(const ConvGemmParams p) {
 template <int BM, int BN, int BKT, int NSTAGE>
 constexpr size_t f16_dma_lds_bytes() {
   const size_t stages = (size_t)NSTAGE * (BM + BN) * BKT * 2;
-  const size_t epi = (size_t)BM * (BN + 4) * 4;
-  const size_t pool = (size_t)BM * 256 * 2;
+  // 256x256 tiles finish as four 128x128 quadrants, two at a time (two transpose regions)
+  const size_t epi = BM == 256 ? 2 * (size_t)128 * (128 + 4) * 4 : (size_t)BM * (BN + 4) * 4;
+  const size_t pool = BM == 256 ? 0 : (size_t)BM * 256 * 2;
   size_t m = stages > epi ? stages : epi;
   return m > pool ? m : pool;
 }
@@ -797,16 +804,22 @@ __device__ __forceinline__ void dma_16B(const void* g, void* lds_base) {
 #endif
 }
 
+// Wavefront grid: 2 x 2 for the 128x128 / 64x64 tiles (two workgroups per CU), 2 x 4 wavefronts of
+// 128x64 outputs each for the 256x256 tile (512 threads, one workgroup per CU, 128 accumulator VGPRs
+// per lane).  What limits this loop is the global -> LDS rate (~22 B/clk/CU measured, by DMA or
+// through registers alike), so the 256x256 tile, which moves half the bytes per flop and reads 25 %
+// fewer fragment bytes per MFMA, is the one that pays.
 template <int BM, int BN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, 2)
 void gemm_f16_dma_kernel(const ConvGemmParams p) {
-  constexpr int WM = 2, WN = 2;
+  constexpr int WM = 2, WN = BM == 256 ? 4 : 2;
+  constexpr int NWAVES = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int CH = BKT / 8;                    // 16-B chunks per row
   constexpr int RPD = 64 / CH;                   // rows covered by one 1-KiB DMA instruction
   constexpr int SWS = CH == 8 ? 1 : 2;           // swizzle key = (row >> SWS) & (CH - 1)
   constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int A_DMA = A_BYTES / 1024 / 4, W_DMA = W_BYTES / 1024 / 4;   // per wavefront and K-tile
+  constexpr int A_DMA = A_BYTES / 1024 / NWAVES, W_DMA = W_BYTES / 1024 / NWAVES;   // per wavefront and K-tile
   constexpr int LPT = A_DMA + W_DMA;
   constexpr int D = NSTAGE - 1;                  // K-tiles in flight
   static_assert(A_DMA >= 1 && W_DMA >= 1 && (CH == 8 || CH == 4), "tile / K-tile combination");
@@ -828,45 +841,38 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = p.K / BKT;
 
-  // per-lane DMA sources: slot (row rr, physical chunk pc) of a 1-KiB piece <- logical chunk pc ^ key(row)
-  const uint16_t* a_src[A_DMA];
-  const uint16_t* w_src[W_DMA];
-  int a_inc[A_DMA], w_inc[W_DMA];
+  // per-lane DMA sources: slot (row rr, physical chunk pc) of a 1-KiB piece <- logical chunk pc ^ key(row).
+  // Rows beyond M / N are clamped to the last valid row (their products only reach outputs that are
+  // never stored), so every piece advances by the same BKT halfs per K-tile: the persistent state is
+  // one 32-bit element offset per piece plus a scalar K offset.
+  int a_off32[A_DMA], w_off32[W_DMA];
   {
     const int rr = lane / CH, pc = lane % CH;
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
       const int row = (wave * A_DMA + j) * RPD + rr;
       const int c = pc ^ ((row >> SWS) & (CH - 1));
-      const bool ok = m0 + row < p.M;
-      a_src[j] = ok ? p.A16 + (long long)(m0 + row) * p.lda16 + p.a_off + c * 8
-                    : reinterpret_cast<const uint16_t*>(p.zeros);
-      a_inc[j] = ok ? BKT : 0;
-
+      const int m = m0 + row < p.M ? m0 + row : p.M - 1;
+      a_off32[j] = m * p.lda16 + p.a_off + c * 8;
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j) {
       const int row = (wave * W_DMA + j) * RPD + rr;
       const int c = pc ^ ((row >> SWS) & (CH - 1));
-      const bool ok = n0 + row < p.N;
-      w_src[j] = ok ? p.Wh + (long long)(n0 + row) * p.ldw + c * 8
-                    : reinterpret_cast<const uint16_t*>(p.zeros);
-      w_inc[j] = ok ? BKT : 0;
-
+      const int n = n0 + row < p.N ? n0 + row : p.N - 1;
+      w_off32[j] = n * p.ldw + c * 8;
     }
   }
+  int k_off = 0;                                 // halfs; wave-uniform
   auto issue = [&](int stage) {
     char* base = ldsb + stage * STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_DMA; ++j) {
-      dma_16B(a_src[j], base + (wave * A_DMA + j) * 1024);
-      a_src[j] += a_inc[j];
-    }
+    for (int j = 0; j < A_DMA; ++j)
+      dma_16B(p.A16 + (unsigned)(a_off32[j] + k_off), base + (wave * A_DMA + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < W_DMA; ++j) {
-      dma_16B(w_src[j], base + A_BYTES + (wave * W_DMA + j) * 1024);
-      w_src[j] += w_inc[j];
-    }
+    for (int j = 0; j < W_DMA; ++j)
+      dma_16B(p.Wh + (unsigned)(w_off32[j] + k_off), base + A_BYTES + (wave * W_DMA + j) * 1024);
+    k_off += BKT;
   };
 
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -921,7 +927,20 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
     st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
     st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
   }
-  gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+  if constexpr (NWAVES == 4) {
+    gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
+  } else {
+    // four 128x128 quadrants, each owned by two wavefronts (128x64 each, a 1 x 2 grid); the two
+    // quadrants of a row half run together on separate transpose regions
+    const int qn = wn >> 1;
+    const int tid_q = ((wn & 1) << 6) | lane;
+    float* region = lds + qn * (128 * (128 + 4));
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+      gemm_epilogue<128, 128, 1, 2, false>(p, acc, region, m0 + ph * 128, n0 + qn * 128, tid_q, wm == ph);
+      __syncthreads();
+    }
+  }
 }
 
 template <int BM, int BN, int BKT, int NSTAGE>
@@ -937,7 +956,7 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(BM == 256 ? 512 : 256), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -1013,10 +1032,34 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   static int dma = -1;
   if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
   const bool use_dma = fast16 && p.A16 && dma;
+  const int rows = p.M - p.m_begin;             // rows this launch covers (m_begin > 0: a peeled tail)
+  // 256x256 tiles (one 16-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
+  // re-enters below with m_begin set
+  static int big = -1;
+  // OFF by default.  Measured in tools/gemm_probe (bare bias/ReLU epilogue): +6 % at N = K = 1536,
+  // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
+  // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
+  if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 0; }
+  if (use_dma && big && p.N % 256 == 0 && p.N >= 1024 && !p.pool_partial) {
+    const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
+    const long long rounds = tiles_m * tiles_n / cus;
+    if (rounds >= 1) {
+      long long main_tiles_m = rounds * cus / tiles_n;
+      // the last round may also be nearly full: then no tail at all
+      if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * 8) main_tiles_m = tiles_m;
+      ConvGemmParams mainb = p;
+      if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
+      hipError_t e = launch_f16_dma<256, 256, 64, 2>(mainb, stream);
+      if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
+      ConvGemmParams rest = p;
+      rest.m_begin = mainb.M;
+      return launch_prec<PREC>(rest, stream);
+    }
+  }
   // Small problems (fewer 128-row tiles than half the chip's block slots): 64x64 tiles put 2-4x
   // more workgroups in flight (CAM++'s dense layers are [B*T/2 x 32..128] GEMMs).
   {
-    const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long long blocks128 = (long long)((rows + 127) / 128) * ((p.N + 127) / 128);
     if (p.splitk <= 1 && blocks128 * 2 < slots) {
       if (use_dma) return launch_f16_dma<64, 64, 64, 2>(p, stream);
       if (fast16) return p.A16 ? launch_f16_fast<64, 64, false>(p, stream) : launch_f16_fast<64, 64, true>(p, stream);
@@ -1032,13 +1075,13 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // same-stream order: the cross-queue event dependencies cost more than the overlap gains.)
   ConvGemmParams main = p, tail = p;
   bool peel = false;
-  if (p.splitk <= 1 && p.m_begin == 0) {
-    const long long tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
+  if (p.splitk <= 1) {
+    const long long tiles_m = (rows + 127) / 128, tiles_n = (p.N + 127) / 128;
     const long long total = tiles_m * tiles_n, rem = total % slots;
     if (total > slots && rem != 0 && rem * 10 <= slots * 7) {
       const long long main_tiles_m = (total - rem) / tiles_n;
       if (main_tiles_m > 0 && main_tiles_m < tiles_m) {
-        main.M = (int)(main_tiles_m * 128);
+        main.M = p.m_begin + (int)(main_tiles_m * 128);
         tail.m_begin = main.M;
         peel = true;
       }
