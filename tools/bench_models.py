@@ -39,7 +39,7 @@ def main():
         wav = device_wavs(batch, 32000, dev, 0)
         rec = {"model": name, "batch": batch, "engine_chunk": chunk, "frames": T,
                "gflop_per_utt": model.flops(1, T) / 1e9}
-        for prec in ("fp32", "f16x3"):
+        for prec in ("fp32", "f16x3", "f16"):
             model.set_precision(prec)
             for _ in range(2):
                 model.extract(fe, wav)

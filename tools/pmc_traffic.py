@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 PMC passes of `bench.py` into profiles/r01_pmc_dominant_kernel_<prec>.json.
+
+Run on the GPU box (counters in SEPARATE passes, kernel-trace only, as gpurun requires):
+
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$i -- \
+          python bench.py --precision f16 --steps 5 --warmup 2 --no-cpu-baseline ; done
+    python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128" $OUT/pmc_* > profiles/r01_pmc_dominant_kernel_f16.json
+
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide
+coalesced read (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    prec, needle = sys.argv[1], sys.argv[2]
+    vals = collections.defaultdict(list)
+    name = None
+    for d in sys.argv[3:]:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if needle in r["Kernel_Name"]:
+                    name = r["Kernel_Name"]
+                    vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    avg = {k: sum(v) / len(v) for k, v in vals.items()}
+    out = {"command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --precision %s "
+                      "--steps 5 --warmup 2 --no-cpu-baseline" % prec,
+           "kernel": name, "launches_profiled": max(len(v) for v in vals.values()),
+           "counters_avg_per_launch": avg}
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        out["fetch_bytes_corrected_x2"] = 2 * 1024 * avg["FETCH_SIZE"]
+        out["write_bytes"] = 1024 * avg["WRITE_SIZE"]
+        out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
+        out["note"] = ("gfx950: FETCH_SIZE reports half the bytes of wide coalesced streaming reads "
+                       "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE uncalibrated, taken as is")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # busy cycles are summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
+        out["mfma_busy_fraction_of_cycles"] = (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (avg["GRBM_GUI_ACTIVE"] / 8.0)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -248,8 +248,11 @@ struct ModelBase : Model {
   hipError_t gemm(const ConvGemmParams& p, hipStream_t st) {
     if (prof.enabled) {
       const double flops = 2.0 * p.M * (double)p.N * p.K;
-      const double bytes = 4.0 * ((double)p.M * p.Cin * (p.A2 ? 2 : 1) + (double)p.N * p.K +
-                                  (double)p.M * p.N);
+      // algorithmic bytes: A once, W once, every stored copy of D once (binary16 tensors count 2 B)
+      const double a_b = p.prec == 2 && p.A16 ? 2.0 : 4.0 * (p.A2 ? 2 : 1);
+      const double w_b = p.prec == 0 ? 4.0 : (p.prec == 1 ? 4.0 : 2.0);
+      const double d_b = (p.D ? 4.0 : 0.0) + (p.D16 ? 2.0 : 0.0);
+      const double bytes = a_b * p.M * (double)p.Cin + w_b * p.N * (double)p.K + d_b * p.M * (double)p.N;
       prof.begin(p.splitk > 1 ? 3 : (p.N <= 64 ? 1 : 0), flops, bytes, st);
     }
     hipError_t e = launch_conv_gemm(p, st);
