@@ -12,7 +12,10 @@
 //      PREC 0  v_mfma_f32_32x32x2_f32: exact fp32 products (bit-identical to an fmaf chain),
 //              157 TF peak.  One ds_read_b128 feeds 4 MFMAs per tile (k-permuted lanes).
 //      PREC 2  "f16": operands rounded to binary16 (hi planes only), ONE MFMA pass, fp32 accumulation
-//              -- the arithmetic of the reference's own TensorRT-fp16 GPU runtime;
+//              -- the arithmetic of the reference's own TensorRT-fp16 GPU runtime.  Plain 1x1 layers
+//              take dedicated K-tile-64 kernels further down: gemm_f16_dma_kernel when the producer
+//              left a binary16 copy of the activations (both operands by LDS-DMA), gemm_f16_kernel
+//              otherwise (fp32 activations converted while staged);
 //      PREC 1  "f16x3": every fp32 operand is split x = hi + lo (hi = half(x), lo = half(x - hi),
 //              22 significant bits) and the product is formed as hi*hi + hi*lo + lo*hi on
 //              v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative product error
@@ -29,9 +32,11 @@
 //    MFMAs and written to the other LDS buffer after them -> one barrier per K-tile.
 //  * XCD-aware bijective tile order; tail peeling: rows beyond the last full round of
 //    (2 tiles per CU) go to a 64x64-tile launch (a partial last round costs a whole tile time).
-//  * epilogue transposed through LDS -> 16-B stores; fused bias (+ per-utterance bias), residual,
-//    ReLU/tanh, BN-after-activation affine, dual store (Res2 pass-through split), segment mask,
-//    deterministic per-64-row column sums (SE mean), or raw split-K partials.
+//  * one shared epilogue (gemm_epilogue) transposed through LDS -> 16-B stores; fused bias
+//    (+ per-utterance bias), residual, ReLU/tanh, BN-after-activation affine, dual store (Res2
+//    pass-through split), binary16 twins of the stores, segment mask, deterministic per-64-row
+//    column sums (SE mean / context statistics), online-softmax pooling partials, or raw split-K
+//    partials.
 #include "kernels.h"
 
 namespace wsamd {
@@ -1033,7 +1038,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
   const bool use_dma = fast16 && p.A16 && dma;
   const int rows = p.M - p.m_begin;             // rows this launch covers (m_begin > 0: a peeled tail)
-  // 256x256 tiles (one 16-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
+  // 256x256 tiles (one 8-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
   // re-enters below with m_begin set
   static int big = -1;
   // OFF by default.  Measured in tools/gemm_probe (bare bias/ReLU epilogue): +6 % at N = K = 1536,
@@ -1087,18 +1092,13 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       }
     }
   }
-#ifdef WS_EIGHT_WAVES
-  hipError_t e = launch_mode<128, 128, 2, 4, PREC>(main, mode, stream);
-#else
   hipError_t e;
-  if (use_dma)
-    e = dma == 3 ? launch_f16_dma<128, 128, 64, 3>(main, stream)
-                 : launch_f16_dma<128, 128, 64, 2>(main, stream);   // (4 stages of K-tile 32: measured 5 % slower)
+  if (use_dma)   // (3 stages at one workgroup per CU: -16 %; 4 stages of K-tile 32: -5 %)
+    e = launch_f16_dma<128, 128, 64, 2>(main, stream);
   else
     e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
                            : launch_f16_fast<128, 128, true>(main, stream))
                : launch_mode<128, 128, 2, 2, PREC>(main, mode, stream);
-#endif
   if (e != hipSuccess || !peel) return e;
   if (use_dma) return launch_f16_dma<64, 64, 64, 2>(tail, stream);
   if (fast16)
