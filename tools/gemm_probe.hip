@@ -111,7 +111,8 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(tr, trace_buffer_address(), sizeof(tr), hipMemcpyDeviceToHost));
       for (int k = 2; k < 12; ++k) {
         printf("  it %2d:", k);
-        for (int j = 1; j < 6; ++j) printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));
+        for (int j = 1; j < (getenv("PROBE_A16") ? 4 : 6); ++j)
+          printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));
         printf("  | loop %6lld\n", (long long)(tr[(k + 1) * 8] - tr[k * 8]));
       }
     }

@@ -785,12 +785,12 @@ void gemm_f16_kernel(const ConvGemmParams p) {
 // s = 1 for 128-B rows (CH = 8), 2 for 64-B rows (CH = 4) -- conflict-free for every ds_read_b128
 // lane group {0-3,12-15,20-27}, ...  NSTAGE LDS stages keep NSTAGE-1 K-tiles in flight across the
 // per-tile barrier (counted vmcnt, raw s_barrier: __syncthreads would drain the queue).
-template <int BM, int BN, int BKT, int NSTAGE>
+template <int BM, int BN, int BKT, int NSTAGE, int NW>
 constexpr size_t f16_dma_lds_bytes() {
   const size_t stages = (size_t)NSTAGE * (BM + BN) * BKT * 2;
   // 256x256 tiles finish as four 128x128 quadrants, two at a time (two transpose regions)
   const size_t epi = BM == 256 ? 2 * (size_t)128 * (128 + 4) * 4 : (size_t)BM * (BN + 4) * 4;
-  const size_t pool = BM == 256 ? 0 : (size_t)BM * 256 * 2;
+  const size_t pool = BM == 256 ? 0 : (size_t)BM * (64 * NW) * 2;
   size_t m = stages > epi ? stages : epi;
   return m > pool ? m : pool;
 }
@@ -814,11 +814,12 @@ __device__ __forceinline__ void dma_16B(const void* g, void* lds_base) {
 // per lane).  What limits this loop is the global -> LDS rate (~22 B/clk/CU measured, by DMA or
 // through registers alike), so the 256x256 tile, which moves half the bytes per flop and reads 25 %
 // fewer fragment bytes per MFMA, is the one that pays.
-template <int BM, int BN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256, 2)
+template <int BM, int BN, int BKT, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, 2)
 void gemm_f16_dma_kernel(const ConvGemmParams p) {
-  constexpr int WM = 2, WN = BM == 256 ? 4 : 2;
-  constexpr int NWAVES = WM * WN;
+  constexpr int WM = 2, WN = NW / 2;
+  constexpr int NWAVES = NW;
+  static_assert((NW == 4 || NW == 8) && (BM != 256 || NW == 8), "wavefront grid");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int CH = BKT / 8;                    // 16-B chunks per row
   constexpr int RPD = 64 / CH;                   // rows covered by one 1-KiB DMA instruction
@@ -924,15 +925,19 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   int st_c = 0, st_i = D % NSTAGE;              // stage computed on / stage the next issue fills
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + D < nk;
+    WS_STAMP(0)
     if (more) issue(st_i);
+    WS_STAMP(1)
     compute_tile(st_c);
+    WS_STAMP(2)
     // tile kt+1 must have landed in every wavefront before anyone reads it; tiles kt+2.. stay in flight
     if (more) wait_vmcnt_barrier<LPT*(D - 1)>();
     else wait_vmcnt_barrier<0>();
+    WS_STAMP(3)
     st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
     st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
   }
-  if constexpr (NWAVES == 4) {
+  if constexpr (BM != 256) {
     gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
   } else {
     // four 128x128 quadrants, each owned by two wavefronts (128x64 each, a 1 x 2 grid); the two
@@ -948,11 +953,11 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE>
+template <int BM, int BN, int BKT, int NSTAGE, int NW = (BM == 256 ? 8 : 4)>
 static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
-  constexpr size_t lds_bytes = f16_dma_lds_bytes<BM, BN, BKT, NSTAGE>();
+  constexpr size_t lds_bytes = f16_dma_lds_bytes<BM, BN, BKT, NSTAGE, NW>();
   static bool attr_set = false;
-  auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE>;
+  auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE, NW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -961,7 +966,7 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(BM == 256 ? 512 : 256), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * NW), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -1093,7 +1098,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     }
   }
   hipError_t e;
-  if (use_dma)   // (3 stages at one workgroup per CU: -16 %; 4 stages of K-tile 32: -5 %)
+  if (use_dma)   // measured alternatives: 3 stages / 4 waves / one workgroup per CU -16 %; 3 stages / 8 waves
+                 // (64x32 per wave) / one workgroup per CU -10 %; 4 stages of K-tile 32 -5 %
     e = launch_f16_dma<128, 128, 64, 2>(main, stream);
   else
     e = fast16 ? (main.A16 ? launch_f16_fast<128, 128, false>(main, stream)
