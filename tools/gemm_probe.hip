@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
           printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));
         printf("  | loop %6lld\n", (long long)(tr[(k + 1) * 8] - tr[k * 8]));
       }
+
     }
 #endif
     printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e\n", s.name, s.M, s.N, s.K,

@@ -1041,7 +1041,9 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
                       (!p.A16 || (p.lda16 & 7) == 0) && (p.a_off & 7) == 0 && (p.lda & 7) == 0;
   static int dma = -1;
   if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
-  const bool use_dma = fast16 && p.A16 && dma;
+  // (the DMA kernel addresses its operands with 32-bit element offsets)
+  const bool use_dma = fast16 && p.A16 && dma && (long long)p.M * p.lda16 < (1LL << 31) &&
+                       (long long)p.N * p.ldw < (1LL << 31);
   const int rows = p.M - p.m_begin;             // rows this launch covers (m_begin > 0: a peeled tail)
   // 256x256 tiles (one 8-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
   // re-enters below with m_begin set
