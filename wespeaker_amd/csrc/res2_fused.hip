@@ -186,10 +186,16 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   }
   __syncthreads();
 
-  const int co = wn * 16 + li;
+  // The weights are the MFMA's A operand and the activations its B operand, i.e. each wavefront
+  // computes a 16 (channels) x 16 (time steps) block of Y^T: a lane then owns FOUR CONSECUTIVE
+  // CHANNELS (rows 4*lq .. 4*lq+3 of the C tile) of ONE time step (column li), so the whole epilogue
+  // -- next-split loads, LDS hi/lo writes of the running activation, output -- moves 8/16-byte
+  // vectors instead of four scalar accesses per accumulator register.
+  const int co = wn * 16 + li;                  // weight row of this lane's A fragment
+  const int c0 = wn * 16 + lq * 4;              // first of the lane's 4 output channels
   constexpr bool PF = MTW <= 7;
-  const int t0 = wm * MTW * 16 + lq * 4;
-  // lane (j = co, q) holds k = 32 ks + 8 q .. +7 of its weight row
+  const int tb = wm * MTW * 16 + li;            // lane's time step inside m-tile 0
+  // lane (i = co, q) holds k = 32 ks + 8 q .. +7 of its weight row
   f16x8 bh[KS], bl[KS];
   auto load_weights = [&](int step) {
     const long long off = (long long)co * p.ldw + lq * 8;
@@ -201,22 +207,23 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   };
   load_weights(0);
   for (int step = 0; step < 7; ++step) {
-    const float bias = p.bias[step][co], sc = p.scale[step][co], sh = p.shift[step][co];
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[step] + c0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale[step] + c0);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift[step] + c0);
     // Row strides / the LDS write base are laundered through an empty asm once per step so the
-    // 4*MTW per-element addresses are recomputed inside the step instead of being hoisted out of
-    // the step loop (where they would live across the MFMA section and spill).
-    int ld1 = p.ldy1, ld2 = p.ldy2, xw = (t0 + d) * XS + co;
+    // per-element addresses are recomputed inside the step instead of being hoisted out of the step
+    // loop (where they would live across the MFMA section and spill).
+    int ld1 = p.ldy1, ld2 = p.ldy2, xw = (tb + d) * XS + c0;
     asm volatile("" : "+v"(ld1), "+v"(ld2), "+v"(xw));
-    float y1n[PF ? MTW : 1][4];
+    f32x4 y1n[PF ? MTW : 1];
     if (PF && step < 6) {
-      const float* y1u = p.y1 + m_base * ld1 + (step + 1) * W + co + (long long)t0 * ld1;
+      const float* y1u = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int t = t0 + mt * 16 + r;
-          y1n[PF ? mt : 0][r] = t < T ? y1u[(mt * 16 + r) * ld1] : 0.f;
-        }
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int t = tb + mt * 16;
+        y1n[PF ? mt : 0] = t < T ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
+                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
     f32x4 acc[MTW];
 #pragma unroll
@@ -248,37 +255,49 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
             n1l = *reinterpret_cast<const f16x8*>(&Xl[o1]);
           }
         }
-        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, bh[ks], acc[mp], 0, 0, 0);
-        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh[ks], acc[mp + 1], 0, 0, 0);
-        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bl[ks], acc[mp], 0, 0, 0);
-        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl[ks], acc[mp + 1], 0, 0, 0);
-        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bh[ks], acc[mp], 0, 0, 0);
-        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh[ks], acc[mp + 1], 0, 0, 0);
+        // (weights, activations): small cross terms first, hi*hi last
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], a0l, acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], a1l, acc[mp + 1], 0, 0, 0);
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ks], a0h, acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ks], a1h, acc[mp + 1], 0, 0, 0);
+        acc[mp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], a0h, acc[mp], 0, 0, 0);
+        if (two) acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks], a1h, acc[mp + 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
       }
     }
     if (step < 6) load_weights(step + 1);
     __syncthreads();
-    const float* y1e = p.y1 + m_base * ld1 + (step + 1) * W + co + (long long)t0 * ld1;
-    float* y2u = p.y2 + m_base * ld2 + step * W + co + (long long)t0 * ld2;
+    const float* y1e = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
+    float* y2u = p.y2 + (m_base + tb) * ld2 + step * W + c0;
     _Float16* xh = Xh + xw;
     _Float16* xl = Xl + xw;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
+      const int t = tb + mt * 16;
+      if (t < T) {
+        f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = t0 + mt * 16 + r;
-        if (t < T) {
-          const float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
-          if (half_out) Y16[t * W + co] = (_Float16)v;
-          else y2u[(mt * 16 + r) * ld2] = v;
-          if (step < 6) {
-            const float x = v + (PF ? y1n[PF ? mt : 0][r] : y1e[(mt * 16 + r) * ld1]);
-            const _Float16 h = (_Float16)x;
-            xh[(mt * 16 + r) * XS] = h;
-            xl[(mt * 16 + r) * XS] = (_Float16)(x - (float)h);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[mt][r] + bias[r], 0.f) * sc[r] + sh[r];
+        if (half_out) {
+          f16x4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+          *reinterpret_cast<f16x4*>(&Y16[t * W + c0]) = hv;
+        } else {
+          *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
+        }
+        if (step < 6) {
+          const f32x4 x = v + (PF ? y1n[PF ? mt : 0]
+                                  : *reinterpret_cast<const f32x4*>(y1e + (long long)(mt * 16) * ld1));
+          f16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            hi[r] = (_Float16)x[r];
+            lo[r] = (_Float16)(x[r] - (float)hi[r]);
           }
+          *reinterpret_cast<f16x4*>(&xh[mt * 16 * XS]) = hi;
+          *reinterpret_cast<f16x4*>(&xl[mt * 16 * XS]) = lo;
         }
       }
     }
