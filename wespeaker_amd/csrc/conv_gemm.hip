@@ -155,6 +155,9 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
               hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
             }
           }
+          // two passes over the lane's RI rows of this half: the maxima of the two image parts first
+          // (LDS reads only), then ONE exponential per logit and no running rescale
+          f32x4 mx0 = {-1e30f, -1e30f, -1e30f, -1e30f}, mx1 = mx0;
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
             const int rl = rr + RPP * i;
@@ -163,20 +166,27 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
               const bool second = rl >= rb;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float mo = second ? pm[hf][1][q] : pm[hf][0][q];
-                const float mn = fmaxf(mo, v[q]);
-                const float sc = __expf(mo - mn), pe = __expf(v[q] - mn);
+                if (second) mx1[q] = fmaxf(mx1[q], v[q]);
+                else mx0[q] = fmaxf(mx0[q], v[q]);
+              }
+            }
+          }
+          pm[hf][0] = mx0;
+          pm[hf][1] = mx1;
+#pragma unroll
+          for (int i = 0; i < RI; ++i) {
+            const int rl = rr + RPP * i;
+            if (mh + rl < p.M) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
+              const bool second = rl >= rb;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float pe = __expf(v[q] - (second ? mx1[q] : mx0[q]));
                 const float h1 = pe * hv[i][q], h2 = h1 * hv[i][q];
                 if (second) {
-                  pm[hf][1][q] = mn;
-                  p0[hf][1][q] = p0[hf][1][q] * sc + pe;
-                  p1[hf][1][q] = p1[hf][1][q] * sc + h1;
-                  p2[hf][1][q] = p2[hf][1][q] * sc + h2;
+                  p0[hf][1][q] += pe; p1[hf][1][q] += h1; p2[hf][1][q] += h2;
                 } else {
-                  pm[hf][0][q] = mn;
-                  p0[hf][0][q] = p0[hf][0][q] * sc + pe;
-                  p1[hf][0][q] = p1[hf][0][q] * sc + h1;
-                  p2[hf][0][q] = p2[hf][0][q] * sc + h2;
+                  p0[hf][0][q] += pe; p1[hf][0][q] += h1; p2[hf][0][q] += h2;
                 }
               }
             }
