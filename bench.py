@@ -187,6 +187,29 @@ def main():
                            FP32_MFMA_PEAK_TFLOPS if other == "fp32" else F16_MFMA_PEAK_TFLOPS})
     model.set_precision(args.precision)
 
+    # ---- BASELINE.json configs[1] beside the headline: ECAPA-TDNN-1024, same 256 x 2 s batch, same
+    # back-end (reported as an extra object; the headline metric is quoted on ECAPA-512)
+    big_info = None
+    if rank == 0:
+        big_name = "ECAPA_TDNN_GLOB_c1024"
+        big = NativeSpeakerModel(big_name, synth.synth_ecapa_state_dict(big_name, 80, 192, seed=42),
+                                 feat_dim=80, embed_dim=192, device=device, max_batch=args.chunk,
+                                 max_frames=T)
+        big.set_precision(args.precision)
+        for _ in range(2):
+            big.extract(fe, wav)
+        torch.cuda.synchronize(device)
+        kb = max(3, min(args.steps, 10))
+        tb = time.perf_counter()
+        for _ in range(kb):
+            big.extract(fe, wav)
+        torch.cuda.synchronize(device)
+        bdt = (time.perf_counter() - tb) / kb
+        big_info = {"model": big_name, "value": args.batch / bdt, "unit": "embeddings/s per GPU",
+                    "ms_per_step": bdt * 1e3, "steps": kb, "precision": args.precision,
+                    "model_tflops": big.flops(1, T) * args.batch / bdt / 1e12}
+        del big
+
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
     if rank == 0:
@@ -280,6 +303,7 @@ def main():
             },
         }
         line["other_precision"] = others
+        line["config1_ecapa_tdnn_1024"] = big_info
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
         # command (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed aggregate is used
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel_%s.json" % prec)
