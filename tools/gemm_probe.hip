@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
   struct Shape { int M, N, K, taps; const char* name; };
   std::vector<Shape> shapes = {{50688, 512, 512, 1, "1x1 512"}, {50688, 1536, 1536, 1, "cat 1536"},
                                {50688, 128, 1536, 1, "astp1"}, {50688, 1536, 128, 1, "astp2"},
-                               {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"},
+                               {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"}, {50688, 32, 96, 3, "n32 k3"},
                                {49152, 512, 512, 1, "512 M=384t"}, {32768, 512, 512, 1, "512 M=256t"},
                                {16384, 512, 512, 1, "512 M=128t"}, {49152, 1536, 1536, 1, "cat M=384t"}};
   const int prec = argc > 1 ? atoi(argv[1]) : 0;
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     p.dil_h = 1; p.dil_w = s.taps == 3 ? 2 : 1; p.pad_w = p.dil_w * (s.taps / 2);
     p.bias = bias; p.act = ACT_RELU; p.post_scale = bias; p.post_shift = bias; p.splitk = 1; p.zeros = Z;
     static uint16_t* A16 = nullptr;
-    if (getenv("PROBE_A16") && prec == 2 && s.taps == 1) {
+    if (getenv("PROBE_A16") && prec == 2) {
       if (!A16) {
         CK(hipMalloc(&A16, maxA * 2));
         std::vector<uint16_t> h16(maxA);
@@ -67,6 +67,21 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(A16, h16.data(), maxA * 2, hipMemcpyHostToDevice));
       }
       p.A16 = A16; p.lda16 = Cin;
+    }
+    double conv_diff = -1.0;
+    if (p.A16 && s.taps > 1) {
+      // convolution on binary16 activations (LDS-DMA kernel) against the fp32-activation kernel
+      ConvGemmParams q = p; q.A16 = nullptr;
+      std::vector<float> ref((size_t)s.M * s.N), got((size_t)s.M * s.N);
+      CK(launch_conv_gemm(q, 0)); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(ref.data(), D, ref.size() * 4, hipMemcpyDeviceToHost));
+      CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(got.data(), D, got.size() * 4, hipMemcpyDeviceToHost));
+      conv_diff = 0.0;
+      for (size_t i = 0; i < ref.size(); ++i) {
+        const double e = fabs((double)ref[i] - got[i]) / (fabs((double)ref[i]) + 1.0);
+        if (e > conv_diff) conv_diff = e;
+      }
     }
     for (int i = 0; i < 3; ++i) CK(launch_conv_gemm(p, 0));
     CK(hipDeviceSynchronize());
@@ -118,8 +133,8 @@ int main(int argc, char** argv) {
 
     }
 #endif
-    printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e\n", s.name, s.M, s.N, s.K,
-           s.taps, us, tf, max_err);
+    printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e  conv-vs-f32A %.2e\n", s.name,
+           s.M, s.N, s.K, s.taps, us, tf, max_err, conv_diff);
   }
   return 0;
 }

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
                                                            int F, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int C,
                                                            float* __restrict__ out,
+                                                           uint16_t* __restrict__ out16,
                                                            long long total) {
   const int c4n = C >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
@@ -52,25 +53,40 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
       for (int k = 0; k < 9; ++k) s += wc[k] * in[k];
       acc[q] = fmaxf(s + bias[c + q], 0.f);
     }
-    *reinterpret_cast<f32x4*>(out + pix * C + c) = acc;
+    if (out16) {                                  // f16 back-end: binary16 activations only
+      typedef _Float16 f16x4c __attribute__((ext_vector_type(4)));
+      f16x4c hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = (_Float16)acc[q];
+      *reinterpret_cast<f16x4c*>(out16 + pix * C + c) = hv;
+    } else {
+      *reinterpret_cast<f32x4*>(out + pix * C + c) = acc;
+    }
   }
 }
 
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
-                               const float* b, int C, float* out, hipStream_t stream) {
+                               const float* b, int C, float* out, hipStream_t stream,
+                               uint16_t* out16) {
   if (C & 3) return hipErrorInvalidValue;
   const long long total = (long long)B * F * T * (C >> 2);
   long long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(stem_conv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feats, T, F,
-                     w, b, C, out, total);
+                     w, b, C, out, out16, total);
   return hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------- TSTP
 // grid = (B*F, ceil(C/64)); block = 256 = 4 time-groups x 64 channels.  Two passes over T
 // (mean, then centred squares) like torch.var; partial sums combined through LDS.
-__global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, int ldx, int F, int T,
+__device__ __forceinline__ float load_act(const float* p) { return *p; }
+__device__ __forceinline__ float load_act(const uint16_t* p) {
+  return (float)*reinterpret_cast<const _Float16*>(p);
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void tstp_kernel(const TX* __restrict__ x, int ldx, int F, int T,
                                                    int C, const float* __restrict__ pre_scale,
                                                    const float* __restrict__ pre_shift,
                                                    float* __restrict__ pooled) {
@@ -79,13 +95,13 @@ __global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, 
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const bool cok = c < C;
-  const float* base = x + (long long)bf * T * ldx + (cok ? c : 0);
+  const TX* base = x + (long long)bf * T * ldx + (cok ? c : 0);
   float ps = 1.f, pb = 0.f;
   const bool pre = pre_scale != nullptr;
   if (pre && cok) { ps = pre_scale[c]; pb = pre_shift[c]; }
   float s = 0.f;
   for (int t = grp; t < T; t += 4) {
-    float v = base[(long long)t * ldx];
+    float v = load_act(base + (long long)t * ldx);
     if (pre) v = fmaxf(v * ps + pb, 0.f);
     s += v;
   }
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, 
   __syncthreads();
   float q = 0.f;
   for (int t = grp; t < T; t += 4) {
-    float v = base[(long long)t * ldx];
+    float v = load_act(base + (long long)t * ldx);
     if (pre) v = fmaxf(v * ps + pb, 0.f);
     const float d = v - mean;
     q += d * d;
@@ -112,8 +128,16 @@ __global__ __launch_bounds__(256) void tstp_kernel(const float* __restrict__ x, 
 
 hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
                        const float* pre_shift, float* pooled, hipStream_t stream) {
-  hipLaunchKernelGGL(tstp_kernel, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x, ldx, F, T, C,
-                     pre_scale, pre_shift, pooled);
+  hipLaunchKernelGGL(tstp_kernel<float>, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x, ldx, F, T,
+                     C, pre_scale, pre_shift, pooled);
+  return hipGetLastError();
+}
+
+hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, int C,
+                           const float* pre_scale, const float* pre_shift, float* pooled,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(tstp_kernel<uint16_t>, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x16, ldx, F,
+                     T, C, pre_scale, pre_shift, pooled);
   return hipGetLastError();
 }
 

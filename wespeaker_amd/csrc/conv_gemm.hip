@@ -215,6 +215,11 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
           if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
           if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
+          if (p.residual16) {
+            const f16x4 r4 = *reinterpret_cast<const f16x4*>(p.residual16 + (long long)m * p.ldr + p.r_off + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += (float)r4[q];
+          }
           if (p.act == ACT_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -824,12 +829,16 @@ __device__ __forceinline__ void dma_16B(const void* g, void* lds_base) {
 // per lane).  What limits this loop is the global -> LDS rate (~22 B/clk/CU measured, by DMA or
 // through registers alike), so the 256x256 tile, which moves half the bytes per flop and reads 25 %
 // fewer fragment bytes per MFMA, is the one that pays.
-template <int BM, int BN, int BKT, int NSTAGE, int NW>
+// CONV = true: general convolution (taps, stride, dilation, zero padding) on binary16 channels-last
+// activations.  A 16-B chunk is 8 consecutive channels of one filter tap (Cin % 8 == 0), so each lane
+// of a DMA piece computes its own source address per K-tile -- tap offset + bounds predicate, the
+// zero page for padding / rows beyond M / k beyond K -- and the rest of the pipeline is unchanged.
+template <int BM, int BN, int BKT, int NSTAGE, int NW, int WM_, bool CONV>
 __global__ __launch_bounds__(64 * NW, 2)
 void gemm_f16_dma_kernel(const ConvGemmParams p) {
-  constexpr int WM = 2, WN = NW / 2;
+  constexpr int WM = WM_, WN = NW / WM_;
   constexpr int NWAVES = NW;
-  static_assert((NW == 4 || NW == 8) && (BM != 256 || NW == 8), "wavefront grid");
+  static_assert((NW == 4 || NW == 8) && (BM != 256 || NW == 8) && WM * WN == NW, "wavefront grid");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int CH = BKT / 8;                    // 16-B chunks per row
   constexpr int RPD = 64 / CH;                   // rows covered by one 1-KiB DMA instruction
@@ -855,21 +864,37 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = p.K / BKT;
+  const int nk = CONV ? (p.K + BKT - 1) / BKT : p.K / BKT;
 
   // per-lane DMA sources: slot (row rr, physical chunk pc) of a 1-KiB piece <- logical chunk pc ^ key(row).
   // Rows beyond M / N are clamped to the last valid row (their products only reach outputs that are
   // never stored), so every piece advances by the same BKT halfs per K-tile: the persistent state is
   // one 32-bit element offset per piece plus a scalar K offset.
   int a_off32[A_DMA], w_off32[W_DMA];
+  int a_pix[CONV ? A_DMA : 1], a_iy[CONV ? A_DMA : 1], a_ix[CONV ? A_DMA : 1], a_kc[CONV ? A_DMA : 1];
   {
     const int rr = lane / CH, pc = lane % CH;
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
       const int row = (wave * A_DMA + j) * RPD + rr;
       const int c = pc ^ ((row >> SWS) & (CH - 1));
-      const int m = m0 + row < p.M ? m0 + row : p.M - 1;
-      a_off32[j] = m * p.lda16 + p.a_off + c * 8;
+      if (CONV) {
+        const int HWo = p.Hout * p.Wout;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / HWo, rem = mm - img * HWo;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int iy0 = oy * p.stride_h - p.pad_h, ix0 = ox * p.stride_w - p.pad_w;
+        a_pix[j] = (img * p.Hin + iy0) * p.Win + ix0;
+        a_iy[j] = ok ? iy0 : -(1 << 28);          // forces the bounds predicate false for rows >= M
+        a_ix[j] = ix0;
+        a_kc[j] = c * 8;
+        a_off32[j] = 0;
+      } else {
+        const int m = m0 + row < p.M ? m0 + row : p.M - 1;
+        a_off32[j] = m * p.lda16 + p.a_off + c * 8;
+      }
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j) {
@@ -883,8 +908,21 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   auto issue = [&](int stage) {
     char* base = ldsb + stage * STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_DMA; ++j)
-      dma_16B(p.A16 + (unsigned)(a_off32[j] + k_off), base + (wave * A_DMA + j) * 1024);
+    for (int j = 0; j < A_DMA; ++j) {
+      if (CONV) {
+        const int kg = k_off + a_kc[j];
+        const int tap = kg / p.Cin, ci = kg - tap * p.Cin;
+        const int ty = tap / p.kw, tx = tap - ty * p.kw;
+        const int dy = ty * p.dil_h, dx = tx * p.dil_w;
+        const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;
+        const bool ok = kg < p.K && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        const uint16_t* src = ok ? p.A16 + ((long long)(a_pix[j] + dy * p.Win + dx) * p.lda16 + p.a_off + ci)
+                                 : reinterpret_cast<const uint16_t*>(p.zeros);
+        dma_16B(src, base + (wave * A_DMA + j) * 1024);
+      } else {
+        dma_16B(p.A16 + (unsigned)(a_off32[j] + k_off), base + (wave * A_DMA + j) * 1024);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j)
       dma_16B(p.Wh + (unsigned)(w_off32[j] + k_off), base + A_BYTES + (wave * W_DMA + j) * 1024);
@@ -963,11 +1001,11 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   }
 }
 
-template <int BM, int BN, int BKT, int NSTAGE, int NW = (BM == 256 ? 8 : 4)>
+template <int BM, int BN, int BKT, int NSTAGE, int NW = (BM == 256 ? 8 : 4), int WM_ = 2, bool CONV = false>
 static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_dma_lds_bytes<BM, BN, BKT, NSTAGE, NW>();
   static bool attr_set = false;
-  auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE, NW>;
+  auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE, NW, WM_, CONV>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1055,6 +1093,30 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool use_dma = fast16 && p.A16 && dma && (long long)p.M * p.lda16 < (1LL << 31) &&
                        (long long)p.N * p.ldw < (1LL << 31);
   const int rows = p.M - p.m_begin;             // rows this launch covers (m_begin > 0: a peeled tail)
+  // f16 back-end, general convolution on binary16 activations: the DMA kernel in CONV form
+  const bool conv16 = PREC == 2 && dma && p.A16 && !p.A2 && !p.pre_scale && !fast16 && p.splitk <= 1 &&
+                      (p.Cin & 7) == 0 && (p.lda16 & 7) == 0 && (p.a_off & 7) == 0 && !p.pool_partial;
+  if (conv16) {
+    if (p.N <= 32) return launch_f16_dma<128, 32, 64, 2, 4, 4, true>(p, stream);
+    if (p.N <= 64) return launch_f16_dma<128, 64, 64, 2, 4, 2, true>(p, stream);
+    const long long blocks128 = (long long)((rows + 127) / 128) * ((p.N + 127) / 128);
+    if (blocks128 * 2 < slots) return launch_f16_dma<64, 64, 64, 2, 4, 2, true>(p, stream);
+    ConvGemmParams mainc = p, tailc = p;
+    const long long tiles_m = (rows + 127) / 128, tiles_n = (p.N + 127) / 128;
+    const long long total = tiles_m * tiles_n, rem = total % slots;
+    bool peelc = false;
+    if (total > slots && rem != 0 && rem * 10 <= slots * 7) {
+      const long long main_tiles_m = (total - rem) / tiles_n;
+      if (main_tiles_m > 0 && main_tiles_m < tiles_m) {
+        mainc.M = p.m_begin + (int)(main_tiles_m * 128);
+        tailc.m_begin = mainc.M;
+        peelc = true;
+      }
+    }
+    hipError_t e = launch_f16_dma<128, 128, 64, 2, 4, 2, true>(mainc, stream);
+    if (e != hipSuccess || !peelc) return e;
+    return launch_f16_dma<64, 64, 64, 2, 4, 2, true>(tailc, stream);
+  }
   // 256x256 tiles (one 8-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
   // re-enters below with m_begin set
   static int big = -1;

@@ -38,6 +38,7 @@ struct ConvGemmParams {
   const float* bias;                          // [N] or null
   const float* bias_img;                      // [num_images][N] or null (per-utterance bias)
   const float* residual; int ldr; int r_off;  // optional, added before the activation
+  const uint16_t* residual16;                 // binary16 form of the residual (same ldr / r_off)
   int act;
   const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
   const float* seg_scale; int seg_len; int segs_per_img;  // optional y *= seg_scale[(img*segs + ox/seg_len)][n]
@@ -117,12 +118,16 @@ hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, in
 // ResNet / FCM stem: Conv2d(1 -> C, 3x3, pad 1, no bias) + folded BN + ReLU, reading the (B, T, F)
 // feature tensor as the (F x T) image and writing channels-last [B][F][T][C].  w: [C][9], b: [C].
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
-                               const float* b, int C, float* out, hipStream_t stream);
+                               const float* b, int C, float* out, hipStream_t stream,
+                               uint16_t* out16 = nullptr);
 // TSTP (pooling_layers.py:78-85) over channels-last x[(b*F + f)*T + t][c]: mean and
 // sqrt(unbiased var + 1e-7) over t; optional pre-activation relu(x*pre_scale[c] + pre_shift[c])
 // (CAM++ out_nonlinear).  pooled[b][c*F + f] = mean, pooled[b][C*F + c*F + f] = std.
 hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
                        const float* pre_shift, float* pooled, hipStream_t stream);
+hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, int C,
+                           const float* pre_scale, const float* pre_shift, float* pooled,
+                           hipStream_t stream);
 // CAM++ context (campplus.py:108-135): ctx = mean_T(h) + segmean_100(h); m = sigmoid(W2 relu(W1 ctx + b1) + b2)
 // h: [B*T][C] (C = 128); mask out: [B][segs][Cout]
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,

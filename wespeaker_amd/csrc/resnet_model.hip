@@ -132,10 +132,27 @@ struct ResNetModel : ModelBase {
 
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
     int H = feat_dim, W = T;
+    // f16 back-end: every activation map lives in HBM as binary16 only (same buffers, half used);
+    // all convolutions then run on the LDS-DMA kernel (conv form), residuals are read as halfs
+    const bool f16io = gemm_precision == 2;
     float* x = buf[0];
     WS_LAUNCH(other(4.0 * B * H * (double)W * 33, st, [&] {
-      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, x, st);
+      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, x, st,
+                                 f16io ? reinterpret_cast<uint16_t*>(x) : nullptr);
     }));
+    // in -> out convolution with the optional residual, in the tensor format of the active back-end
+    auto conv = [&](const ConvW& cw, const float* in, int Cin_, float* out, int Cout_, int Hin_, int Win_,
+                    int s_, int pad, int act, const float* res, int ldr) {
+      ConvGemmParams p = conv2d(cw, in, Cin_, 0, out, Cout_, 0, B, Hin_, Win_, s_, s_, 1, 1, pad, pad, act);
+      if (f16io) {
+        p.A16 = reinterpret_cast<const uint16_t*>(in); p.lda16 = Cin_;
+        p.D = nullptr; p.D16 = reinterpret_cast<uint16_t*>(out); p.ldd16 = Cout_;
+        if (res) { p.residual16 = reinterpret_cast<const uint16_t*>(res); p.ldr = ldr; p.r_off = 0; }
+      } else if (res) {
+        p.residual = res; p.ldr = ldr; p.r_off = 0;
+      }
+      return gemm(p, st);
+    };
     int cur = 0;          // index of the buffer holding x
     for (const Block& blk : blocks) {
       float* t1 = buf[(cur + 1) & 3];
@@ -147,29 +164,28 @@ struct ResNetModel : ModelBase {
       const float* res = x;
       int ldr = Cx;
       if (blk.has_sc) {     // 1x1 stride-s conv + BN on the block input
-        WS_LAUNCH(gemm(conv2d(blk.sc, x, Cx, 0, t2, Co, 0, B, H, W, s, s, 1, 1, 0, 0, ACT_NONE), st));
+        WS_LAUNCH(conv(blk.sc, x, Cx, t2, Co, H, W, s, 0, ACT_NONE, nullptr, 0));
         res = t2;
         ldr = Co;
       }
       if (lay.bottleneck) {
-        WS_LAUNCH(gemm(conv2d(blk.c1, x, Cx, 0, t1, P, 0, B, H, W, 1, 1, 1, 1, 0, 0, ACT_RELU), st));
-        WS_LAUNCH(gemm(conv2d(blk.c2, t1, P, 0, out, P, 0, B, H, W, s, s, 1, 1, 1, 1, ACT_RELU), st));
-        ConvGemmParams p3 = conv2d(blk.c3, out, P, 0, t1, Co, 0, B, Ho, Wo, 1, 1, 1, 1, 0, 0, ACT_RELU);
-        p3.residual = res; p3.ldr = ldr; p3.r_off = 0;
-        WS_LAUNCH(gemm(p3, st));
+        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0));
+        WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0));
+        WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr));
         cur = (cur + 1) & 3;            // result in t1
       } else {
-        WS_LAUNCH(gemm(conv2d(blk.c1, x, Cx, 0, t1, P, 0, B, H, W, s, s, 1, 1, 1, 1, ACT_RELU), st));
-        ConvGemmParams p2 = conv2d(blk.c2, t1, P, 0, out, Co, 0, B, Ho, Wo, 1, 1, 1, 1, 1, 1, ACT_RELU);
-        p2.residual = res; p2.ldr = ldr; p2.r_off = 0;
-        WS_LAUNCH(gemm(p2, st));
+        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, s, 1, ACT_RELU, nullptr, 0));
+        WS_LAUNCH(conv(blk.c2, t1, P, out, Co, Ho, Wo, 1, 1, ACT_RELU, res, ldr));
         cur = (cur + 3) & 3;            // result in out
       }
       x = buf[cur];
       H = Ho; W = Wo;
     }
     const int Cl = 256 * exp;           // channels of the last stage
-    WS_LAUNCH(other(8.0 * B * H * (double)W * Cl, st, [&] {
+    WS_LAUNCH(other((f16io ? 4.0 : 8.0) * B * H * (double)W * Cl, st, [&] {
+      if (f16io)
+        return launch_tstp_f16(reinterpret_cast<const uint16_t*>(x), Cl, B, H, W, Cl, nullptr, nullptr,
+                               pooled, st);
       return launch_tstp(x, Cl, B, H, W, Cl, nullptr, nullptr, pooled, st);
     }));
     if (!two_emb) {
