@@ -834,7 +834,7 @@ __device__ __forceinline__ void dma_16B(const void* g, void* lds_base) {
 // of a DMA piece computes its own source address per K-tile -- tap offset + bounds predicate, the
 // zero page for padding / rows beyond M / k beyond K -- and the rest of the pipeline is unchanged.
 template <int BM, int BN, int BKT, int NSTAGE, int NW, int WM_, bool CONV>
-__global__ __launch_bounds__(64 * NW, 2)
+__global__ __launch_bounds__(64 * NW, (BN <= 32 ? 4 : 2))
 void gemm_f16_dma_kernel(const ConvGemmParams p) {
   constexpr int WM = WM_, WN = NW / WM_;
   constexpr int NWAVES = NW;
@@ -844,10 +844,14 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   constexpr int RPD = 64 / CH;                   // rows covered by one 1-KiB DMA instruction
   constexpr int SWS = CH == 8 ? 1 : 2;           // swizzle key = (row >> SWS) & (CH - 1)
   constexpr int A_BYTES = BM * BKT * 2, W_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int A_DMA = A_BYTES / 1024 / NWAVES, W_DMA = W_BYTES / 1024 / NWAVES;   // per wavefront and K-tile
+  // 1-KiB pieces per wavefront and K-tile.  A narrow weight tile has fewer pieces than wavefronts:
+  // the surplus wavefronts repeat a piece (same bytes to the same place) so that every wavefront
+  // counts the same number of loads per tile (the vmcnt arithmetic below relies on it).
+  constexpr int W_PIECES = W_BYTES / 1024;
+  constexpr int A_DMA = A_BYTES / 1024 / NWAVES, W_DMA = W_PIECES >= NWAVES ? W_PIECES / NWAVES : 1;
   constexpr int LPT = A_DMA + W_DMA;
   constexpr int D = NSTAGE - 1;                  // K-tiles in flight
-  static_assert(A_DMA >= 1 && W_DMA >= 1 && (CH == 8 || CH == 4), "tile / K-tile combination");
+  static_assert(A_DMA >= 1 && W_PIECES >= 1 && (CH == 8 || CH == 4), "tile / K-tile combination");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
 
@@ -898,7 +902,7 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j) {
-      const int row = (wave * W_DMA + j) * RPD + rr;
+      const int row = ((wave * W_DMA + j) % W_PIECES) * RPD + rr;
       const int c = pc ^ ((row >> SWS) & (CH - 1));
       const int n = n0 + row < p.N ? n0 + row : p.N - 1;
       w_off32[j] = n * p.ldw + c * 8;
@@ -925,7 +929,7 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
     }
 #pragma unroll
     for (int j = 0; j < W_DMA; ++j)
-      dma_16B(p.Wh + (unsigned)(w_off32[j] + k_off), base + A_BYTES + (wave * W_DMA + j) * 1024);
+      dma_16B(p.Wh + (unsigned)(w_off32[j] + k_off), base + A_BYTES + ((wave * W_DMA + j) % W_PIECES) * 1024);
     k_off += BKT;
   };
 
@@ -1097,7 +1101,9 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool conv16 = PREC == 2 && dma && p.A16 && !p.A2 && !p.pre_scale && !fast16 && p.splitk <= 1 &&
                       (p.Cin & 7) == 0 && (p.lda16 & 7) == 0 && (p.a_off & 7) == 0 && !p.pool_partial;
   if (conv16) {
-    if (p.N <= 32) return launch_f16_dma<128, 32, 64, 2, 4, 4, true>(p, stream);
+    // N <= 32 (ResNet stage 1, CAM++ head: K = 9 * 32): K-tile 32 divides K exactly, 10-KB stages
+    // -> 4 stages and 4 workgroups per CU hide the DMA round trip
+    if (p.N <= 32) return launch_f16_dma<128, 32, 32, 4, 4, 4, true>(p, stream);
     if (p.N <= 64) return launch_f16_dma<128, 64, 64, 2, 4, 2, true>(p, stream);
     const long long blocks128 = (long long)((rows + 127) / 128) * ((p.N + 127) / 128);
     if (blocks128 * 2 < slots) return launch_f16_dma<64, 64, 64, 2, 4, 2, true>(p, stream);
