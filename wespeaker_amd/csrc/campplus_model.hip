@@ -154,10 +154,20 @@ struct CamppModel : ModelBase {
 
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
     // ---------------- FCM head (2-D, stride only along frequency)
+    // f16 back-end: the head's activation maps are binary16 only and its convolutions (and the TDNN
+    // layer that consumes them) run on the LDS-DMA kernel in convolution form
+    const bool f16io = gemm_precision == 2;
     int H = feat_dim;
     WS_LAUNCH(other(4.0 * B * H * (double)T * 33, st, [&] {
-      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, fa, st);
+      return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, fa, st,
+                                 f16io ? reinterpret_cast<uint16_t*>(fa) : nullptr);
     }));
+    auto to16 = [&](ConvGemmParams& p, const float* in, float* out, const float* res) {
+      if (!f16io) { if (res) { p.residual = res; p.ldr = 32; p.r_off = 0; } return; }
+      p.A16 = reinterpret_cast<const uint16_t*>(in); p.lda16 = 32;
+      if (out) { p.D = nullptr; p.D16 = reinterpret_cast<uint16_t*>(out); p.ldd16 = 32; }
+      if (res) { p.residual16 = reinterpret_cast<const uint16_t*>(res); p.ldr = 32; p.r_off = 0; }
+    };
     float* x = fa;          // block input
     float* t1 = fb;
     float* t2 = fc;
@@ -165,21 +175,27 @@ struct CamppModel : ModelBase {
       const int s = res[i].stride, Ho = (H - 1) / s + 1;
       const float* r = x;
       if (res[i].has_sc) {
-        WS_LAUNCH(gemm(conv2d(res[i].sc, x, 32, 0, t2, 32, 0, B, H, T, s, 1, 1, 1, 0, 0, ACT_NONE), st));
+        ConvGemmParams ps = conv2d(res[i].sc, x, 32, 0, t2, 32, 0, B, H, T, s, 1, 1, 1, 0, 0, ACT_NONE);
+        to16(ps, x, t2, nullptr);
+        WS_LAUNCH(gemm(ps, st));
         r = t2;
       }
-      WS_LAUNCH(gemm(conv2d(res[i].c1, x, 32, 0, t1, 32, 0, B, H, T, s, 1, 1, 1, 1, 1, ACT_RELU), st));
+      ConvGemmParams p1 = conv2d(res[i].c1, x, 32, 0, t1, 32, 0, B, H, T, s, 1, 1, 1, 1, 1, ACT_RELU);
+      to16(p1, x, t1, nullptr);
+      WS_LAUNCH(gemm(p1, st));
       // conv2 writes over the block input buffer when that is no longer needed (shortcut case),
       // otherwise into t2
       float* out = res[i].has_sc ? x : t2;
       ConvGemmParams p2 = conv2d(res[i].c2, t1, 32, 0, out, 32, 0, B, Ho, T, 1, 1, 1, 1, 1, 1, ACT_RELU);
-      p2.residual = r; p2.ldr = 32; p2.r_off = 0;
+      to16(p2, t1, out, r);
       WS_LAUNCH(gemm(p2, st));
       if (!res[i].has_sc) { float* tmp = x; x = t2; t2 = tmp; }
       H = Ho;
     }
     {   // head.conv2: 3x3 stride (2,1) + BN + ReLU  -> [b][F'][T][32]
-      WS_LAUNCH(gemm(conv2d(head_conv2, x, 32, 0, t1, 32, 0, B, H, T, 2, 1, 1, 1, 1, 1, ACT_RELU), st));
+      ConvGemmParams ph = conv2d(head_conv2, x, 32, 0, t1, 32, 0, B, H, T, 2, 1, 1, 1, 1, 1, ACT_RELU);
+      to16(ph, x, t1, nullptr);
+      WS_LAUNCH(gemm(ph, st));
       H = (H - 1) / 2 + 1;
     }
     // ---------------- TDNN (k5, stride 2) over the (F' x T) image -> [B*T'][128] at channel 0 of xbuf
@@ -187,7 +203,11 @@ struct CamppModel : ModelBase {
     float* X = xbuf;
     float* Xn = xbuf2;
     int ldx = 128 + 32 * kLayers[0];
-    WS_LAUNCH(gemm(conv2d(tdnn, t1, 32, 0, X, ldx, 0, B, H, T, 1, 2, 1, 1, 0, 2, ACT_RELU), st));
+    {
+      ConvGemmParams pt0 = conv2d(tdnn, t1, 32, 0, X, ldx, 0, B, H, T, 1, 2, 1, 1, 0, 2, ACT_RELU);
+      to16(pt0, t1, nullptr, nullptr);          // binary16 input, fp32 output (the dense blocks stay fp32)
+      WS_LAUNCH(gemm(pt0, st));
+    }
     const int segs = (Tp + 99) / 100;
     int ch = 128;
     for (int k = 0; k < 3; ++k) {
