@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--trials", type=int, default=1000000)
     ap.add_argument("--cpu-utts", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the other back-ends, the ECAPA-1024 leg and the CPU baseline (for rocprofv3 "
+                         "runs: the kernel statistics then describe the headline workload alone)")
     ap.add_argument("--precision", default="f16", choices=["fp32", "f16x3", "f16"],
                     help="GEMM contraction back-end of the headline run (include/wespeaker_amd.h): "
                          "f16 = binary16 MFMA operands, fp32 accumulation (the arithmetic of the "
@@ -165,7 +168,7 @@ def main():
 
     # the other contraction back-ends, same workload, fewer steps (reported, not the headline)
     others = []
-    for other in [m for m in ("f16", "f16x3", "fp32") if m != args.precision]:
+    for other in [m for m in ("f16", "f16x3", "fp32") if m != args.precision and not args.headline_only]:
         model.set_precision(other)
         osteps = max(3, min(args.steps, 10))
         for _ in range(2):
@@ -190,7 +193,7 @@ def main():
     # ---- BASELINE.json configs[1] beside the headline: ECAPA-TDNN-1024, same 256 x 2 s batch, same
     # back-end (reported as an extra object; the headline metric is quoted on ECAPA-512)
     big_info = None
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         big_name = "ECAPA_TDNN_GLOB_c1024"
         big = NativeSpeakerModel(big_name, synth.synth_ecapa_state_dict(big_name, 80, 192, seed=42),
                                  feat_dim=80, embed_dim=192, device=device, max_batch=args.chunk,
@@ -314,7 +317,7 @@ def main():
             line["roofline"]["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)"
             line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
             line["roofline"]["algorithmic_bytes_per_launch"] = g["bytes"] / max(1, g["launches"])
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(args.model, args.cpu_utts)
         assert all_emb.shape == (n_total, 192) and bool(torch.isfinite(all_emb).all())
         print(json.dumps(line), flush=True)

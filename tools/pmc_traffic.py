@@ -6,7 +6,7 @@ Run on the GPU box (counters in SEPARATE passes, kernel-trace only, as gpurun re
     cd /tmp && export TMPDIR=/tmp
     for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ; do
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$i -- \
-          python bench.py --precision f16 --steps 5 --warmup 2 --no-cpu-baseline ; done
+          python bench.py --precision f16 --steps 5 --warmup 2 --headline-only ; done
     python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128" $OUT/pmc_* > profiles/r01_pmc_dominant_kernel_f16.json
 
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide
@@ -32,7 +32,7 @@ def main():
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     avg = {k: sum(v) / len(v) for k, v in vals.items()}
     out = {"command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --precision %s "
-                      "--steps 5 --warmup 2 --no-cpu-baseline" % prec,
+                      "--steps 5 --warmup 2 --headline-only" % prec,
            "kernel": name, "launches_profiled": max(len(v) for v in vals.values()),
            "counters_avg_per_launch": avg}
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
