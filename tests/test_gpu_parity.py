@@ -430,6 +430,25 @@ def test_campplus_forward_matches_oracle_and_golden(golden_dir):
         assert _rel_err(e, ocam.campplus_forward(sd, f).numpy()).max() < REL_TOL
 
 
+def test_speaker_api_precision_switch(tmp_path):
+    """Speaker.set_precision (extension): all three back-ends through the file-level API agree with
+    each other inside the north-star cosine bar."""
+    import wespeaker_amd
+    d = str(tmp_path / "ecapa")
+    synth.write_model_dir(d, "ECAPA_TDNN_GLOB_c512", embed_dim=192, seed=42)
+    wav = str(tmp_path / "u.wav")
+    synth.write_wav(wav, synth.synth_wav(5))
+    spk = wespeaker_amd.load_model(d)
+    embs = {}
+    for mode in ("fp32", "f16x3", "f16"):
+        spk.set_precision(mode)
+        embs[mode] = spk.extract_embedding(wav).numpy()
+    assert _cos_err(embs["f16x3"][None], embs["fp32"][None]).max() < 1e-6
+    assert _cos_err(embs["f16"][None], embs["fp32"][None]).max() < COS_TOL
+    with pytest.raises(KeyError):
+        spk.set_precision("int8")
+
+
 def test_speaker_api_resnet_and_campplus_model_dirs(tmp_path):
     import wespeaker_amd as wespeaker
     from oracle import campplus as ocam

@@ -110,6 +110,13 @@ class Speaker:
                                        % (self.device, idx))
         self.model = self.model.to(dev)
 
+    def set_precision(self, mode: str):
+        """Extension (not in the reference API): GEMM back-end of the forward -- 'fp32' (default,
+        exact fp32 MFMA), 'f16x3' (fp32-grade split binary16) or 'f16' (binary16 operands and
+        inter-layer tensors with fp32 accumulation: what the reference's TensorRT-fp16 runtime
+        computes).  See include/wespeaker_amd.h, ws_engine_set_precision."""
+        self.model.set_precision(mode)
+
     def set_diarization_params(self, min_duration=0.255, window_secs=1.5, period_secs=0.75,
                                frame_shift=10, batch_size=32, subseg_cmn=True):
         self.diar_min_duration = min_duration
