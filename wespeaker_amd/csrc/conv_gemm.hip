@@ -1211,6 +1211,9 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   }
   if (p.prec == 2) {
     if (!p.Wh) return hipErrorInvalidValue;
+    static int direct = -1;
+    if (direct < 0) { const char* ev = getenv("WS_DIRECT3X3"); direct = ev ? atoi(ev) : 1; }
+    if (direct && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
     return launch_prec<2>(p, stream);
   }
   return launch_prec<0>(p, stream);

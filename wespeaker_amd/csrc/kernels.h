@@ -188,6 +188,10 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
                                  const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
                                  int64_t num_trials, double* out, hipStream_t stream);
 
+// -------- direct 3x3, 32 -> 32 channel convolution on binary16 maps (conv3x3_direct.hip)
+bool conv3x3_direct_supported(const ConvGemmParams& p);
+hipError_t launch_conv3x3_direct(const ConvGemmParams& p, hipStream_t stream);
+
 // -------- PLDA training statistics (plda_train.hip; two_cov_plda.py:48-66,95-107,261-275)
 int64_t plda_stats_scratch_doubles(int n, int dim);
 hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets,
