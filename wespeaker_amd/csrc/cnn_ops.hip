@@ -19,48 +19,67 @@ __device__ __forceinline__ float wave_sum32(float v) {
 
 // -------------------------------------------------------------------------------------- stem
 // out[((b*F + f)*T + t)*C + c] = relu(b[c] + sum_{dy,dx} w[c][dy*3+dx] * img(f+dy-1, t+dx-1)),
-// img(f, t) = feats[(b*T + t)*F + f].  One thread per (pixel, 4 channels): 16-B coalesced stores.
-__global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ feats, int T,
-                                                           int F, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int C,
-                                                           float* __restrict__ out,
-                                                           uint16_t* __restrict__ out16,
-                                                           long long total) {
-  const int c4n = C >> 2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % c4n) * 4;
-    const long long pix = i / c4n;
-    const int t = (int)(pix % T);
-    const long long bf = pix / T;
-    const int f = (int)(bf % F);
-    const long long b = bf / F;
-    const float* img = feats + b * T * F;
-    float in[9];
+// img(f, t) = feats[(b*T + t)*F + f];  C = 32.
+// One workgroup = an 8 (f) x 32 (t) tile of output pixels, one thread per pixel and all 32 channels:
+// the 10 x 34 input patch and the 32 x 9 weights are staged in LDS once (weights are read back as
+// wave-uniform broadcasts), each thread keeps its 9 inputs in registers and writes its pixel's 32
+// channels as one contiguous run (64 B binary16 / 128 B fp32; 32 neighbouring threads -> 2-4 KB).
+// The tensor it writes (B*F*T*32 values) is 40x the size of what it reads: store-bound.
+constexpr int ST_FH = 8, ST_TW = 32;
+
+template <bool OUT16>
+__global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __restrict__ feats, int T,
+                                                                int F, const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out,
+                                                                uint16_t* __restrict__ out16) {
+  __shared__ float in_s[ST_FH + 2][ST_TW + 2 + 1];
+  __shared__ __attribute__((aligned(16))) float w_s[32 * 12];     // [c][12]: 9 taps + bias + pad
+  const int t0 = blockIdx.x * ST_TW, f0 = blockIdx.y * ST_FH, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const float* img = feats + (long long)b * T * F;
+  for (int i = tid; i < (ST_FH + 2) * (ST_TW + 2); i += 256) {
+    const int tx = i / (ST_FH + 2), fy = i - tx * (ST_FH + 2);   // f fastest: contiguous in feats
+    const int tt = t0 + tx - 1, ff = f0 + fy - 1;
+    in_s[fy][tx] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? img[(long long)tt * F + ff] : 0.f;
+  }
+  for (int i = tid; i < 32 * 12; i += 256) {
+    const int c = i / 12, k = i - c * 12;
+    w_s[i] = k < 9 ? w[c * 9 + k] : (k == 9 ? bias[c] : 0.f);
+  }
+  __syncthreads();
+  const int tx = tid & (ST_TW - 1), fy = tid / ST_TW;
+  const int t = t0 + tx, f = f0 + fy;
+  float in[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int ff = f + dy - 1, tt = t + dx - 1;
-        in[dy * 3 + dx] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? img[(long long)tt * F + ff] : 0.f;
-      }
-    f32x4 acc;
+    for (int dx = 0; dx < 3; ++dx) in[dy * 3 + dx] = in_s[fy + dy][tx + dx];
+  if (t >= T || f >= F) return;
+  const long long pix = ((long long)b * F + f) * T + t;
+  typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* wc = w + (c + q) * 9;
-      float s = 0.f;
+  for (int c0 = 0; c0 < 32; c0 += 8) {
+    float r[8];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) s += wc[k] * in[k];
-      acc[q] = fmaxf(s + bias[c + q], 0.f);
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12]);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12 + 4]);
+      const f32x4 wc = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12 + 8]);
+      float sacc = wc[1];                          // bias
+      sacc += wa[0] * in[0] + wa[1] * in[1] + wa[2] * in[2] + wa[3] * in[3];
+      sacc += wb[0] * in[4] + wb[1] * in[5] + wb[2] * in[6] + wb[3] * in[7];
+      sacc += wc[0] * in[8];
+      r[q] = fmaxf(sacc, 0.f);
     }
-    if (out16) {                                  // f16 back-end: binary16 activations only
-      typedef _Float16 f16x4c __attribute__((ext_vector_type(4)));
-      f16x4c hv;
+    if (OUT16) {
+      f16x8c hv;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hv[q] = (_Float16)acc[q];
-      *reinterpret_cast<f16x4c*>(out16 + pix * C + c) = hv;
+      for (int q = 0; q < 8; ++q) hv[q] = (_Float16)r[q];
+      *reinterpret_cast<f16x8c*>(out16 + pix * 32 + c0) = hv;
     } else {
-      *reinterpret_cast<f32x4*>(out + pix * C + c) = acc;
+      *reinterpret_cast<f32x4*>(out + pix * 32 + c0) = (f32x4){r[0], r[1], r[2], r[3]};
+      *reinterpret_cast<f32x4*>(out + pix * 32 + c0 + 4) = (f32x4){r[4], r[5], r[6], r[7]};
     }
   }
 }
@@ -68,12 +87,14 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
                                const float* b, int C, float* out, hipStream_t stream,
                                uint16_t* out16) {
-  if (C & 3) return hipErrorInvalidValue;
-  const long long total = (long long)B * F * T * (C >> 2);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(stem_conv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feats, T, F,
-                     w, b, C, out, out16, total);
+  if (C != 32 || B <= 0) return C != 32 ? hipErrorInvalidValue : hipSuccess;
+  dim3 grid((T + ST_TW - 1) / ST_TW, (F + ST_FH - 1) / ST_FH, B);
+  if (out16)
+    hipLaunchKernelGGL(stem_conv3x3_tile_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
+                       out16);
+  else
+    hipLaunchKernelGGL(stem_conv3x3_tile_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
+                       out16);
   return hipGetLastError();
 }
 
