@@ -41,7 +41,7 @@ struct CamppModel : ModelBase {
   static constexpr int kDil[3] = {1, 2, 2};
   static constexpr int kSplitK = 8;
   float *fa = nullptr, *fb = nullptr, *fc = nullptr, *xbuf = nullptr, *xbuf2 = nullptr, *hbuf = nullptr,
-        *mask = nullptr, *pooled = nullptr, *partial = nullptr;
+        *mask = nullptr, *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
   int max_segs = 1;
 
   CamppModel(int fd, int ed) : ModelBase("CAMPPlus", fd, ed) {}
@@ -142,11 +142,13 @@ struct CamppModel : ModelBase {
     size_t o_fa = take(img), o_fb = take(img / 2 + 64), o_fc = take(img / 2 + 64),
            o_x = take(Mp * 1024), o_x2 = take(Mp * 1024), o_h = take(Mp * 128),
            o_mask = take((size_t)maxB * max_segs * 32), o_pool = take((size_t)maxB * 1024),
+           o_colsum = take(((Mp + 63) / 64 + 2) * 2 * 128),
            o_part = take((size_t)kSplitK * maxB * embed_dim),
            o_feats = take((size_t)maxB * maxT * feat_dim);
     if ((err = upload_and_alloc(total))) return err;
     float* base = ws.as<float>();
     fa = base + o_fa; fb = base + o_fb; fc = base + o_fc; xbuf = base + o_x; xbuf2 = base + o_x2;
+    colsum = base + o_colsum;
     hbuf = base + o_h; mask = base + o_mask; pooled = base + o_pool; partial = base + o_part;
     feats_ws = base + o_feats;
     return 0;
@@ -216,9 +218,16 @@ struct CamppModel : ModelBase {
         // BN-ReLU -> 1x1 (Cin -> 128) -> BN -> ReLU
         ConvGemmParams p1 = conv1d(L.lin1, X, ldx, 0, hbuf, 128, 0, B, Tp, 1, ACT_RELU);
         p1.pre_scale = arena.at(L.pre_s); p1.pre_shift = arena.at(L.pre_b);
+        // one context segment (T' <= 100) and >= 64 rows per utterance: the time mean of the
+        // bottleneck output comes out of this GEMM's epilogue, the mask kernel never reads hbuf
+        const bool ctx_from_colsum = segs == 1 && Tp >= 64;
+        if (ctx_from_colsum) p1.colsum = colsum;
         WS_LAUNCH(gemm(p1, st));
         // context mask m[b][seg][32]
-        WS_LAUNCH(other(4.0 * B * (double)Tp * 128, st, [&] {
+        WS_LAUNCH(other(ctx_from_colsum ? 0.0 : 4.0 * B * (double)Tp * 128, st, [&] {
+          if (ctx_from_colsum)
+            return launch_cam_context_from_colsum(colsum, B, Tp, 128, arena.at(L.cw1), arena.at(L.cb1), 64,
+                                                  arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
           return launch_cam_context(hbuf, 128, B, Tp, 128, 100, arena.at(L.cw1), arena.at(L.cb1), 64,
                                     arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
         }));

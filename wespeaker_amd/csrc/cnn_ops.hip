@@ -232,6 +232,56 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
   }
 }
 
+// Single-segment case (T <= seg_len, i.e. utterances up to 4 s at the TDNN's stride 2): the segment
+// mean equals the global mean, and that comes from the producing GEMM's per-64-row column sums
+// (ConvGemmParams::colsum) -- h is not read again.  grid = B, block = 128 (C <= 128, hidden <= 128).
+__global__ __launch_bounds__(128) void cam_context_from_colsum_kernel(
+    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
+    const float* __restrict__ b1, int hidden, const float* __restrict__ w2,
+    const float* __restrict__ b2, int Cout, float* __restrict__ mask) {
+  __shared__ float ctx[128], hid[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long r0 = (long long)b * T, r1 = r0 + T - 1;
+  const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
+  if (tid < C) {
+    float v = 0.f;
+    for (int tm = t_first; tm <= t_last; ++tm) {
+      const int first_img = (int)(((long long)tm * 64) / T);
+      v += colsum[((long long)tm * 2 + (first_img == b ? 0 : 1)) * C + tid];
+    }
+    ctx[tid] = 2.f * v / (float)T;               // global mean + (identical) segment mean
+  }
+  __syncthreads();
+  if (tid < hidden) {                            // hid = relu(W1 ctx + b1): thread per row, 16-B loads
+    const float* wr = w1 + (long long)tid * C;
+    float v = b1[tid];
+    for (int k = 0; k < C; k += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k);
+      v += w4[0] * ctx[k] + w4[1] * ctx[k + 1] + w4[2] * ctx[k + 2] + w4[3] * ctx[k + 3];
+    }
+    hid[tid] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  if (tid < Cout) {                              // m = sigmoid(W2 hid + b2)
+    const float* wr = w2 + (long long)tid * hidden;
+    float v = b2[tid];
+    for (int k = 0; k < hidden; k += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k);
+      v += w4[0] * hid[k] + w4[1] * hid[k + 1] + w4[2] * hid[k + 2] + w4[3] * hid[k + 3];
+    }
+    mask[(long long)b * Cout + tid] = 1.f / (1.f + expf(-v));
+  }
+}
+
+hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
+                                          const float* b1, int hidden, const float* w2, const float* b2,
+                                          int Cout, float* mask, hipStream_t stream) {
+  if (C > 128 || (C & 3) || hidden > 128 || (hidden & 3) || Cout > 128 || T < 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cam_context_from_colsum_kernel, dim3(B), dim3(128), 0, stream, colsum, T, C, w1, b1,
+                     hidden, w2, b2, Cout, mask);
+  return hipGetLastError();
+}
+
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
                               const float* w1, const float* b1, int hidden, const float* w2,
                               const float* b2, int Cout, float* mask, hipStream_t stream) {

@@ -130,6 +130,9 @@ hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, in
                            hipStream_t stream);
 // CAM++ context (campplus.py:108-135): ctx = mean_T(h) + segmean_100(h); m = sigmoid(W2 relu(W1 ctx + b1) + b2)
 // h: [B*T][C] (C = 128); mask out: [B][segs][Cout]
+hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
+                                          const float* b1, int hidden, const float* w2, const float* b2,
+                                          int Cout, float* mask, hipStream_t stream);
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
                               const float* w1, const float* b1, int hidden, const float* w2,
                               const float* b2, int Cout, float* mask, hipStream_t stream);
