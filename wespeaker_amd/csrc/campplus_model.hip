@@ -222,6 +222,10 @@ struct CamppModel : ModelBase {
         // bottleneck output comes out of this GEMM's epilogue, the mask kernel never reads hbuf
         const bool ctx_from_colsum = segs == 1 && Tp >= 64;
         if (ctx_from_colsum) p1.colsum = colsum;
+        // f16 back-end: the bottleneck output feeds only the k3 conv (and the statistics above): keep it
+        // as binary16 (hbuf reused), read by the conv DMA kernel
+        const bool h_half = f16io && ctx_from_colsum;
+        if (h_half) { p1.D = nullptr; p1.D16 = reinterpret_cast<uint16_t*>(hbuf); p1.ldd16 = 128; }
         WS_LAUNCH(gemm(p1, st));
         // context mask m[b][seg][32]
         WS_LAUNCH(other(ctx_from_colsum ? 0.0 : 4.0 * B * (double)Tp * 128, st, [&] {
@@ -234,6 +238,7 @@ struct CamppModel : ModelBase {
         // local k3 dilated conv 128 -> 32, times the mask, appended at channel offset cin
         ConvGemmParams p2 = conv1d(L.local, hbuf, 128, 0, X, ldx, L.cin, B, Tp, kDil[k], ACT_NONE);
         p2.seg_scale = mask; p2.seg_len = 100; p2.segs_per_img = segs;
+        if (h_half) { p2.A16 = reinterpret_cast<const uint16_t*>(hbuf); p2.lda16 = 128; }
         WS_LAUNCH(gemm(p2, st));
       }
       ch += 32 * kLayers[k];
