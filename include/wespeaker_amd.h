@@ -194,6 +194,15 @@ int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets
                   const double* mean_vec, int normalize_length, double* class_mean, double* scatter,
                   double* scratch, int64_t scratch_doubles, ws_stream stream);
 
+/* One link of the embedding-processing chain (wespeaker/utils/embedding_processing.py: MeanSubtraction
+ * :204-216, Length_norm :181-195, Lda.__call__ :177-178) applied to n rows:
+ *   y = (x - sub) M ;  if normalize: y /= |y|.
+ * x DEVICE (n, d_in) float32 (x_is_f64 = 0) or float64 (1); sub DEVICE float64[d_in] or NULL;
+ * M DEVICE float64 (d_in, d_out) row-major or NULL (identity, d_out must equal d_in);
+ * out DEVICE float64 (n, d_out).  The LDA / mean statistics come from ws_plda_stats. */
+int ws_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub, const double* M,
+                   int d_out, int normalize, double* out, ws_stream stream);
+
 /* ------------------------------------------------------------------ cosine scoring + AS-norm
  * Stateless device functions replacing the numpy/sklearn back-end of wespeaker/bin/score.py:38-72
  * (trials_cosine_score) and wespeaker/bin/score_norm.py:26-36,93-115 (get_mean_std + the

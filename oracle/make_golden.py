@@ -18,6 +18,9 @@ What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerat
   * plda_train_ref.npz -- the reference's own TwoCovPLDA(scp_file, utt2spk_file, ...).train(3) and
                        .adapt(adapt_scp) run on ark/scp files of the synth_plda_training_set
                        fixture: B, W, mu, psi and LLRs of fixed pairs under the trained / adapted model.
+  * embd_proc_ref.npz -- the reference's own EmbeddingProcessingChain ("mean-subtract | length-norm |
+                       lda --dim 20 | length-norm") built from ark/scp files of the PLDA training
+                       fixture and applied to 24 probe embeddings.
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
 The GPU box has no /root/reference; tests there compare against these committed files.
@@ -168,6 +171,23 @@ def make_plda_train():
     print("plda train: psi[:4]", out["plain/psi"][:4], "adapt psi[:4]", out["plain/adapt_psi"][:4])
 
 
+def make_embd_proc():
+    import tempfile
+    mod = ref_shim.ref_module("wespeaker.utils.embedding_processing")
+    fix = synth.synth_plda_training_set()
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+    with tempfile.TemporaryDirectory() as d:
+        paths = synth.write_plda_training_files(fix, d)
+        chain = ("mean-subtract --scp %s | length-norm | lda --scp %s --utt2spk %s --dim 20 | length-norm"
+                 % (paths["scp"], paths["scp"], paths["utt2spk"]))
+        c = mod.EmbeddingProcessingChain(chain=chain)
+        out = c(probe)
+        np.savez_compressed(os.path.join(GOLD, "embd_proc_ref.npz"), out=out,
+                            mean1=c.chain_of_classes[0].mean, lda_m=c.chain_of_classes[2].m,
+                            lda_abs_colsum=np.abs(c.chain_of_classes[2].lda).sum(0))
+    print("embd proc: out", out.shape, out.dtype)
+
+
 def make_score():
     import tempfile
     score_mod = ref_shim.ref_module("wespeaker.bin.score")
@@ -207,4 +227,5 @@ if __name__ == "__main__":
     make_plda()
     make_score()
     make_plda_train()
+    make_embd_proc()
     print("golden fixtures written to", GOLD)

@@ -727,3 +727,34 @@ def test_full_size_plda_stats_properties():
     # trace identity and a full check through torch's float64 matmul
     assert abs(np.trace(sc) - float((yc * yc).sum())) <= 1e-9 * np.trace(sc)
     assert np.abs(sc - (yc.T @ yc).cpu().numpy()).max() <= 1e-10 * np.abs(sc).max()
+
+
+# ================================================= embedding-processing chain (LDA)
+def test_embedding_processing_chain_matches_reference_golden(tmp_path, golden_dir):
+    """EmbeddingProcessingChain built from ark/scp files (statistics by ws_plda_stats, links applied
+    by ws_rows_affine) against the reference's own chain; eigenvector signs aligned per column."""
+    from oracle import embedding_processing as oproc
+    from wespeaker_amd import embedding_processing as wproc
+    from wespeaker_amd.kaldi_io import read_vec_scp
+    g = np.load(os.path.join(golden_dir, "embd_proc_ref.npz"))
+    fix = synth.synth_plda_training_set()
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+    paths = synth.write_plda_training_files(fix, str(tmp_path))
+    chain_str = ("mean-subtract --scp %s | length-norm | lda --scp %s --utt2spk %s --dim 20 | length-norm"
+                 % (paths["scp"], paths["scp"], paths["utt2spk"]))
+    assert wproc.chain_string_to_dict("a --x 1 | b --y=2")[1] == ['b', {'y': '2'}]
+    chain = wproc.prep_embd_proc(chain_str, str(tmp_path / "chain.pkl"))
+    out = chain(probe)
+    sgn = np.sign(np.sum(out * g["out"], axis=0))
+    assert np.abs(out * sgn - g["out"]).max() <= 1e-5
+    ref, _ = oproc.chain_fit_apply(fix["emb"], fix["spk"], 20, probe)
+    assert np.abs(out * np.sign(np.sum(out * ref, axis=0)) - ref).max() <= 1e-5
+    np.testing.assert_allclose(chain.chain_of_classes[0].mean, g["mean1"], rtol=0, atol=1e-6)
+    # save / load / apply through files (bin/apply_embd_proc.py)
+    res = wproc.apply_embd_proc(str(tmp_path / "chain.pkl"), paths["adapt_scp"], str(tmp_path / "o.ark,scp"))
+    back = np.vstack(list(read_vec_scp(str(tmp_path / "o.scp")).values()))
+    assert back.shape == (300, 20) and np.abs(back - res).max() <= 1e-12
+    assert np.abs(np.linalg.norm(back, axis=1) - 1.0).max() <= 1e-12
+    # update_link: replace the LDA by a 10-dimensional one
+    chain.update_link(2, "lda --scp %s --utt2spk %s --dim 10" % (paths["scp"], paths["utt2spk"]))
+    assert chain(probe).shape == (24, 10)

@@ -231,3 +231,22 @@ def test_plda_training_restatement_vs_reference_golden(golden_dir, tag, sub, nl)
     np.testing.assert_allclose(np.sort(a["psi"]), np.sort(g[tag + "/adapt_psi"]), rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(a["mu"], g[tag + "/adapt_mu"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(llr(a, 1), g[tag + "/adapt_llr"], rtol=0, atol=1e-6)
+
+
+def _align_signs(a, ref):
+    """eigh leaves each LDA eigenvector's sign arbitrary: flip columns of `a` to match `ref`."""
+    s = np.sign(np.sum(a * ref, axis=0))
+    s[s == 0] = 1.0
+    return a * s
+
+
+def test_embedding_processing_restatement_vs_reference_golden(golden_dir):
+    from oracle import embedding_processing as oproc
+    g = np.load(os.path.join(golden_dir, "embd_proc_ref.npz"))
+    fix = synth.synth_plda_training_set()
+    probe, _ = synth.synth_embeddings(24, 64, seed=47)
+    out, (mean1, lda_m, lda) = oproc.chain_fit_apply(fix["emb"], fix["spk"], 20, probe)
+    np.testing.assert_allclose(mean1, g["mean1"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(lda_m, g["lda_m"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.abs(lda).sum(0), g["lda_abs_colsum"], rtol=1e-5)
+    assert np.abs(_align_signs(out, g["out"]) - g["out"]).max() <= 1e-5

@@ -50,6 +50,8 @@ SIGNATURES = {
     "ws_plda_stats_scratch": (c_int64, [c_int, c_int]),
     "ws_plda_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int64, c_void_p]),
+    "ws_rows_affine": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                               c_void_p]),
     "ws_cos_table_rows": (c_int, [c_int]),
     "ws_cos_table_ld": (c_int, [c_int]),
     "ws_cos_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -536,6 +536,18 @@ int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets
   return WS_OK;
 }
 
+int ws_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub, const double* M,
+                   int d_out, int normalize, double* out, ws_stream stream) {
+  if (n == 0) return WS_OK;
+  if (!x || !out || n < 0 || d_in <= 0 || d_out <= 0 || (!M && d_in != d_out)) {
+    set_error("ws_rows_affine: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_rows_affine(x, x_is_f64, n, d_in, sub, M, d_out, normalize, out,
+                                  (hipStream_t)stream));
+  return WS_OK;
+}
+
 // ============================================================================= cosine scoring
 namespace {
 // 256 B of zeros per device for the GEMM's masked loads (lives for the life of the process)

@@ -202,6 +202,10 @@ hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* gr
                              double* class_mean, double* scatter, double* scratch,
                              hipStream_t stream);
 
+hipError_t launch_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub,
+                              const double* M, int d_out, int normalize, double* out,
+                              hipStream_t stream);
+
 // -------- cosine scoring + score normalisation (score.hip; bin/score.py, bin/score_norm.py)
 hipError_t launch_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit,
                               float* mag, hipStream_t stream);

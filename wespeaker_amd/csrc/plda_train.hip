@@ -185,4 +185,61 @@ hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* gr
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// One link of the embedding-processing chain (utils/embedding_processing.py:177-217) applied to rows:
+//   y = (x - sub) [M]      then optionally y /= |y|      (mean-subtract / lda / length-norm)
+// x (n, d_in) float32 or float64, sub float64[d_in] or null, M float64 (d_in, d_out) row-major or null
+// (then d_out == d_in), out float64 (n, d_out).  One workgroup per row; the row sits in LDS as f64.
+template <typename TX>
+__global__ __launch_bounds__(256) void rows_affine_kernel(const TX* __restrict__ x, int d_in,
+                                                          const double* __restrict__ sub,
+                                                          const double* __restrict__ M, int d_out,
+                                                          int normalize, double* __restrict__ out) {
+  extern __shared__ double rowv[];             // v[d_in] | y[d_out] | red[4]
+  double* v = rowv;
+  double* y = rowv + d_in;
+  double* red = y + d_out;
+  const long long r = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int d = tid; d < d_in; d += 256) v[d] = (double)x[r * d_in + d] - (sub ? sub[d] : 0.0);
+  __syncthreads();
+  double ss = 0.0;
+  for (int j = tid; j < d_out; j += 256) {
+    double acc;
+    if (M) {
+      acc = 0.0;
+      for (int d = 0; d < d_in; ++d) acc += v[d] * M[(long long)d * d_out + j];
+    } else {
+      acc = v[j];
+    }
+    y[j] = acc;
+    ss += acc * acc;
+  }
+  double scale = 1.0;
+  if (normalize) {
+    ss = wave_sum_dt(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    scale = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
+  }
+  __syncthreads();
+  for (int j = tid; j < d_out; j += 256) out[r * d_out + j] = y[j] * scale;
+}
+
+hipError_t launch_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub,
+                              const double* M, int d_out, int normalize, double* out,
+                              hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (!M && d_out != d_in) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(d_in + d_out + 4) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  if (x_is_f64)
+    hipLaunchKernelGGL(rows_affine_kernel<double>, dim3(n), dim3(256), lds, stream,
+                       reinterpret_cast<const double*>(x), d_in, sub, M, d_out, normalize, out);
+  else
+    hipLaunchKernelGGL(rows_affine_kernel<float>, dim3(n), dim3(256), lds, stream,
+                       reinterpret_cast<const float*>(x), d_in, sub, M, d_out, normalize, out);
+  return hipGetLastError();
+}
+
 }  // namespace wsamd
