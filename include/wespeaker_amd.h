@@ -97,6 +97,14 @@ int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, fl
 int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
                ws_stream stream);
+/* Polyphase windowed-sinc resampling of one channel: the arithmetic of
+ * torchaudio.transforms.Resample(orig_freq, new_freq) as Speaker.extract_embedding_from_pcm applies it
+ * (cli/speaker.py:157-160).  orig / new are the rates divided by their gcd; kernel DEVICE float32
+ * [new][2 * width + orig] is the filter bank (host-built: wespeaker_amd.audio.resample_kernel);
+ * x DEVICE float32[n_in]; y DEVICE float32[n_out], n_out = ceil(new * n_in / orig). */
+int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int new_rate, int width,
+                float* y, int64_t n_out, ws_stream stream);
+
 /* Chunk-and-average extraction of ONE utterance, the native runtime's
  * SpeakerEngine::ExtractEmbedding(const int16_t*, int, std::vector<float>* avg_emb)
  * (runtime/core/speaker/speaker_engine.cc:83-159; SamplesPerChunk ctor argument speaker_engine.h:29-31).

@@ -758,3 +758,29 @@ def test_embedding_processing_chain_matches_reference_golden(tmp_path, golden_di
     # update_link: replace the LDA by a 10-dimensional one
     chain.update_link(2, "lda --scp %s --utt2spk %s --dim 10" % (paths["scp"], paths["utt2spk"]))
     assert chain(probe).shape == (24, 10)
+
+
+def test_resample_matches_oracle_and_speaker_api(tmp_path):
+    """ws_resample (torchaudio.transforms.Resample arithmetic, cli/speaker.py:157-160) vs the numpy
+    restatement, for down- and up-sampling, and through Speaker.extract_embedding on an 8 kHz file."""
+    import wespeaker_amd
+    from oracle import resample as oresample
+    from wespeaker_amd import audio
+    rng = np.random.RandomState(0)
+    for orig, new, n in [(8000, 16000, 8000), (44100, 16000, 22050), (16000, 8000, 4001), (48000, 16000, 4800)]:
+        x = (rng.randn(n) * 3000).astype(np.float32)
+        got = audio.resample(torch.from_numpy(x), orig, new).cpu().numpy()
+        ref = oresample.resample(x, orig, new)
+        assert got.shape == ref.shape == (-(-new * n // orig),)
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()          # float32 summation order
+    # a pure tone keeps its frequency and amplitude
+    t = np.arange(8000) / 8000.0
+    y = audio.resample(torch.from_numpy(np.sin(2 * np.pi * 440 * t).astype(np.float32)), 8000, 16000).cpu().numpy()
+    t2 = np.arange(y.shape[0]) / 16000.0
+    assert np.abs(y[200:-200] - np.sin(2 * np.pi * 440 * t2)[200:-200]).max() < 2e-2
+    d = str(tmp_path / "ecapa")
+    synth.write_model_dir(d, "ECAPA_TDNN_GLOB_c512", embed_dim=192, seed=42)
+    wav8 = str(tmp_path / "u8k.wav")
+    synth.write_wav(wav8, synth.synth_wav(3, 16000), sample_rate=8000)      # 2 s at 8 kHz
+    emb = wespeaker_amd.load_model(d).extract_embedding(wav8)
+    assert emb.shape == (192,) and bool(torch.isfinite(emb).all())

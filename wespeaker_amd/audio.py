@@ -30,3 +30,55 @@ def load_wav(path: str, normalize: bool = False):
     else:
         raise ValueError("unsupported sample width %d in %s" % (width, path))
     return out, sr
+
+
+# ------------------------------------------------------------------------------------ resampling
+def resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Filter bank of torchaudio.transforms.Resample's default method (sinc_interp_hann), the
+    transform the reference applies at cli/speaker.py:157-160.  torchaudio is a third-party dependency
+    that is not vendored in the reference nor installed here: this restates its published algorithm
+    (functional._get_sinc_resample_kernel) -- float64 construction, float32 result.
+    Returns (kernel float32 [new][2*width+orig], orig, new, width) with the rates divided by their gcd."""
+    import math
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base_freq))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = t * base_freq
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    with np.errstate(invalid="ignore", divide="ignore"):
+        kernels = np.where(t == 0, 1.0, np.sin(t) / t)
+    kernels = kernels * window * scale
+    return kernels.astype(np.float32), orig, new, width
+
+
+def resample(pcm: torch.Tensor, orig_freq: int, new_freq: int, device=None) -> torch.Tensor:
+    """(C, N) or (N,) -> same rank at new_freq, computed by ws_resample on the GPU (float32 like
+    torchaudio); output length ceil(new * N / orig)."""
+    from . import _lib
+    if orig_freq == new_freq:
+        return pcm
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    kern, orig, new, width = resample_kernel(orig_freq, new_freq)
+    kt = torch.from_numpy(kern).to(dev)
+    x = pcm.to(device=dev, dtype=torch.float32)
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x.unsqueeze(0)
+    x = x.contiguous()
+    n_in = int(x.shape[1])
+    n_out = -(-new * n_in // orig)
+    y = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for c in range(x.shape[0]):
+            _lib.check(_lib.lib().ws_resample(_lib.ptr(x[c]), n_in, _lib.ptr(kt), orig, new, width,
+                                              _lib.ptr(y[c]), n_out, _lib.current_stream_ptr(dev)),
+                       "ws_resample")
+        torch.cuda.current_stream(dev).synchronize()
+    return y[0] if squeeze else y

@@ -265,6 +265,17 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
   return WS_OK;
 }
 
+int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int new_rate, int width,
+                float* y, int64_t n_out, ws_stream stream) {
+  if (n_out == 0) return WS_OK;
+  if (!x || !kernel || !y || n_in <= 0 || n_out < 0 || orig <= 0 || new_rate <= 0 || width < 0) {
+    set_error("ws_resample: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_resample(x, n_in, kernel, orig, new_rate, width, y, n_out, (hipStream_t)stream));
+  return WS_OK;
+}
+
 int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
                        int num_samples, int samples_per_chunk, float scale, int window_type,
                        float* emb, ws_stream stream) {

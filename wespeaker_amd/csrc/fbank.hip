@@ -204,6 +204,36 @@ hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ polyphase sinc resampling
+// torchaudio.transforms.Resample as the reference calls it (cli/speaker.py:157-160): output sample
+// n = q * new + ph is  sum_k kernel[ph][k] * x[q * orig + k - width]  (zero outside the signal).
+// kernel: float32 [new][taps], taps = 2 * width + orig.  One thread per output sample.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long long n_in,
+                                                       const float* __restrict__ kern, int orig,
+                                                       int nw, int width, int taps,
+                                                       float* __restrict__ y, long long n_out) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_out) return;
+  const long long q = n / nw;
+  const int ph = (int)(n - q * nw);
+  const float* kr = kern + (long long)ph * taps;
+  const long long base = q * orig - width;
+  float acc = 0.f;
+  for (int k = 0; k < taps; ++k) {
+    const long long i = base + k;
+    if (i >= 0 && i < n_in) acc += kr[k] * x[i];
+  }
+  y[n] = acc;
+}
+
+hipError_t launch_resample(const float* x, long long n_in, const float* kern, int orig, int nw, int width,
+                           float* y, long long n_out, hipStream_t stream) {
+  if (n_out <= 0) return hipSuccess;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, x, n_in,
+                     kern, orig, nw, width, 2 * width + orig, y, n_out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ binary16 im2col (layer 1)
 // one thread per 8 output halfs (16-B store); F % 4 == 0 and ld % 8 == 0
 __global__ __launch_bounds__(256) void im2col_f16_kernel(const float* __restrict__ feats, int T, int F,

@@ -153,6 +153,8 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream);
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream);
+hipError_t launch_resample(const float* x, long long n_in, const float* kern, int orig, int nw, int width,
+                           float* y, long long n_out, hipStream_t stream);
 // binary16 im2col of a k-tap "same" Conv1d over time: out[(b,t)][tap*F + f] = feats[b][t + tap - pad][f]
 // (0 outside the utterance), row length ld (>= taps*F, tail zero filled) -- turns the first TDNN layer
 // into a plain GEMM for the LDS-DMA kernel

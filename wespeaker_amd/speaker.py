@@ -160,9 +160,9 @@ class Speaker:
     def extract_embedding_from_pcm(self, pcm: torch.Tensor, sample_rate: int):
         if self.apply_vad:
             raise NotImplementedError("VAD is outside the MI355X hot path")
-        if sample_rate != self.resample_rate:
-            raise NotImplementedError("resampling (%d -> %d Hz) is not on the MI355X hot path yet"
-                                      % (sample_rate, self.resample_rate))
+        if sample_rate != self.resample_rate:       # cli/speaker.py:157-160 (torchaudio Resample)
+            from .audio import resample
+            pcm = resample(pcm.to(torch.float), sample_rate, self.resample_rate, self.device)
         wav = pcm[0:1] if pcm.dim() == 2 else pcm.unsqueeze(0)
         fe = self._frontend(self.resample_rate)
         emb = self.model.extract(fe, wav, window_type=self.window_type)
@@ -172,7 +172,8 @@ class Speaker:
         """(B, N) equal-length utterances -> (B, E) on the GPU (the batched form of
         extract_embedding_from_pcm; results are identical to B single calls)."""
         if sample_rate != self.resample_rate:
-            raise NotImplementedError("resampling is not on the MI355X hot path yet")
+            from .audio import resample
+            wavs = resample(wavs.to(torch.float), sample_rate, self.resample_rate, self.device)
         return self.model.extract(self._frontend(self.resample_rate), wavs,
                                   window_type=self.window_type)
 
