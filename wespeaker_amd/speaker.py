@@ -188,7 +188,8 @@ class Speaker:
                 names.append(name)
                 pcm, sr = load_wav(wav_path, normalize=self.wavform_norm)
                 if sr != self.resample_rate:
-                    raise NotImplementedError("resampling is not on the MI355X hot path yet")
+                    from .audio import resample
+                    pcm = resample(pcm.to(torch.float), sr, self.resample_rate, self.device).cpu()
                 wavs.append(pcm[0])
         embeddings = [None] * len(names)
         by_len = {}
