@@ -1,5 +1,5 @@
 // Stand-alone timing probe for the conv-GEMM kernel (not part of the product).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip wespeaker_amd/csrc/conv_gemm.hip -o /tmp/gemm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip wespeaker_amd/csrc/conv_gemm.hip wespeaker_amd/csrc/conv3x3_direct.hip -o /tmp/gemm_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -78,20 +78,22 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
   const int li = lane & 31, lh = lane >> 5;
   const int HW = p.Hout * p.Wout;
 
-  // ---------------- epilogue.  C/D layout of the 32x32 MFMA (both back-ends): col = lane & 31,
-  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // ---------------- epilogue.  The kernels issue mfma(W fragment, A fragment): the accumulator block is
+  // C^T[n][m] with the 32x32 C/D layout col = lane & 31 (= output pixel m), row = (reg & 3) +
+  // 8 * (reg >> 2) + 4 * (lane >> 5) (= output channel n).
   if (p.splitk > 1) {
     if (!active) return;
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      const int n = n0 + (wn * TN + in) * 32 + li;
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
+      for (int im = 0; im < TM; ++im) {
+        const int m = m0 + (wm * TM + im) * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int n = n0 + (wn * TN + in) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < p.M && n < p.N) p.partial[((long long)blockIdx.y * p.M + m) * p.N + n] = acc[im][in][r];
         }
+      }
     }
     return;
   }
@@ -106,9 +108,13 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + im) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          Es[row * ES + (wn * TN + in) * 32 + li] = acc[im][in][r];
+        for (int g = 0; g < 4; ++g) {
+          // weights are the MFMA's A operand: a lane holds 4 consecutive output channels (rows of the
+          // C^T block) of ONE output pixel (column li) per register quad -> one 16-B LDS store each
+          const int row = (wm * TM + im) * 32 + li;
+          const int col = (wn * TN + in) * 32 + 8 * g + 4 * lh;
+          *reinterpret_cast<f32x4*>(&Es[row * ES + col]) =
+              (f32x4){acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2], acc[im][in][4 * g + 3]};
         }
   }
   __syncthreads();
@@ -554,7 +560,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
           for (int im = 0; im < TM; ++im)
 #pragma unroll
             for (int in = 0; in < TN; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[in][s], a[im][s], acc[im][in], 0, 0, 0);
       }
     } else {
       // 32x32x16 f16 MFMA: lane (i = l & 31, h = l >> 5) holds k = 8h .. 8h+7 of row/col i
@@ -582,18 +588,18 @@ void conv_gemm_kernel(const ConvGemmParams p) {
           for (int im = 0; im < TM; ++im)
 #pragma unroll
             for (int in = 0; in < TN; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[im], bh[in], acc[im][in], 0, 0, 0);
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[in], al[im], acc[im][in], 0, 0, 0);
 #pragma unroll
           for (int im = 0; im < TM; ++im)
 #pragma unroll
             for (int in = 0; in < TN; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[in], ah[im], acc[im][in], 0, 0, 0);
         }
 #pragma unroll
         for (int im = 0; im < TM; ++im)
 #pragma unroll
           for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[im], bh[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[in], ah[im], acc[im][in], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -758,7 +764,7 @@ void gemm_f16_kernel(const ConvGemmParams p) {
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
-          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[im], b[in], acc[im][in], 0, 0, 0);
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[in], a[im], acc[im][in], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -963,7 +969,7 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
-          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[im], b[in], acc[im][in], 0, 0, 0);
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[in], a[im], acc[im][in], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
