@@ -1,4 +1,4 @@
-// Direct 3x3 convolution, 32 -> 32 channels, on binary16 channels-last maps (f16 back-end).
+// Direct 3x3 convolution, C -> C channels (C = 32 or 64), on binary16 channels-last maps (f16 back-end).
 //
 // ResNet18/34's first stage (wespeaker/models/resnet.py:35-69,163-169: BasicBlock convs on the
 // 32-channel 80 x T map) and CAM++'s FCM head (campplus.py:245-330) are 3x3 convolutions with 32
@@ -14,6 +14,9 @@
 // while the current one is multiplied.  LDS pixels are 64 B; the four 16-B chunks of a pixel are
 // XOR-swizzled by (pixel >> 2) & 3 on the DMA source side and on the reads (ds_read_b128 then hits
 // 16 distinct 16-B slots per lane group up to a 2-way overlap at patch-row boundaries).
+// C = 64 (ResNet stage 2): pixels are 128 B (8 chunks, key (pixel >> 1) & 7) and the workgroup has 8
+// wavefronts = 4 pixel groups x 2 output-channel halves, so that each wavefront's 36 weight fragments
+// (144 VGPRs) still live in registers; the two halves read the same activation fragments.
 #include "kernels.h"
 
 namespace wsamd {
@@ -36,35 +39,44 @@ __device__ __forceinline__ void wait_vm_barrier() {
 
 constexpr int PH = 8, PW = 16;                   // output pixels per patch (rows x cols)
 
-template <int SH, int SW>
-__global__ __launch_bounds__(256, 2) void conv3x3_c32_f16_kernel(const ConvGemmParams p, int pyb, int pxb,
-                                                                 int total) {
+template <int C, int SH, int SW>
+__global__ __launch_bounds__(C == 32 ? 256 : 512, 2) void conv3x3_direct_f16_kernel(const ConvGemmParams p,
+                                                                                    int pyb, int pxb,
+                                                                                    int total) {
+  constexpr int NWV = C == 32 ? 4 : 8;           // wavefronts: 4 pixel groups x (C / 32) channel halves
+  constexpr int CHK = C / 8;                     // 16-B chunks per pixel
+  constexpr int PXP = 64 / CHK;                  // pixels per 1-KiB DMA piece
+  constexpr int KSUB = C / 16;                   // 16-wide k-steps per tap
+  constexpr int KS = 9 * KSUB;                   // k-steps in all
   constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
   constexpr int RP = IH * IW;                    // region pixels
-  constexpr int NP = (RP + 15) / 16;             // 1-KiB pieces (16 pixels each)
-  constexpr int PPW = (NP + 3) / 4;              // pieces per wavefront
+  constexpr int NP = (RP + PXP - 1) / PXP;       // 1-KiB pieces
+  constexpr int PPW = (NP + NWV - 1) / NWV;      // pieces per wavefront
   constexpr int STAGE = NP * 1024;
   extern __shared__ __attribute__((aligned(16))) char lds_d[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = C == 32 ? wave : wave >> 1;     // pixel group (2 patch rows)
+  const int ct = C == 32 ? 0 : wave & 1;         // 32-channel output tile
   const int li = lane & 31, lh = lane >> 5;
+  auto key = [](int q) { return C == 32 ? (q >> 2) & 3 : (q >> 1) & 7; };
 
-  // ---- weights: A fragments of the 18 k-steps (k = 16 s + 8 lh .. +7 of row cout = li)
-  f16x8d wf[18];
+  // ---- weights: A fragments of the k-steps (k = 16 s + 8 lh .. +7 of row cout = 32 ct + li)
+  f16x8d wf[KS];
 #pragma unroll
-  for (int s = 0; s < 18; ++s)
-    wf[s] = *reinterpret_cast<const f16x8d*>(p.Wh + (long long)li * p.ldw + 16 * s + 8 * lh);
+  for (int s = 0; s < KS; ++s)
+    wf[s] = *reinterpret_cast<const f16x8d*>(p.Wh + (long long)(32 * ct + li) * p.ldw + 16 * s + 8 * lh);
 
-  // ---- DMA roles: piece pi covers region pixels 16 pi .. 16 pi + 15, lane -> (pixel, physical chunk)
+  // ---- DMA roles: piece pi covers region pixels PXP pi .., lane -> (pixel, physical chunk)
   int d_ry[PPW], d_rx[PPW], d_c[PPW], d_slot[PPW];
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
     int pi = wave * PPW + k;
     if (pi > NP - 1) pi = NP - 1;                // surplus wavefronts repeat the last piece
-    const int q = pi * 16 + (lane >> 2), pc = lane & 3;
+    const int q = pi * PXP + lane / CHK, pc = lane % CHK;
     d_ry[k] = q < RP ? q / IW : -(1 << 20);      // out of region -> predicate false
     d_rx[k] = q - (q / IW) * IW;
-    d_c[k] = (pc ^ ((q >> 2) & 3)) * 8;          // logical chunk (halfs) stored at physical slot pc
+    d_c[k] = (pc ^ key(q)) * 8;                  // logical chunk (halfs) stored at physical slot pc
     d_slot[k] = pi * 1024;
   }
   auto issue = [&](int patch, int stage) {
@@ -76,19 +88,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_f16_kernel(const ConvGemmP
     for (int k = 0; k < PPW; ++k) {
       const int iy = iy0 + d_ry[k], ix = ix0 + d_rx[k];
       const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-      const uint16_t* src = ok ? p.A16 + (((long long)img * p.Hin + iy) * p.Win + ix) * 32 + d_c[k]
+      const uint16_t* src = ok ? p.A16 + (((long long)img * p.Hin + iy) * p.Win + ix) * C + d_c[k]
                                : reinterpret_cast<const uint16_t*>(p.zeros);
       dma16_direct(src, base + d_slot[k]);
     }
   };
 
-  // ---- compute roles: lane li -> patch pixel (row 2 wave + li / 16, col li % 16)
-  const int ppy = 2 * wave + (li >> 4), ppx = li & 15;
+  // ---- compute roles: lane li -> patch pixel (row 2 pg + li / 16, col li % 16)
+  const int ppy = 2 * pg + (li >> 4), ppx = li & 15;
   const int q0 = ppy * SH * IW + ppx * SW;       // region pixel of tap (0, 0)
-  // per-channel epilogue constants: after the lane exchange a lane owns channels 16 lh .. 16 lh + 15
-  float bias[16];
+  // per-channel epilogue constants: after the lane exchange a lane owns channels 32 ct + 16 lh .. + 15
+  const int ch0 = 32 * ct + 16 * lh;
+  // (C = 64 has no registers to spare for the bias: it is re-read from L1/L2 per patch there)
+  float bias[C == 32 ? 16 : 1];
+  if constexpr (C == 32) {
 #pragma unroll
-  for (int c = 0; c < 16; ++c) bias[c] = p.bias ? p.bias[16 * lh + c] : 0.f;
+    for (int c = 0; c < 16; ++c) bias[c] = p.bias ? p.bias[ch0 + c] : 0.f;
+  }
 
   int stage = 0;
   int patch = blockIdx.x;
@@ -108,16 +124,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_f16_kernel(const ConvGemmP
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int q = q0 + (tap / 3) * IW + (tap % 3);
-      const int key = (q >> 2) & 3;
+      const int kq = key(q);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int c = half * 2 + lh;
-        const f16x8d a = *reinterpret_cast<const f16x8d*>(base + q * 64 + ((c ^ key) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2 * tap + half], a, acc, 0, 0, 0);
+      for (int sub = 0; sub < KSUB; ++sub) {
+        const int c = sub * 2 + lh;
+        const f16x8d a = *reinterpret_cast<const f16x8d*>(base + q * (C * 2) + ((c ^ kq) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap * KSUB + sub], a, acc, 0, 0, 0);
       }
     }
-    // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh.  Exchange quads with
-    // lane ^ 32 so that lh = 0 owns channels 0..15 and lh = 1 owns 16..31 (contiguous 32 B each).
+    // C^T layout: column = pixel li, rows (channels of this tile) = (r & 3) + 8 (r >> 2) + 4 lh.  Exchange
+    // with lane ^ 32 so that lh = 0 owns channels 0..15 and lh = 1 owns 16..31 (contiguous 32 B each).
     float v[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -133,20 +149,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_f16_kernel(const ConvGemmP
     if (oy < p.Hout && ox < p.Wout) {
       const long long m = ((long long)img * p.Hout + oy) * p.Wout + ox;
       if (p.residual16) {
-        const f16x8d r0 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + 16 * lh);
-        const f16x8d r1 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + 16 * lh + 8);
+        const f16x8d r0 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + ch0);
+        const f16x8d r1 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + ch0 + 8);
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[c] += (float)r0[c]; v[8 + c] += (float)r1[c]; }
+      }
+      if constexpr (C != 32) {
+        if (p.bias) {
+#pragma unroll
+          for (int c = 0; c < 16; c += 4) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch0 + c);
+            v[c] += b4.x; v[c + 1] += b4.y; v[c + 2] += b4.z; v[c + 3] += b4.w;
+          }
+        }
       }
       f16x8d o0, o1;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        float a = v[c] + bias[c], b = v[8 + c] + bias[8 + c];
+        float a = v[c], b = v[8 + c];
+        if constexpr (C == 32) { a += bias[c]; b += bias[8 + c]; }
         if (p.act == ACT_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
         o0[c] = (_Float16)a; o1[c] = (_Float16)b;
       }
-      *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + 16 * lh) = o0;
-      *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + 16 * lh + 8) = o1;
+      *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + ch0) = o0;
+      *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + ch0 + 8) = o1;
     }
     __syncthreads();                             // everyone is done with this stage before it is refilled
     stage ^= 1;
@@ -154,21 +180,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_f16_kernel(const ConvGemmP
 }
 
 bool conv3x3_direct_supported(const ConvGemmParams& p) {
+  const bool c32 = p.Cin == 32 && p.N == 32 && p.K == 288;
+  const bool c64 = p.Cin == 64 && p.N == 64 && p.K == 576 && p.stride_h == 1 && p.stride_w == 1;   // strided regions would not fit LDS
   return p.prec == 2 && p.A16 && p.D16 && !p.D && !p.A2 && !p.pre_scale && p.kh == 3 && p.kw == 3 &&
-         p.dil_h == 1 && p.dil_w == 1 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 32 && p.N == 32 &&
-         p.lda16 == 32 && p.ldd16 == 32 && p.a_off == 0 && p.d_off == 0 && p.K == 288 && p.ldw >= 288 &&
+         p.dil_h == 1 && p.dil_w == 1 && p.pad_h == 1 && p.pad_w == 1 && (c32 || c64) &&
+         p.lda16 == p.Cin && p.ldd16 == p.N && p.a_off == 0 && p.d_off == 0 && p.ldw >= p.K &&
          (p.stride_h == 1 || p.stride_h == 2) && (p.stride_w == 1 || p.stride_w == 2) &&
          !(p.stride_h == 1 && p.stride_w == 2) && !p.residual && !p.colsum && !p.pool_partial &&
          !p.seg_scale && !p.post_scale && !p.bias_img && !p.D2 && p.splitk <= 1 && p.m_begin == 0 &&
-         p.act != ACT_TANH && (!p.residual16 || (p.ldr == 32 && p.r_off == 0));
+         p.act != ACT_TANH && (!p.residual16 || (p.ldr == p.N && p.r_off == 0));
 }
 
-template <int SH, int SW>
+template <int C, int SH, int SW>
 static hipError_t launch_direct(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
-  constexpr int NP = (IH * IW + 15) / 16;
+  constexpr int PXP = 64 / (C / 8);
+  constexpr int NP = (IH * IW + PXP - 1) / PXP;
   constexpr size_t lds = 2 * (size_t)NP * 1024;
-  auto kern = conv3x3_c32_f16_kernel<SH, SW>;
+  auto kern = conv3x3_direct_f16_kernel<C, SH, SW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -187,17 +216,21 @@ static hipError_t launch_direct(const ConvGemmParams& p, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess)
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  const size_t per_cu = 160 * 1024 / lds;             // LDS limit; the ~170 VGPRs allow 2 workgroups per CU
-  long long blocks = (long long)cus * (per_cu < 2 ? per_cu : 2);
+  // resident workgroups per CU: the VGPR budget allows 8 wavefronts (2 x 4 waves for C = 32, 1 x 8 for 64)
+  const size_t by_lds = 160 * 1024 / lds;
+  const size_t by_regs = C == 32 ? 2 : 1;
+  long long blocks = (long long)cus * (by_lds < by_regs ? by_lds : by_regs);
   if (blocks > total) blocks = total;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, pyb, pxb, (int)total);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C == 32 ? 256 : 512), lds, stream, p, pyb, pxb,
+                     (int)total);
   return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_direct(const ConvGemmParams& p, hipStream_t stream) {
-  if (p.stride_h == 1) return launch_direct<1, 1>(p, stream);
-  if (p.stride_w == 1) return launch_direct<2, 1>(p, stream);
-  return launch_direct<2, 2>(p, stream);
+  if (p.Cin == 64) return launch_direct<64, 1, 1>(p, stream);
+  if (p.stride_h == 1) return launch_direct<32, 1, 1>(p, stream);
+  if (p.stride_w == 1) return launch_direct<32, 2, 1>(p, stream);
+  return launch_direct<32, 2, 2>(p, stream);
 }
 
 }  // namespace wsamd
