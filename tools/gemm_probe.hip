@@ -11,6 +11,7 @@ using namespace wsamd;
 #ifdef WS_TRACE
 namespace wsamd { unsigned long long* trace_buffer_address(); }
 #endif
+namespace wsamd { extern int g_ws_big_tiles; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -124,15 +125,52 @@ int main(int argc, char** argv) {
     if (s.K == 1536 && s.N == 1536) {
       unsigned long long tr[64 * 8];
       CK(hipMemcpy(tr, trace_buffer_address(), sizeof(tr), hipMemcpyDeviceToHost));
+      printf("  marks: prologue %lld  loop %lld  epilogue %lld\n", (long long)(tr[63 * 8 + 1] - tr[63 * 8]),
+             (long long)(tr[63 * 8 + 2] - tr[63 * 8 + 1]), (long long)(tr[63 * 8 + 3] - tr[63 * 8 + 2]));
       for (int k = 2; k < 12; ++k) {
         printf("  it %2d:", k);
-        for (int j = 1; j < (getenv("PROBE_A16") ? 4 : 6); ++j)
+        for (int j = 1; j < (getenv("PROBE_STAMPS") ? atoi(getenv("PROBE_STAMPS")) : getenv("PROBE_A16") ? 4 : 6); ++j)
           printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));
         printf("  | loop %6lld\n", (long long)(tr[(k + 1) * 8] - tr[k * 8]));
       }
 
     }
 #endif
+    if (getenv("PROBE_XCMP") && s.taps == 1 && s.N >= 1024) {
+      // the same launch through the 128x128 kernel and through tile mode PROBE_XCMP, whole outputs compared
+      std::vector<float> r0((size_t)s.M * s.N), r1((size_t)s.M * s.N);
+      const int keep = g_ws_big_tiles;
+      for (int rep = 0; rep < 3; ++rep) {
+        g_ws_big_tiles = 0;
+        CK(hipMemset(D, 0xff, r0.size() * 4));
+        CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r0.data(), D, r0.size() * 4, hipMemcpyDeviceToHost));
+        g_ws_big_tiles = atoi(getenv("PROBE_XCMP"));
+        CK(hipMemset(D, 0xff, r0.size() * 4));
+        CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r1.data(), D, r1.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0.0; size_t ndiff = 0, nnan = 0;
+        for (size_t i = 0; i < r0.size(); ++i) {
+          if (r1[i] != r1[i]) { ++nnan; continue; }
+          if (r0[i] != r1[i]) { ++ndiff; const double e = fabs((double)r0[i] - r1[i]) / (fabs((double)r0[i]) + 1.0); if (e > worst) worst = e; }
+        }
+        printf("  xcmp[%d] %s: %zu of %zu differ, worst rel %.3e, nan %zu\n", rep, s.name, ndiff, r0.size(), worst, nnan);
+      }
+      g_ws_big_tiles = keep;
+    }
+    if (getenv("PROBE_HASH") && s.taps == 1) {
+      // full-output hash over repeated launches: equal across tile shapes (same k order) and across runs
+      std::vector<float> hd((size_t)s.M * s.N);
+      for (int rep = 0; rep < atoi(getenv("PROBE_HASH")); ++rep) {
+        CK(hipMemset(D, 0xff, hd.size() * 4));
+        CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hd.data(), D, hd.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long hsh = 1469598103934665603ull;
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(hd.data());
+        for (size_t i = 0; i < hd.size(); ++i) { hsh ^= u[i]; hsh *= 1099511628211ull; }
+        printf("  hash[%d] %s %016llx\n", rep, s.name, hsh);
+      }
+    }
     printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e  conv-vs-f32A %.2e\n", s.name,
            s.M, s.N, s.K, s.taps, us, tf, max_err, conv_diff);
   }

@@ -66,11 +66,14 @@ constexpr size_t tile_lds_bytes() {
 // `tid` is the thread's index inside the group of 64*WM*WN threads that owns this tile (= threadIdx.x
 // for the one-tile kernels; the 256x256 kernel runs four such groups).  Every thread of the
 // WORKGROUP must call it the same number of times (the barriers are workgroup-wide); a group whose
-// `active` is false only keeps the barriers company.  POOL = false compiles the fused-pooling path out.
-template <int BM, int BN, int WM, int WN, bool POOL = true>
+// `active` is false only keeps the barriers company -- unless it passes `stid` (its index among SNT threads
+// that finish the tile's rows: the 256x256 kernels let both wave rows store each quadrant).  POOL = false
+// compiles the fused-pooling path out.
+template <int BM, int BN, int WM, int WN, bool POOL = true, int SNT = 64 * WM * WN>
 __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                              float* lds, int m0, int n0, int tid, bool active = true) {
+                                              float* lds, int m0, int n0, int tid, bool active = true,
+                                              int stid = -1) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
@@ -120,8 +123,11 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
   __syncthreads();
   {
     constexpr int C4 = BN / 4;                 // float4 columns per tile row
-    constexpr int RPP = NT / C4;               // rows per pass
-    const int c4 = tid % C4, rr = tid / C4;
+    // the threads that finish rows: the tile's own group, or (256x256 kernels) SNT threads of both wave rows
+    const int st = stid >= 0 ? stid : tid;
+    const bool storer = stid >= 0 ? true : active;
+    constexpr int RPP = SNT / C4;              // rows per pass
+    const int c4 = st % C4, rr = st / C4;
     const int n = n0 + c4 * 4;
     constexpr int NH = BM / 64;                // 64-row halves (column-sum granularity)
     f32x4 cs[NH][2];
@@ -140,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
       // ASTP fused into the logit GEMM: the logits are never written to HBM.  All h rows of a
       // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
       // online-softmax tuples of the (half, image part) groups.
-      if (active && n < p.N) {
+      if (storer && n < p.N) {
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -200,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         }
       }
     } else
-    if (active && n < p.N) {                   // N % 4 == 0 (checked on the host)
+    if (storer && n < p.N) {                   // N % 4 == 0 (checked on the host)
       f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
       if (p.post_scale) {
@@ -267,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
       // plain store per column -> colsum[(tile64*2 + which)][N].
       __syncthreads();                                  // everyone is done reading the E tile
       float* red = lds;                                 // [NH][2][RPP][BN]
-      if (active) {
+      if (storer) {
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
@@ -275,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
             *reinterpret_cast<f32x4*>(&red[((hf * 2 + wh) * RPP + rr) * BN + c4 * 4]) = cs[hf][wh];
       }
       __syncthreads();
-      for (int o = active ? tid : NH * 2 * BN; o < NH * 2 * BN; o += NT) {
+      for (int o = storer ? st : NH * 2 * BN; o < NH * 2 * BN; o += SNT) {
         const int hw = o / BN, col = o - hw * BN;        // hw = hf*2 + which
         float sacc = 0.f;
 #pragma unroll
@@ -300,7 +306,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           *reinterpret_cast<f32x4*>(r0p + 3 * BN) = p2[hf][wh];
         }
       __syncthreads();
-      for (int o = tid; o < NH * 2 * BN; o += NT) {
+      for (int o = st; o < NH * 2 * BN; o += SNT) {
         const int hw = o / BN, col = o - hw * BN;
         float mx = -1e30f;
 #pragma unroll
@@ -639,9 +645,12 @@ unsigned long long* trace_buffer_address() {
   return p;
 }
 #define WS_STAMP(slot)                                                              \
-  if (blockIdx.x == 8 && tid == 0 && kt < 64) g_trace[kt * 8 + (slot)] = __builtin_readcyclecounter();
+  if (blockIdx.x == 8 && tid == 0 && kt < 63) g_trace[kt * 8 + (slot)] = __builtin_readcyclecounter();
+#define WS_MARK(slot) \
+  if (blockIdx.x == 8 && threadIdx.x == 0) g_trace[63 * 8 + (slot)] = __builtin_readcyclecounter();
 #else
 #define WS_STAMP(slot)
+#define WS_MARK(slot)
 #endif
 
 template <int BM, int BN>
@@ -1028,6 +1037,202 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---- 256x256 tile, phase-staggered pipeline (plain GEMM on binary16 activations) -----------------------
+// Eight wavefronts (2 x 4, 128x64 outputs each) in two groups that run one barrier interval apart:
+// while one group issues its 8 (or 16) MFMAs of a phase the other one does the phase's LDS fragment
+// reads and LDS-DMA issues, so a SIMD's two resident wavefronts alternate between the matrix pipe and
+// the memory pipes instead of colliding in them.  A K-tile of 64 is four phases (one 64x32 output
+// quadrant each); its operands are staged as four 16-KiB half-tiles (A0 = row sub-tile 0 of both wave
+// rows, B0 / B1 = column sub-tiles of all four wave columns, A1), each read in exactly one phase
+// (A0+B0 in phase 1, B1 in 2, A1 in 3), so a slot can be refilled two phases after that read:
+//   phase 1 stages B1(kt+1), 2 stages A1(kt+1), 3 stages A0(kt+2), 4 stages B0(kt+2) + vmcnt(4)
+// i.e. loads run 6 phases (~1.5 K-tiles) ahead of their use with two 64-KiB buffers, which is what
+// covers the ~1500-cycle LDS-DMA round trip the 2-stage loop above waits for.
+constexpr size_t f16_p8_lds_bytes() {
+  const size_t stages = 2 * 4 * 16384, epi = 2 * (size_t)128 * (128 + 4) * 4;
+  return stages > epi ? stages : epi;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void raw_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+__global__ __launch_bounds__(512, 1)
+void gemm_f16_p8_kernel(const ConvGemmParams p) {
+  constexpr int HT = 16384, BUF = 4 * HT;        // half-tile, buffer (A0 | B0 | B1 | A1)
+  constexpr int SLOT_A[2] = {0, 3 * HT}, SLOT_B[2] = {HT, 2 * HT};
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.N + 255) / 256;
+  int work;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    work = xcd * q + (xcd < r ? xcd : r) + local;
+  }
+  const int tile_m = work / tiles_n;
+  const int tile_n = work - tile_m * tiles_n;
+  const int m0 = p.m_begin + tile_m * 256, n0 = tile_n * 256;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nk = p.K / 64;
+
+  // DMA sources of this lane: half-tile h, piece 2 wave + j -> local rows 8 (2 wave + j) + lane / 8
+  int a_off32[2][2], w_off32[2][2];
+  {
+    const int rr = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lr = (wave * 2 + j) * 8 + rr;
+        const int c = pc ^ ((lr >> 1) & 7);
+        const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
+        const int m = m0 + trow < p.M ? m0 + trow : p.M - 1;
+        a_off32[h][j] = m * p.lda16 + p.a_off + c * 8;
+        const int tcol = (lr >> 5) * 64 + h * 32 + (lr & 31);
+        const int n = n0 + tcol < p.N ? n0 + tcol : p.N - 1;
+        w_off32[h][j] = n * p.ldw + c * 8;
+      }
+  }
+  auto stage_a = [&](int h, int buf, int k_off) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dma_16B(p.A16 + (unsigned)(a_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
+  };
+  auto stage_b = [&](int h, int buf, int k_off) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dma_16B(p.Wh + (unsigned)(w_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_B[h] + (wave * 2 + j) * 1024);
+  };
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int sw = (li >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks << 1) | lh) ^ sw) << 4;   // bytes
+  const int a_row = (wr * 64 + li) * 128, b_row = (wc * 32 + li) * 128;     // bytes inside a half-tile
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int im = 0; im < 4; ++im)
+#pragma unroll
+    for (int in = 0; in < 2; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+  f16x8 a[2][4], b0[4], b1[4];
+  auto read_a = [&](const char* base, int h) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        a[t][ks] = *reinterpret_cast<const f16x8*>(base + SLOT_A[h] + a_row + t * 32 * 128 + koff[ks]);
+  };
+  auto read_b = [&](const char* base, int h, f16x8* b) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      b[ks] = *reinterpret_cast<const f16x8*>(base + SLOT_B[h] + b_row + koff[ks]);
+  };
+  auto mma = [&](int mh, int in, const f16x8* b) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        acc[2 * mh + t][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks], a[t][ks], acc[2 * mh + t][in], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: all of tile 0, A0 / B0 of tile 1
+  WS_MARK(0)
+  stage_a(0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0); stage_a(1, 0, 0);
+  if (nk > 1) { stage_a(0, 1, 64); stage_b(0, 1, 64); wait_vmcnt<4>(); }
+  else wait_vmcnt<0>();
+  raw_barrier();
+  WS_MARK(1)
+  if (wr == 1) raw_barrier();                    // group 1 runs one barrier interval behind group 0
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const char* base = ldsb + buf * BUF;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    const int k1 = (kt + 1) * 64, k2 = (kt + 2) * 64;
+    // phase 1: quadrant (0, 0)
+    WS_STAMP(0)
+    read_a(base, 0);
+    read_b(base, 0, b0);
+    if (n1) stage_b(1, buf ^ 1, k1);
+    WS_STAMP(1)
+    raw_barrier();
+    WS_STAMP(2)
+    mma(0, 0, b0);
+    WS_STAMP(3)
+    raw_barrier();
+    // phase 2: quadrant (0, 1)
+    WS_STAMP(4)
+    read_b(base, 1, b1);
+    if (n1) stage_a(1, buf ^ 1, k1);
+    WS_STAMP(5)
+    raw_barrier();
+    WS_STAMP(6)
+    mma(0, 1, b1);
+    WS_STAMP(7)
+    raw_barrier();
+    // phase 3: quadrant (1, 1)
+    read_a(base, 1);
+    if (n2) stage_a(0, buf, k2);
+    raw_barrier();
+    mma(1, 1, b1);
+    raw_barrier();
+    // phase 4: quadrant (1, 0); tile kt+1 has landed once every wavefront passed this wait + a barrier
+    if (n2) { stage_b(0, buf, k2); wait_vmcnt<4>(); }
+    else wait_vmcnt<0>();
+    raw_barrier();
+    mma(1, 0, b0);
+    raw_barrier();
+  }
+  if (wr == 0) raw_barrier();
+  __syncthreads();
+  WS_MARK(2)
+  // four 128x128 quadrants, each owned by two wavefronts (a 1 x 2 grid of 128x64); the two quadrants
+  // of a row half run together on separate transpose regions
+  const int qn = wc >> 1;
+  const int tid_q = ((wc & 1) << 6) | lane;
+  float* region = lds + qn * (128 * (128 + 4));
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {
+    gemm_epilogue<128, 128, 1, 2, false, 256>(p, acc, region, m0 + ph * 128, n0 + qn * 128, tid_q, wr == ph,
+                                              (wr << 7) | tid_q);
+    __syncthreads();
+  }
+  WS_MARK(3)
+}
+
+static hipError_t launch_f16_p8(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr size_t lds_bytes = f16_p8_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_p8_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_m = (p.M - p.m_begin + 255) / 256, tiles_n = (p.N + 255) / 256;
+  if (tiles_m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gemm_f16_p8_kernel, dim3(tiles_m * tiles_n), dim3(512), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, bool AF32>
 static hipError_t launch_f16_fast(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_lds_bytes<BM, BN>();
@@ -1080,6 +1285,9 @@ static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t str
   }
 }
 
+// tile-shape switch for the big f16 GEMMs (env WS_BIG_TILES at first use; tools/gemm_probe flips it)
+int g_ws_big_tiles = -1;
+
 template <int PREC>
 static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool simple = !p.pre_scale && !p.A2 && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
@@ -1131,11 +1339,11 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   }
   // 256x256 tiles (one 8-wave workgroup per CU) for whole rounds of the big f16 GEMMs; what is left
   // re-enters below with m_begin set
-  static int big = -1;
+  int& big = g_ws_big_tiles;
   // OFF by default.  Measured in tools/gemm_probe (bare bias/ReLU epilogue): +6 % at N = K = 1536,
   // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
-  if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 0; }
+  if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 2; }
   if (use_dma && big && p.N % 256 == 0 && p.N >= 1024 && !p.pool_partial) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
     const long long rounds = tiles_m * tiles_n / cus;
@@ -1145,7 +1353,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * 8) main_tiles_m = tiles_m;
       ConvGemmParams mainb = p;
       if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
-      hipError_t e = launch_f16_dma<256, 256, 64, 2>(mainb, stream);
+      hipError_t e = big == 2 ? launch_f16_p8(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
       if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
       ConvGemmParams rest = p;
       rest.m_begin = mainb.M;
