@@ -127,7 +127,17 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(tr, trace_buffer_address(), sizeof(tr), hipMemcpyDeviceToHost));
       printf("  marks: prologue %lld  loop %lld  epilogue %lld\n", (long long)(tr[63 * 8 + 1] - tr[63 * 8]),
              (long long)(tr[63 * 8 + 2] - tr[63 * 8 + 1]), (long long)(tr[63 * 8 + 3] - tr[63 * 8 + 2]));
-      for (int k = 2; k < 12; ++k) {
+      printf("  clock: %lld shader ticks in %lld realtime ticks (100 MHz) -> %.0f MHz\n",
+             (long long)(tr[63 * 8 + 3] - tr[63 * 8]), (long long)(tr[63 * 8 + 5] - tr[63 * 8 + 4]),
+             100.0 * (double)(tr[63 * 8 + 3] - tr[63 * 8]) / (double)(tr[63 * 8 + 5] - tr[63 * 8 + 4]));
+      for (int k = 0; k < (getenv("PROBE_ITERS") ? atoi(getenv("PROBE_ITERS")) : 12); ++k) {
+        if (getenv("PROBE_P8")) {
+          const unsigned long long* t = tr + (32 + k) * 8;
+          printf("  kt %2d: P1 mem+bar %5lld mma+bar %5lld | P2 %5lld %5lld | tile %5lld\n", k,
+                 (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]),
+                 (long long)(t[4] - t[0]));
+          continue;
+        }
         printf("  it %2d:", k);
         for (int j = 1; j < (getenv("PROBE_STAMPS") ? atoi(getenv("PROBE_STAMPS")) : getenv("PROBE_A16") ? 4 : 6); ++j)
           printf(" %6lld", (long long)(tr[k * 8 + j] - tr[k * 8 + j - 1]));

@@ -646,10 +646,17 @@ unsigned long long* trace_buffer_address() {
 }
 #define WS_STAMP(slot)                                                              \
   if (blockIdx.x == 8 && tid == 0 && kt < 63) g_trace[kt * 8 + (slot)] = __builtin_readcyclecounter();
-#define WS_MARK(slot) \
-  if (blockIdx.x == 8 && threadIdx.x == 0) g_trace[63 * 8 + (slot)] = __builtin_readcyclecounter();
+#define WS_STAMP2(slot)                                                             \
+  if (blockIdx.x == 8 && tid == 0 && kt < 31) g_trace[(32 + kt) * 8 + (slot)] = __builtin_readcyclecounter();
+#define WS_MARK(slot)                                                                \
+  if (blockIdx.x == 8 && threadIdx.x == 0) {                                          \
+    g_trace[63 * 8 + (slot)] = __builtin_readcyclecounter();                          \
+    if ((slot) == 0) g_trace[63 * 8 + 4] = __builtin_amdgcn_s_memrealtime();         \
+    if ((slot) == 3) g_trace[63 * 8 + 5] = __builtin_amdgcn_s_memrealtime();         \
+  }
 #else
 #define WS_STAMP(slot)
+#define WS_STAMP2(slot)
 #define WS_MARK(slot)
 #endif
 
@@ -1040,14 +1047,18 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
 // ---- 256x256 tile, phase-staggered pipeline (plain GEMM on binary16 activations) -----------------------
 // Eight wavefronts (2 x 4, 128x64 outputs each) in two groups that run one barrier interval apart:
 // while one group issues its 8 (or 16) MFMAs of a phase the other one does the phase's LDS fragment
-// reads and LDS-DMA issues, so a SIMD's two resident wavefronts alternate between the matrix pipe and
-// the memory pipes instead of colliding in them.  A K-tile of 64 is four phases (one 64x32 output
-// quadrant each); its operands are staged as four 16-KiB half-tiles (A0 = row sub-tile 0 of both wave
+// reads, so a SIMD's two resident wavefronts alternate between the matrix pipe and
+// the memory pipes instead of colliding in them.  A K-tile of 64 is two phases (one 64x64 half of the
+// wavefront's outputs each: measured, a barrier interval costs ~110 cycles on top of its MFMAs, so 16
+// MFMAs per phase beat 8); its operands are staged as four 16-KiB half-tiles (A0 = row sub-tile 0 of both wave
 // rows, B0 / B1 = column sub-tiles of all four wave columns, A1), each read in exactly one phase
-// (A0+B0 in phase 1, B1 in 2, A1 in 3), so a slot can be refilled two phases after that read:
-//   phase 1 stages B1(kt+1), 2 stages A1(kt+1), 3 stages A0(kt+2), 4 stages B0(kt+2) + vmcnt(4)
-// i.e. loads run 6 phases (~1.5 K-tiles) ahead of their use with two 64-KiB buffers, which is what
-// covers the ~1500-cycle LDS-DMA round trip the 2-stage loop above waits for.
+// (A0 + B0 + B1 in phase 1, A1 in phase 2 of its tile), so a slot is refilled one phase after that read
+// and the DMA pieces are issued inside the MFMA runs (their ~100-cycle issue cost hides there):
+//   phase 1 of tile kt: vmcnt(6) [retires A1(kt)]       | 16 MFMA + stage A1(kt+1)        -> other buffer
+//   phase 2 of tile kt: vmcnt(2) [retires A0/B0/B1(kt+1)] | 16 MFMA + stage A0, B0, B1(kt+2) -> this buffer
+// i.e. every piece is in flight for ~5 barrier intervals (~3000 cycles) before its first reader, which
+// covers the ~1500-cycle LDS-DMA round trip that the 2-stage loop above waits for.  Reads happen one
+// phase after the wait + barrier that retires their data (MI355X guide: nothing else orders LDS-DMA).
 constexpr size_t f16_p8_lds_bytes() {
   const size_t stages = 2 * 4 * 16384, epi = 2 * (size_t)128 * (128 + 4) * 4;
   return stages > epi ? stages : epi;
@@ -1144,20 +1155,40 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
     for (int ks = 0; ks < 4; ++ks)
       b[ks] = *reinterpret_cast<const f16x8*>(base + SLOT_B[h] + b_row + koff[ks]);
   };
-  auto mma = [&](int mh, int in, const f16x8* b) {
+  // 16 MFMAs of one 64x64 half of the wavefront's outputs (row sub-tile mh x both column sub-tiles) as 8
+  // pairs.  `piece(i)` issues at most one DMA piece after pair i (spread out, each ~60-100-cycle issue
+  // hides under matrix work).  The phase-closing barrier sits BEFORE the last pair: it orders LDS traffic
+  // only, and releasing the other group while this one still has two MFMAs to issue keeps the matrix
+  // pipe fed across the hand-over (measured: a hand-over bubble of ~110 cycles per interval otherwise).
+  auto mma = [&](int mh, const f16x8* bf, const f16x8* bs, int inf, int ins, auto&& piece) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int i = 0; i < 8; ++i) {
+      const f16x8* b = i < 4 ? bf : bs;
+      const int in = i < 4 ? inf : ins, ks = i & 3;
+      if (i == 7) raw_barrier();
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         acc[2 * mh + t][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks], a[t][ks], acc[2 * mh + t][in], 0, 0, 0);
+      if (i < 7) {
+        __builtin_amdgcn_sched_barrier(0);
+        piece(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto piece_a = [&](int h, int j, int buf, int k_off) {
+    dma_16B(p.A16 + (unsigned)(a_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
+  };
+  auto piece_b = [&](int h, int j, int buf, int k_off) {
+    dma_16B(p.Wh + (unsigned)(w_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_B[h] + (wave * 2 + j) * 1024);
+  };
 
-  // prologue: all of tile 0, A0 / B0 of tile 1
+  // prologue: all of tile 0 and A0 / B0 / B1 of tile 1
   WS_MARK(0)
   stage_a(0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0); stage_a(1, 0, 0);
-  if (nk > 1) { stage_a(0, 1, 64); stage_b(0, 1, 64); wait_vmcnt<4>(); }
+  if (nk > 1) { stage_a(0, 1, 64); stage_b(0, 1, 64); stage_b(1, 1, 64); wait_vmcnt<6>(); }
   else wait_vmcnt<0>();
   raw_barrier();
   WS_MARK(1)
@@ -1167,39 +1198,38 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
     const char* base = ldsb + buf * BUF;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
     const int k1 = (kt + 1) * 64, k2 = (kt + 2) * 64;
-    // phase 1: quadrant (0, 0)
-    WS_STAMP(0)
+    // phase 1: row sub-tile 0 x (B0, B1).  Its wait leaves only the six pieces of A0 / B0 / B1(kt+1) in
+    // flight, i.e. retires A1(kt), which phase 2 reads.
+    WS_STAMP2(0)
     read_a(base, 0);
     read_b(base, 0, b0);
-    if (n1) stage_b(1, buf ^ 1, k1);
-    WS_STAMP(1)
-    raw_barrier();
-    WS_STAMP(2)
-    mma(0, 0, b0);
-    WS_STAMP(3)
-    raw_barrier();
-    // phase 2: quadrant (0, 1)
-    WS_STAMP(4)
     read_b(base, 1, b1);
-    if (n1) stage_a(1, buf ^ 1, k1);
-    WS_STAMP(5)
-    raw_barrier();
-    WS_STAMP(6)
-    mma(0, 1, b1);
-    WS_STAMP(7)
-    raw_barrier();
-    // phase 3: quadrant (1, 1)
-    read_a(base, 1);
-    if (n2) stage_a(0, buf, k2);
-    raw_barrier();
-    mma(1, 1, b1);
-    raw_barrier();
-    // phase 4: quadrant (1, 0); tile kt+1 has landed once every wavefront passed this wait + a barrier
-    if (n2) { stage_b(0, buf, k2); wait_vmcnt<4>(); }
+    if (n1) wait_vmcnt<6>();
     else wait_vmcnt<0>();
     raw_barrier();
-    mma(1, 0, b0);
+    WS_STAMP2(1)
+    mma(0, b0, b1, 0, 1, [&](int i) {
+      if (n1 && (i == 1 || i == 4)) piece_a(1, i == 4, buf ^ 1, k1);
+    });
+    // phase 2: row sub-tile 1 x (B1, B0).  Its wait leaves only A1(kt+1)'s two pieces in flight:
+    // A0 / B0 / B1 of tile kt+1 have landed for phase 1 of the next tile.
+    WS_STAMP2(2)
+    read_a(base, 1);
+    if (n1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
     raw_barrier();
+    WS_STAMP2(3)
+    mma(1, b1, b0, 1, 0, [&](int i) {
+      if (n2) {
+        if (i == 0) piece_a(0, 0, buf, k2);
+        if (i == 1) piece_a(0, 1, buf, k2);
+        if (i == 2) piece_b(0, 0, buf, k2);
+        if (i == 3) piece_b(0, 1, buf, k2);
+        if (i == 4) piece_b(1, 0, buf, k2);
+        if (i == 5) piece_b(1, 1, buf, k2);
+      }
+    });
+    WS_STAMP2(4)
   }
   if (wr == 0) raw_barrier();
   __syncthreads();
