@@ -491,6 +491,40 @@ def test_full_size_batch_properties_ecapa():
         ref = oecapa.ecapa_forward(sd, np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])).numpy()
         assert _rel_err(full[rows].cpu().numpy(), ref).max() < 5e-4
         assert bool(torch.isfinite(full).all())
+    # the headline back-end at the headline size (this is the only size at which the wide layer runs on
+    # the phase-staggered 256x256 kernel).  A row's binary16 roundings depend on fp32 summation-order
+    # noise of the column-sum tiles it shares, so batch position moves it by ~1e-4, not 0.
+    model.set_precision("f16")
+    full = model.extract(fe, wav)
+    shuffled = model.extract(fe, wav[perm])
+    assert _rel_err(shuffled.cpu().numpy(), full[perm].cpu().numpy()).max() < F16_REL_TOL
+    assert _cos_err(shuffled.cpu().numpy(), full[perm].cpu().numpy()).max() < 1e-5
+    single = torch.cat([model.extract(fe, wav[i:i + 1]) for i in (0, 131, 255)])
+    assert _rel_err(single.cpu().numpy(), full[[0, 131, 255]].cpu().numpy()).max() < F16_REL_TOL
+    assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL
+    assert _rel_err(full[rows].cpu().numpy(), ref).max() < F16_REL_TOL
+    assert torch.equal(model.extract(fe, wav), full)          # same launch sequence -> same bits
+    assert bool(torch.isfinite(full).all())
+
+
+def test_full_size_ecapa1024_f16_spot_check():
+    """configs[1] (ECAPA-TDNN-1024, 256 x 2 s) on the headline back-end: its 1024-channel layers all run
+    on the phase-staggered 256x256 kernel at this size.  Oracle spot rows + run-to-run bit equality."""
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c1024", 80, 192, seed=11)
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c1024", sd, max_batch=256, max_frames=198)
+    fe = Frontend(16000, 80)
+    wav = device_wavs(256, 32000, model.device, 9)
+    model.set_precision("f16")
+    full = model.extract(fe, wav)
+    rows = [0, 77, 255]
+    ref = oecapa.ecapa_forward(sd, np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])).numpy()
+    assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL
+    assert _rel_err(full[rows].cpu().numpy(), ref).max() < F16_REL_TOL
+    assert torch.equal(model.extract(fe, wav), full)
+    model.set_precision("f16x3")
+    assert _rel_err(model.extract(fe, wav)[rows].cpu().numpy(), ref).max() < 5e-4
 
 
 def test_full_size_plda_one_million_trials():
