@@ -7,7 +7,12 @@ Run on the GPU box (counters in SEPARATE passes, kernel-trace only, as gpurun re
     for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ; do
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$i -- \
           python bench.py --precision f16 --steps 5 --warmup 2 --headline-only ; done
-    python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128" $OUT/pmc_* > profiles/r01_pmc_dominant_kernel_f16.json
+    python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel" $OUT/pmc_* \
+        > profiles/r01_pmc_dominant_kernel_f16.json
+
+The needle may name several kernels ("a|b"): the dominant class of the f16 back-end is the 128x128 LDS-DMA
+GEMM plus the phase-staggered 256x256 GEMM of the wide layer.  Counters are averaged per DISPATCH of any of
+them (bench.py's roofline launches are launch_conv_gemm calls: 10 per step, 11 dispatches).
 
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide
 coalesced read (MI355X_MICROARCH.md, HBM section) and is doubled here; WRITE_SIZE is taken as is.
@@ -21,20 +26,25 @@ import sys
 
 
 def main():
-    prec, needle = sys.argv[1], sys.argv[2]
+    prec, needles = sys.argv[1], sys.argv[2].split("|")
     vals = collections.defaultdict(list)
-    name = None
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = set()
     for d in sys.argv[3:]:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if needle in r["Kernel_Name"]:
-                    name = r["Kernel_Name"]
+                if any(n in r["Kernel_Name"] for n in needles):
+                    names.add(r["Kernel_Name"])
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    per_kernel[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     avg = {k: sum(v) / len(v) for k, v in vals.items()}
     out = {"command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --precision %s "
                       "--steps 5 --warmup 2 --headline-only" % prec,
-           "kernel": name, "launches_profiled": max(len(v) for v in vals.values()),
-           "counters_avg_per_launch": avg}
+           "kernel": sorted(names), "launches_profiled": max(len(v) for v in vals.values()),
+           "counters_avg_per_launch": avg,
+           "per_kernel": {k: {"dispatches": max(len(x) for x in c.values()),
+                              "counters_avg": {cn: sum(x) / len(x) for cn, x in c.items()}}
+                          for k, c in per_kernel.items()}}
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
         out["fetch_bytes_corrected_x2"] = 2 * 1024 * avg["FETCH_SIZE"]
         out["write_bytes"] = 1024 * avg["WRITE_SIZE"]
