@@ -55,8 +55,11 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     per = shard_size(n_total, world)
     width = local.shape[1:]
-    padded = torch.zeros((per,) + tuple(width), dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]] = local
+    if local.shape[0] == per:                     # the usual case: full shard, nothing to pad
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((per,) + tuple(width), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(width), dtype=local.dtype, device=local.device)
     if dist.get_backend(group) == "gloo" and local.is_cuda:
         # gloo has no CUDA all_gather_into_tensor: stage through the host (test / debug path only;
