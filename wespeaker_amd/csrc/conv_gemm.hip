@@ -60,6 +60,13 @@ constexpr size_t tile_lds_bytes() {
   return 2 * stage > epi ? 2 * stage : epi;
 }
 
+#ifdef WS_TRACE
+extern __device__ unsigned long long g_trace[64 * 8];
+#define WS_EMARK(slot) \
+  if (BM == 128 && p.pool_partial && blockIdx.x == 8 && threadIdx.x == 0) g_trace[62 * 8 + (slot)] = __builtin_readcyclecounter();
+#else
+#define WS_EMARK(slot)
+#endif
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the MFMA GEMM kernels: takes the 32x32 accumulator blocks of the workgroup's
 // BM x BN tile, returns after all global stores (it ends on code every thread executes).
@@ -104,6 +111,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
   // finishes 4 consecutive output channels of one row: 16-B global stores, 512 B contiguous per
   // output row, instead of 4-B stores (which are ~6x slower per byte on gfx950).
   constexpr int ES = BN + 4;
+  WS_EMARK(0)
   if (active) {
     float* Es = lds;
 #pragma unroll
@@ -121,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         }
   }
   __syncthreads();
+  WS_EMARK(1)
   {
     constexpr int C4 = BN / 4;                 // float4 columns per tile row
     // the threads that finish rows: the tile's own group, or (256x256 kernels) SNT threads of both wave rows
@@ -147,34 +156,60 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
       // 64-row half are fetched up front (independent 16-B loads in flight), then folded into the
       // online-softmax tuples of the (half, image part) groups.
       if (storer && n < p.N) {
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+        // All h rows of BOTH 64-row halves are requested before anything is consumed, and the
+        // binary16 / fp32 choice is made outside the load loops: with the branch inside, hipcc put an
+        // s_waitcnt vmcnt(0) behind every single load (16 serialized HBM round trips per tile, 2/3 of
+        // this kernel's time by s_memtime stamps).  (Requesting them before the K loop was measured too:
+        // the wait only moves, the tile takes the same 30 k cycles.)
+        constexpr int RI = 64 / RPP;
+        f16x4 hraw[NH][RI];
+        f32x4 hall[NH][RI];
+        if (p.pool_h16) {
+#pragma unroll
+          for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+              const int m = m0 + hf * 64 + rr + RPP * i;
+              const int mc = m < p.M ? m : p.M - 1;
+              hraw[hf][i] = *reinterpret_cast<const f16x4*>(p.pool_h16 + (long long)mc * p.ldh + n);
+            }
+        } else {
+#pragma unroll
+          for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+              const int m = m0 + hf * 64 + rr + RPP * i;
+              const int mc = m < p.M ? m : p.M - 1;
+              hall[hf][i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+            }
+        }
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
           const int mh = m0 + hf * 64;
           const int rb = (mh / HW + 1) * HW - mh;
-          constexpr int RI = 64 / RPP;
           f32x4 hv[RI];
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
-            const int m = mh + rr + RPP * i;
-            const int mc = m < p.M ? m : p.M - 1;
             if (p.pool_h16) {
-              const f16x4 h4 = *reinterpret_cast<const f16x4*>(p.pool_h16 + (long long)mc * p.ldh + n);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) hv[i][q] = (float)h4[q];
+              for (int q = 0; q < 4; ++q) hv[i][q] = (float)hraw[hf][i][q];
             } else {
-              hv[i] = *reinterpret_cast<const f32x4*>(p.pool_h + (long long)mc * p.ldh + n);
+              hv[i] = hall[hf][i];
             }
           }
           // two passes over the lane's RI rows of this half: the maxima of the two image parts first
-          // (LDS reads only), then ONE exponential per logit and no running rescale
+          // (LDS reads only), then ONE exponential per logit and no running rescale.  The column bias is
+          // NOT added: it is constant over the rows, so it cancels in softmax_t (the unfused path adds it
+          // and gets the same weights); the exponent runs in the exp2 domain with the max folded into one
+          // fma, h*h is formed off the critical path -- 8 VALU ops per logit instead of 12 (this loop was
+          // VALU-bound: 12.5 k of the tile's 30 k cycles by s_memtime stamps).
+          constexpr float LOG2E = 1.4426950408889634f;
           f32x4 mx0 = {-1e30f, -1e30f, -1e30f, -1e30f}, mx1 = mx0;
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
             const int rl = rr + RPP * i;
             if (mh + rl < p.M) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]);
               const bool second = rl >= rb;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -185,21 +220,22 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           }
           pm[hf][0] = mx0;
           pm[hf][1] = mx1;
+          const f32x4 ml0 = mx0 * LOG2E, ml1 = mx1 * LOG2E;
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
             const int rl = rr + RPP * i;
             if (mh + rl < p.M) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]) + bias;
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]);
               const bool second = rl >= rb;
+              const f32x4 arg = v * LOG2E - (second ? ml1 : ml0);
+              const f32x4 h = hv[i], hh = h * h;
+              f32x4 pe;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float pe = __expf(v[q] - (second ? mx1[q] : mx0[q]));
-                const float h1 = pe * hv[i][q], h2 = h1 * hv[i][q];
-                if (second) {
-                  p0[hf][1][q] += pe; p1[hf][1][q] += h1; p2[hf][1][q] += h2;
-                } else {
-                  p0[hf][0][q] += pe; p1[hf][0][q] += h1; p2[hf][0][q] += h2;
-                }
+              for (int q = 0; q < 4; ++q) pe[q] = __builtin_amdgcn_exp2f(arg[q]);
+              if (second) {
+                p0[hf][1] += pe; p1[hf][1] += pe * h; p2[hf][1] += pe * hh;
+              } else {
+                p0[hf][0] += pe; p1[hf][0] += pe * h; p2[hf][0] += pe * hh;
               }
             }
           }
@@ -290,10 +326,12 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           p.colsum[((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col] = sacc;
       }
     }
+    WS_EMARK(2)
     if (POOL && p.pool_partial) {
       // fold the RPP row phases: (max, s0, s1, s2) tuples combined with the usual rescaling;
       // one [4]-tuple per (64-row tile, image part, column) -> pool_partial[tile64*2 + which][N][4]
       __syncthreads();
+      WS_EMARK(3)
       float* red = lds;                                 // [NH*2][RPP][4][BN]
 #pragma unroll
       for (int hf = 0; hf < NH; ++hf)
@@ -306,6 +344,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
           *reinterpret_cast<f32x4*>(r0p + 3 * BN) = p2[hf][wh];
         }
       __syncthreads();
+      WS_EMARK(4)
       for (int o = st; o < NH * 2 * BN; o += SNT) {
         const int hw = o / BN, col = o - hw * BN;
         float mx = -1e30f;
@@ -324,6 +363,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
               p.pool_partial + (((long long)(m0 / 64) * 2 + hw) * p.N + n0 + col) * 4) = outv;
         }
       }
+      WS_EMARK(5)
     }
   }
 }
@@ -876,6 +916,7 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   static_assert(A_DMA >= 1 && W_PIECES >= 1 && (CH == 8 || CH == 4), "tile / K-tile combination");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
+  WS_EMARK(6)
 
   const int tid = threadIdx.x;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -1013,6 +1054,7 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
   }
   if constexpr (BM != 256) {
     gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
+    WS_EMARK(7)
   } else {
     // four 128x128 quadrants, each owned by two wavefronts (128x64 each, a 1 x 2 grid); the two
     // quadrants of a row half run together on separate transpose regions
