@@ -250,55 +250,132 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         pb = *reinterpret_cast<const f32x4*>(p.post_shift + n);
       }
       const bool to_d2 = p.D2 && n >= p.d2_col0;
+      auto store_row = [&](int m, const f32x4& v) {
+        if (p.D) *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
+        if (p.D16) {
+          f16x4 hv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+          *reinterpret_cast<f16x4*>(p.D16 + (long long)m * p.ldd16 + p.d_off + n) = hv;
+        }
+        if (to_d2) {
+          *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
+          if (p.D2_16) {
+            f16x4 hv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+            *reinterpret_cast<f16x4*>(p.D2_16 + (long long)m * p.ldd2_16 + p.d2_off + (n - p.d2_col0)) = hv;
+          }
+        }
+      };
 #pragma unroll
       for (int hf = 0; hf < NH; ++hf) {
         // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
         const int mh = m0 + hf * 64;
         const int rb = (mh / HW + 1) * HW - mh;
+        const bool rowops = POOL && (p.bias_img || p.residual || p.residual16 || p.seg_scale);
+        if (!rowops) {
+          // plain layer: row by row, nothing to wait for
 #pragma unroll 4
-        for (int rl = rr; rl < 64; rl += RPP) {
-          const int row = hf * 64 + rl;
-          const int m = m0 + row;
-          if (m >= p.M) break;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
-          if (p.bias_img) v += *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(m / HW) * p.N + n);
-          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long long)m * p.ldr + p.r_off + n);
-          if (p.residual16) {
-            const f16x4 r4 = *reinterpret_cast<const f16x4*>(p.residual16 + (long long)m * p.ldr + p.r_off + n);
+          for (int rl = rr; rl < 64; rl += RPP) {
+            const int row = hf * 64 + rl;
+            const int m = m0 + row;
+            if (m >= p.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
+            if (p.act == ACT_RELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += (float)r4[q];
-          }
-          if (p.act == ACT_RELU) {
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            } else if (p.act == ACT_TANH) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-          } else if (p.act == ACT_TANH) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
-          }
-          if (p.post_scale) v = v * ps + pb;
-          if (p.seg_scale) {
-            const int img = m / HW, ox = (m - img * HW) % p.Wout;
-            v *= *reinterpret_cast<const f32x4*>(
-                p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
-          }
-          if (p.D) *reinterpret_cast<f32x4*>(p.D + (long long)m * p.ldd + p.d_off + n) = v;
-          if (p.D16) {
-            f16x4 hv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
-            *reinterpret_cast<f16x4*>(p.D16 + (long long)m * p.ldd16 + p.d_off + n) = hv;
-          }
-          if (to_d2) {
-            *reinterpret_cast<f32x4*>(p.D2 + (long long)m * p.ldd2 + p.d2_off + (n - p.d2_col0)) = v;
-            if (p.D2_16) {
-              f16x4 hv;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
-              *reinterpret_cast<f16x4*>(p.D2_16 + (long long)m * p.ldd2_16 + p.d2_off + (n - p.d2_col0)) = hv;
+              for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+            }
+            if (p.post_scale) v = v * ps + pb;
+            store_row(m, v);
+            if (p.colsum) {
+              if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
             }
           }
-          if (p.colsum) {
-            if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
+          continue;
+        }
+        // Rows in groups of G: the optional per-row operands (image bias, residuals, segment scale) of a
+        // whole group are requested first, each kind behind ONE wave-uniform branch, then the group is
+        // finished.  With the branches inside the row loop hipcc put an s_waitcnt vmcnt(0) behind every
+        // load -- one exposed HBM round trip per row, which also waited for the previous row's stores.
+        // (POOL = false callers -- the 256x256 kernels, whose accumulators are still live here -- are never
+        // given these operands by the dispatcher; the code is compiled out for them.)
+        constexpr bool ROWOPS = POOL;
+        constexpr int RPT = 64 / RPP, G = RPT < 4 ? RPT : 4;
+#pragma unroll
+        for (int g0 = 0; g0 < RPT; g0 += G) {
+          int mrow[G];
+          f32x4 bi[G], r32[G], ss[G], vv[G];
+          f16x4 r16[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int m = m0 + hf * 64 + rr + RPP * (g0 + g);
+            mrow[g] = m < p.M ? m : p.M - 1;       // clamped: loads stay unconditional, stores are masked
+          }
+          if (ROWOPS && p.bias_img) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              bi[g] = *reinterpret_cast<const f32x4*>(p.bias_img + (long long)(mrow[g] / HW) * p.N + n);
+          }
+          if (ROWOPS && p.residual) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              r32[g] = *reinterpret_cast<const f32x4*>(p.residual + (long long)mrow[g] * p.ldr + p.r_off + n);
+          }
+          if (ROWOPS && p.residual16) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              r16[g] = *reinterpret_cast<const f16x4*>(p.residual16 + (long long)mrow[g] * p.ldr + p.r_off + n);
+          }
+          if (ROWOPS && p.seg_scale) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int img = mrow[g] / HW, ox = (mrow[g] - img * HW) % p.Wout;
+              ss[g] = *reinterpret_cast<const f32x4*>(
+                  p.seg_scale + ((long long)img * p.segs_per_img + ox / p.seg_len) * p.N + n);
+            }
+          }
+          // every row of the group is finished in registers ...
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int rl = rr + RPP * (g0 + g);
+            const int row = hf * 64 + rl;
+            const int m = m0 + row;
+            vv[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
+            if (ROWOPS && p.bias_img) v += bi[g];
+            if (ROWOPS && p.residual) v += r32[g];
+            if (ROWOPS && p.residual16) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += (float)r16[g][q];
+            }
+            if (p.act == ACT_RELU) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+            }
+            if (p.post_scale) v = v * ps + pb;
+            if (ROWOPS && p.seg_scale) v *= ss[g];
+            if (p.colsum) {
+              if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
+            }
+            if constexpr (ROWOPS) vv[g] = v;
+            else store_row(m, v);
+          }
+          // ... and only then stored: a load's first use waits for everything older in the VMEM queue,
+          // which must not include this group's own stores
+          if constexpr (ROWOPS) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int m = m0 + hf * 64 + rr + RPP * (g0 + g);
+              if (m < p.M) store_row(m, vv[g]);
+            }
           }
         }
       }
@@ -1416,7 +1493,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
   if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 2; }
-  if (use_dma && big && p.N % 256 == 0 && p.N >= 1024 && !p.pool_partial) {
+  if (use_dma && big && p.N % 256 == 0 && p.N >= 1024 && !p.pool_partial && !p.bias_img && !p.residual &&
+      !p.residual16 && !p.seg_scale) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
     const long long rounds = tiles_m * tiles_n / cus;
     if (rounds >= 1) {
