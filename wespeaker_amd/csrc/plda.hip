@@ -263,8 +263,43 @@ __global__ __launch_bounds__(256) void plda_gemm_f64_kernel(const double* __rest
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-  // staging: 64 rows x 16 doubles = 1024 doubles per operand; thread -> row tid>>2, 4 doubles
+  // staging: 64 rows x 16 doubles = 1024 doubles per operand; thread -> row tid>>2, 4 doubles.
+  // Rows beyond M / N are clamped (their products reach no stored output), so with K % 16 == 0 the loads
+  // are unconditional 16-byte pairs and the next K-tile is requested before the current one is
+  // multiplied (the predicated scalar form below made hipcc wait after every 8-byte load).
   const int sr = tid >> 2, sk = (tid & 3) * 4;
+  if ((K & 15) == 0) {
+    const int ma = m0 + sr < M ? m0 + sr : M - 1, nb = n0 + sr < N ? n0 + sr : N - 1;
+    const double* ap = A + (long long)ma * K + sk;
+    const double* bp = Bm + (long long)nb * K + sk;
+    double2 a0 = *reinterpret_cast<const double2*>(ap), a1 = *reinterpret_cast<const double2*>(ap + 2);
+    double2 b0 = *reinterpret_cast<const double2*>(bp), b1 = *reinterpret_cast<const double2*>(bp + 2);
+    for (int k0 = 0; k0 < K; k0 += DBK) {
+      As[sr * DS + sk] = a0.x; As[sr * DS + sk + 1] = a0.y; As[sr * DS + sk + 2] = a1.x; As[sr * DS + sk + 3] = a1.y;
+      Bs[sr * DS + sk] = b0.x; Bs[sr * DS + sk + 1] = b0.y; Bs[sr * DS + sk + 2] = b1.x; Bs[sr * DS + sk + 3] = b1.y;
+      __syncthreads();
+      if (k0 + DBK < K) {
+        a0 = *reinterpret_cast<const double2*>(ap + k0 + DBK);
+        a1 = *reinterpret_cast<const double2*>(ap + k0 + DBK + 2);
+        b0 = *reinterpret_cast<const double2*>(bp + k0 + DBK);
+        b1 = *reinterpret_cast<const double2*>(bp + k0 + DBK + 2);
+      }
+#pragma unroll
+      for (int ks = 0; ks < DBK; ks += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int im = 0; im < 2; ++im) a[im] = As[(wm * 32 + im * 16 + li) * DS + ks + lk];
+#pragma unroll
+        for (int in = 0; in < 2; ++in) b[in] = Bs[(wn * 32 + in * 16 + li) * DS + ks + lk];
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+#pragma unroll
+          for (int in = 0; in < 2; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[im], b[in], acc[im][in], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else
   for (int k0 = 0; k0 < K; k0 += DBK) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
