@@ -103,12 +103,27 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
   const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
+  // the tile partials of an utterance (<= 8 for T <= 448; more fall back to the serial loop): all
+  // requested at once, in tile order -- a serial loop exposed one L2 round trip per tile
   for (int c = tid; c < C; c += 512) {
     float v = 0.f;
-    for (int tm = t_first; tm <= t_last; ++tm) {
-      const int first_img = (int)(((long long)tm * 64) / T);
-      const int which = (first_img == b) ? 0 : 1;
-      v += colsum[((long long)tm * 2 + which) * C + c];
+    if (t_last - t_first < 8) {
+      float part[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int tm = t_first + i <= t_last ? t_first + i : t_last;
+        const int first_img = (int)(((long long)tm * 64) / T);
+        const int which = (first_img == b) ? 0 : 1;
+        part[i] = colsum[((long long)tm * 2 + which) * C + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v += t_first + i <= t_last ? part[i] : 0.f;
+    } else {
+      for (int tm = t_first; tm <= t_last; ++tm) {
+        const int first_img = (int)(((long long)tm * 64) / T);
+        const int which = (first_img == b) ? 0 : 1;
+        v += colsum[((long long)tm * 2 + which) * C + c];
+      }
     }
     mean[c] = v / (float)T;
   }
@@ -117,6 +132,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   // FC1: hidden = relu(W1 mean + b1); 4 rows per wavefront pass (4 x C/256 loads in flight)
   for (int j0 = wave * 4; j0 < bott; j0 += 32) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + j0);   // (not behind the lane-0 branch below)
     for (int c = lane * 4; c < C; c += 256) {
       const f32x4 m = *reinterpret_cast<const f32x4*>(&mean[c]);
 #pragma unroll
@@ -128,13 +144,14 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float t = wave_sum(v[q]);
-      if (lane == 0) hidden[j0 + q] = fmaxf(t + b1[j0 + q], 0.f);
+      if (lane == 0) hidden[j0 + q] = fmaxf(t + bias1[q], 0.f);
     }
   }
   __syncthreads();
   // FC2: thread per output channel; its weight row is bott contiguous floats, 8 loads in flight
   for (int c = tid; c < C; c += 512) {
     const float* wr = w2 + (long long)c * bott;
+    const float bias2 = b2[c];
     float v = 0.f;
     for (int k = 0; k < bott; k += 32) {
       f32x4 w[8];
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
         v += w[q][0] * h[0] + w[q][1] * h[1] + w[q][2] * h[2] + w[q][3] * h[3];
       }
     }
-    s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + b2[c])));
+    s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + bias2)));
   }
 }
 
