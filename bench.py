@@ -24,8 +24,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing otherwise fail with
+# hipIpcGetMemHandle: invalid argument); the launch environment exports it, keep it if it does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
