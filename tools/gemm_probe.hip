@@ -11,7 +11,7 @@ using namespace wsamd;
 #ifdef WS_TRACE
 namespace wsamd { unsigned long long* trace_buffer_address(); }
 #endif
-namespace wsamd { extern int g_ws_big_tiles; }
+namespace wsamd { extern int g_ws_big_tiles; extern int g_ws_big_conv; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
                                {50688, 512, 400, 5, "layer1"}, {50688, 64, 192, 3, "res2"}, {50688, 32, 96, 3, "n32 k3"},
                                {49152, 512, 512, 1, "512 M=384t"}, {32768, 512, 512, 1, "512 M=256t"},
                                {16384, 512, 512, 1, "512 M=128t"}, {49152, 1536, 1536, 1, "cat M=384t"}};
+  if (getenv("PROBE_ONLY_CONV2D")) shapes.clear();
   const int prec = argc > 1 ? atoi(argv[1]) : 0;
   float *A, *W, *D, *Z, *bias;
   uint16_t *Wh, *Wl;
@@ -183,6 +184,62 @@ int main(int argc, char** argv) {
     }
     printf("%-10s M=%d N=%d K=%d taps=%d : %8.1f us  %6.1f TF  spot-err %.2e  conv-vs-f32A %.2e\n", s.name,
            s.M, s.N, s.K, s.taps, us, tf, max_err, conv_diff);
+  }
+  if (getenv("PROBE_CONV2D") && prec == 2) {
+    // 2-D 3x3 convolutions on binary16 maps (ResNet stage 4): the phase-staggered 256x256 kernel against the
+    // 128x128 convolution kernel, whole outputs, with and without a binary16 residual; then timing of both
+    struct C2 { int images, Hin, Win, Cin, N, stride; const char* name; };
+    std::vector<C2> cases = {{512, 10, 25, 256, 256, 1, "s4 3x3 256->256"}, {512, 20, 50, 128, 256, 2, "s4 3x3/2 128->256"},
+                             {37, 10, 25, 256, 256, 1, "ragged 37 images"}};
+    uint16_t* A16c; uint16_t* R16; float* D2;
+    const size_t maxIn = 512ull * 20 * 50 * 128 > 512ull * 10 * 25 * 256 ? 512ull * 20 * 50 * 128 : 512ull * 10 * 25 * 256;
+    const size_t maxOut = 512ull * 10 * 25 * 256;
+    CK(hipMalloc(&A16c, maxIn * 2)); CK(hipMalloc(&R16, maxOut * 2)); CK(hipMalloc(&D2, maxOut * 4));
+    {
+      std::vector<uint16_t> hin(maxIn), hr(maxOut);
+      for (size_t i = 0; i < maxIn; ++i) { _Float16 v = (_Float16)h[i % h.size()]; memcpy(&hin[i], &v, 2); }
+      for (size_t i = 0; i < maxOut; ++i) { _Float16 v = (_Float16)h[(i * 7 + 3) % h.size()]; memcpy(&hr[i], &v, 2); }
+      CK(hipMemcpy(A16c, hin.data(), maxIn * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(R16, hr.data(), maxOut * 2, hipMemcpyHostToDevice));
+    }
+    for (auto& c : cases) {
+      ConvGemmParams p; memset(&p, 0, sizeof(p));
+      const int Hout = (c.Hin + 2 - 3) / c.stride + 1, Wout = (c.Win + 2 - 3) / c.stride + 1;
+      p.prec = 2; p.Wh = Wh; p.Wl = Wl; p.W = W; p.A = A;
+      p.A16 = A16c; p.lda16 = c.Cin; p.lda = c.Cin;
+      p.M = c.images * Hout * Wout; p.N = c.N; p.K = 9 * c.Cin; p.Cin = c.Cin; p.ldw = p.K;
+      p.Hin = c.Hin; p.Win = c.Win; p.Hout = Hout; p.Wout = Wout; p.stride_h = p.stride_w = c.stride;
+      p.kh = p.kw = 3; p.dil_h = p.dil_w = 1; p.pad_h = p.pad_w = 1;
+      p.bias = bias; p.act = ACT_RELU; p.splitk = 1; p.zeros = Z;
+      p.D = D2; p.ldd = c.N;
+      const size_t nout = (size_t)p.M * p.N;
+      std::vector<float> r0(nout), r1(nout);
+      for (int res = 0; res < 2; ++res) {
+        p.residual16 = res ? R16 : nullptr; p.ldr = c.N; p.r_off = 0;
+        g_ws_big_conv = 0;
+        CK(hipMemset(D2, 0xff, nout * 4)); CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r0.data(), D2, nout * 4, hipMemcpyDeviceToHost));
+        g_ws_big_conv = 1;
+        CK(hipMemset(D2, 0xff, nout * 4)); CK(launch_conv_gemm(p, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r1.data(), D2, nout * 4, hipMemcpyDeviceToHost));
+        size_t ndiff = 0, nnan = 0; double worst = 0;
+        for (size_t i = 0; i < nout; ++i) {
+          if (r1[i] != r1[i]) { ++nnan; continue; }
+          if (r0[i] != r1[i]) { ++ndiff; const double e = fabs((double)r0[i] - r1[i]) / (fabs((double)r0[i]) + 1.0); if (e > worst) worst = e; }
+        }
+        printf("  conv2d %-20s residual16=%d: %zu of %zu differ, worst rel %.3e, nan %zu\n", c.name, res, ndiff, nout, worst, nnan);
+      }
+      for (int big = 0; big < 2; ++big) {
+        g_ws_big_conv = big;
+        for (int i = 0; i < 3; ++i) CK(launch_conv_gemm(p, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) CK(launch_conv_gemm(p, 0));
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  conv2d %-20s big=%d: %8.1f us  %6.1f TF\n", c.name, big, ms * 50.0, 2.0 * p.M * p.N * p.K / (ms * 50e-6) / 1e12);
+      }
+    }
   }
   return 0;
 }

@@ -76,7 +76,7 @@ extern __device__ unsigned long long g_trace[64 * 8];
 // `active` is false only keeps the barriers company -- unless it passes `stid` (its index among SNT threads
 // that finish the tile's rows: the 256x256 kernels let both wave rows store each quadrant).  POOL = false
 // compiles the fused-pooling path out.
-template <int BM, int BN, int WM, int WN, bool POOL = true, int SNT = 64 * WM * WN>
+template <int BM, int BN, int WM, int WN, bool POOL = true, int SNT = 64 * WM * WN, bool ROWOPS_ = POOL>
 __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                               float* lds, int m0, int n0, int tid, bool active = true,
@@ -273,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
         const int mh = m0 + hf * 64;
         const int rb = (mh / HW + 1) * HW - mh;
-        const bool rowops = POOL && (p.bias_img || p.residual || p.residual16 || p.seg_scale);
+        const bool rowops = ROWOPS_ && (p.bias_img || p.residual || p.residual16 || p.seg_scale);
         if (!rowops) {
           // plain layer: row by row, nothing to wait for
 #pragma unroll 4
@@ -303,8 +303,9 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         // load -- one exposed HBM round trip per row, which also waited for the previous row's stores.
         // (POOL = false callers -- the 256x256 kernels, whose accumulators are still live here -- are never
         // given these operands by the dispatcher; the code is compiled out for them.)
-        constexpr bool ROWOPS = POOL;
-        constexpr int RPT = 64 / RPP, G = RPT < 4 ? RPT : 4;
+        constexpr bool ROWOPS = ROWOPS_;
+        constexpr int GMAX = SNT == 64 * WM * WN ? 4 : 2;     // (256x256 kernels: accumulators still live)
+        constexpr int RPT = 64 / RPP, G = RPT < GMAX ? RPT : GMAX;
 #pragma unroll
         for (int g0 = 0; g0 < RPT; g0 += G) {
           int mrow[G];
@@ -1197,6 +1198,10 @@ __device__ __forceinline__ void raw_barrier() {
 #endif
 }
 
+// CONV = true: convolution form (binary16 channels-last maps, Cin % 64 == 0 so that a K-tile lies inside one
+// filter tap: the tap decode is wave-uniform, each lane only adds the tap offset to its pixel and checks
+// the bounds; padding / rows beyond M read the zero page) -- ResNet's 256-channel 3x3 layers.
+template <bool CONV>
 __global__ __launch_bounds__(512, 1)
 void gemm_f16_p8_kernel(const ConvGemmParams p) {
   constexpr int HT = 16384, BUF = 4 * HT;        // half-tile, buffer (A0 | B0 | B1 | A1)
@@ -1221,6 +1226,7 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
 
   // DMA sources of this lane: half-tile h, piece 2 wave + j -> local rows 8 (2 wave + j) + lane / 8
   int a_off32[2][2], w_off32[2][2];
+  int a_pix[CONV ? 2 : 1][2], a_iy[CONV ? 2 : 1][2], a_ix[CONV ? 2 : 1][2];
   {
     const int rr = lane >> 3, pc = lane & 7;
 #pragma unroll
@@ -1230,17 +1236,44 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
         const int lr = (wave * 2 + j) * 8 + rr;
         const int c = pc ^ ((lr >> 1) & 7);
         const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
-        const int m = m0 + trow < p.M ? m0 + trow : p.M - 1;
-        a_off32[h][j] = m * p.lda16 + p.a_off + c * 8;
+        if (CONV) {
+          const int HWo = p.Hout * p.Wout;
+          const int m = m0 + trow;
+          const bool ok = m < p.M;
+          const int mm = ok ? m : 0;
+          const int img = mm / HWo, rem = mm - img * HWo;
+          const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+          const int iy0 = oy * p.stride_h - p.pad_h, ix0 = ox * p.stride_w - p.pad_w;
+          a_pix[CONV ? h : 0][j] = (img * p.Hin + iy0) * p.Win + ix0;
+          a_iy[CONV ? h : 0][j] = ok ? iy0 : -(1 << 28);     // rows >= M: bounds predicate always false
+          a_ix[CONV ? h : 0][j] = ix0;
+          a_off32[h][j] = p.a_off + c * 8;                   // channel offset inside the pixel
+        } else {
+          const int m = m0 + trow < p.M ? m0 + trow : p.M - 1;
+          a_off32[h][j] = m * p.lda16 + p.a_off + c * 8;
+        }
         const int tcol = (lr >> 5) * 64 + h * 32 + (lr & 31);
         const int n = n0 + tcol < p.N ? n0 + tcol : p.N - 1;
         w_off32[h][j] = n * p.ldw + c * 8;
       }
   }
+  // one A piece of K-tile k_off (halfs): j-th piece of half-tile h
+  auto a_src = [&](int h, int j, int k_off) -> const uint16_t* {
+    if (CONV) {
+      const int tap = k_off / p.Cin, ci0 = k_off - tap * p.Cin;          // wave-uniform (Cin % 64 == 0)
+      const int ty = tap / p.kw, tx = tap - ty * p.kw;
+      const int dy = ty * p.dil_h, dx = tx * p.dil_w;
+      const int iy = a_iy[CONV ? h : 0][j] + dy, ix = a_ix[CONV ? h : 0][j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      return ok ? p.A16 + ((long long)(a_pix[CONV ? h : 0][j] + dy * p.Win + dx) * p.lda16 + ci0 + a_off32[h][j])
+                : reinterpret_cast<const uint16_t*>(p.zeros);
+    }
+    return p.A16 + (unsigned)(a_off32[h][j] + k_off);
+  };
   auto stage_a = [&](int h, int buf, int k_off) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      dma_16B(p.A16 + (unsigned)(a_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
+      dma_16B(a_src(h, j, k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
   };
   auto stage_b = [&](int h, int buf, int k_off) {
 #pragma unroll
@@ -1298,7 +1331,7 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
   auto piece_a = [&](int h, int j, int buf, int k_off) {
-    dma_16B(p.A16 + (unsigned)(a_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
+    dma_16B(a_src(h, j, k_off), ldsb + buf * BUF + SLOT_A[h] + (wave * 2 + j) * 1024);
   };
   auto piece_b = [&](int h, int j, int buf, int k_off) {
     dma_16B(p.Wh + (unsigned)(w_off32[h][j] + k_off), ldsb + buf * BUF + SLOT_B[h] + (wave * 2 + j) * 1024);
@@ -1360,25 +1393,26 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
   float* region = lds + qn * (128 * (128 + 4));
 #pragma unroll 1
   for (int ph = 0; ph < 2; ++ph) {
-    gemm_epilogue<128, 128, 1, 2, false, 256>(p, acc, region, m0 + ph * 128, n0 + qn * 128, tid_q, wr == ph,
-                                              (wr << 7) | tid_q);
+    gemm_epilogue<128, 128, 1, 2, false, 256, CONV>(p, acc, region, m0 + ph * 128, n0 + qn * 128, tid_q,
+                                                    wr == ph, (wr << 7) | tid_q);
     __syncthreads();
   }
   WS_MARK(3)
 }
 
+template <bool CONV = false>
 static hipError_t launch_f16_p8(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_p8_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_p8_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_p8_kernel<CONV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles_m = (p.M - p.m_begin + 255) / 256, tiles_n = (p.N + 255) / 256;
   if (tiles_m <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gemm_f16_p8_kernel, dim3(tiles_m * tiles_n), dim3(512), lds_bytes, stream, p);
+  hipLaunchKernelGGL(gemm_f16_p8_kernel<CONV>, dim3(tiles_m * tiles_n), dim3(512), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -1436,6 +1470,7 @@ static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t str
 
 // tile-shape switch for the big f16 GEMMs (env WS_BIG_TILES at first use; tools/gemm_probe flips it)
 int g_ws_big_tiles = -1;
+int g_ws_big_conv = -1;       // the same for the convolution form (env WS_BIG_CONV)
 
 template <int PREC>
 static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
@@ -1468,6 +1503,26 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     // -> 4 stages and 4 workgroups per CU hide the DMA round trip
     if (p.N <= 32) return launch_f16_dma<128, 32, 32, 4, 4, 4, true>(p, stream);
     if (p.N <= 64) return launch_f16_dma<128, 64, 64, 2, 4, 2, true>(p, stream);
+    // 256-wide layers whose K-tiles lie inside one filter tap: whole rounds on the phase-staggered 256x256
+    // kernel (ResNet stage 4 / the 256-plane bottlenecks), the rest re-enters with m_begin set
+    int& bigc = g_ws_big_conv;
+    if (bigc < 0) { const char* ev = getenv("WS_BIG_CONV"); bigc = ev ? atoi(ev) : 1; }
+    if (bigc && p.N % 256 == 0 && p.Cin % 64 == 0 && p.K % 64 == 0 && !p.bias_img && !p.residual &&
+        !p.seg_scale && !p.colsum && !p.D2) {
+      const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
+      const long long rounds = tiles_m * tiles_n / cus;
+      if (rounds >= 1) {
+        long long main_tiles_m = rounds * cus / tiles_n;
+        if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * 8) main_tiles_m = tiles_m;
+        ConvGemmParams mainb = p;
+        if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
+        hipError_t e = launch_f16_p8<true>(mainb, stream);
+        if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
+        ConvGemmParams rest = p;
+        rest.m_begin = mainb.M;
+        return launch_prec<PREC>(rest, stream);
+      }
+    }
     const long long blocks128 = (long long)((rows + 127) / 128) * ((p.N + 127) / 128);
     if (blocks128 * 2 < slots) return launch_f16_dma<64, 64, 64, 2, 4, 2, true>(p, stream);
     ConvGemmParams mainc = p, tailc = p;
@@ -1503,7 +1558,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * 8) main_tiles_m = tiles_m;
       ConvGemmParams mainb = p;
       if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
-      hipError_t e = big == 2 ? launch_f16_p8(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
+      hipError_t e = big == 2 ? launch_f16_p8<false>(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
       if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
       ConvGemmParams rest = p;
       rest.m_begin = mainb.M;
