@@ -1547,18 +1547,18 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // OFF by default.  Measured in tools/gemm_probe (bare bias/ReLU epilogue): +6 % at N = K = 1536,
   // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
-  if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 2; }
-  if (use_dma && big && p.N % 256 == 0 && p.N >= 1024 && !p.pool_partial && !p.bias_img && !p.residual &&
-      !p.residual16 && !p.seg_scale) {
+  if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 3; }
+  if (use_dma && big && p.N % 256 == 0 && p.N >= (big >= 3 ? 512 : 1024) && !p.pool_partial && !p.bias_img &&
+      !p.residual && !p.residual16 && !p.seg_scale) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
     const long long rounds = tiles_m * tiles_n / cus;
     if (rounds >= 1) {
       long long main_tiles_m = rounds * cus / tiles_n;
       // the last round may also be nearly full: then no tail at all
-      if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * 8) main_tiles_m = tiles_m;
+      if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * (big >= 3 ? 4 : 8)) main_tiles_m = tiles_m;
       ConvGemmParams mainb = p;
       if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
-      hipError_t e = big == 2 ? launch_f16_p8<false>(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
+      hipError_t e = big >= 2 ? launch_f16_p8<false>(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
       if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
       ConvGemmParams rest = p;
       rest.m_begin = mainb.M;
