@@ -270,9 +270,10 @@ def main():
                         "the reference's own GPU runtime is TensorRT fp16)",
                  "f16x3": "f16x3 split MFMA, f32 accumulate (fp32-grade: 1.7e-6 rel err)",
                  "fp32": "f32"}[prec]
-        kernel = {"f16": "gemm_f16_dma_kernel<128,128,64,2> (v_mfma_f32_32x32x16_f16, K-tile 64, both binary16 "
-                         "operands staged by global_load_lds_dwordx4) + gemm_f16_p8_kernel (256x256 "
-                         "phase-staggered form, the N = 1536 layer) + their 64x64 tail launches",
+        kernel = {"f16": "gemm_f16_p8_kernel (256x256 tile, two wave groups one barrier interval apart, "
+                         "v_mfma_f32_32x32x16_f16, both binary16 operands staged by global_load_lds_dwordx4: "
+                         "the eight N >= 512 layers) + gemm_f16_dma_kernel<128,128,64,2> (the two attention "
+                         "layers, one with the fused pooling epilogue) + their 64x64 tail launches",
                   "f16x3": "conv_gemm_kernel<128,128,2,2,...,PREC=1> (3 x v_mfma_f32_32x32x16_f16)",
                   "fp32": "conv_gemm_kernel<128,128,2,2,...,PREC=0> (v_mfma_f32_32x32x2_f32)"}[prec]
         note = {"f16": "achieved counts ALGORITHMIC flops (2MNK) = the MFMA work (one pass)",
