@@ -527,6 +527,31 @@ def test_full_size_ecapa1024_f16_spot_check():
     assert _rel_err(model.extract(fe, wav)[rows].cpu().numpy(), ref).max() < 5e-4
 
 
+def test_full_size_resnet34_f16_spot_check():
+    """configs[2] (ResNet34) at 512 x 2 s on the f16 back-end: the only size at which its 256-wide 3x3
+    layers run on the convolution form of the phase-staggered 256x256 kernel (>= 65 536 output pixels);
+    also the 64-channel direct kernel and the grouped residual epilogue at full size.  Oracle spot rows,
+    equality with a small-batch run of the same utterances (within binary16 rounding), run-to-run bits."""
+    from oracle import resnet as oresnet
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_resnet_state_dict("ResNet34", 80, 256, seed=3)
+    model = NativeSpeakerModel("ResNet34", sd, feat_dim=80, embed_dim=256, max_batch=512, max_frames=198)
+    fe = Frontend(16000, 80)
+    wav = device_wavs(512, 32000, model.device, 21)
+    model.set_precision("f16")
+    full = model.extract(fe, wav)
+    rows = [1, 300, 511]
+    feats = np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])
+    ref = oresnet.resnet_forward(sd, feats, "ResNet34").numpy()
+    assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL
+    assert _rel_err(full[rows].cpu().numpy(), ref).max() < F16_REL_TOL
+    small = model.extract(fe, wav[rows])
+    assert _rel_err(small.cpu().numpy(), full[rows].cpu().numpy()).max() < F16_REL_TOL
+    assert torch.equal(model.extract(fe, wav), full)
+    assert bool(torch.isfinite(full).all())
+
+
 def test_full_size_plda_one_million_trials():
     """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
