@@ -11,7 +11,7 @@ using namespace wsamd;
 #ifdef WS_TRACE
 namespace wsamd { unsigned long long* trace_buffer_address(); }
 #endif
-namespace wsamd { extern int g_ws_big_tiles; extern int g_ws_big_conv; }
+namespace wsamd { extern int g_ws_big_tiles; extern int g_ws_big_conv; extern int g_ws_epi16; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -168,6 +168,39 @@ int main(int argc, char** argv) {
         printf("  xcmp[%d] %s: %zu of %zu differ, worst rel %.3e, nan %zu\n", rep, s.name, ndiff, r0.size(), worst, nnan);
       }
       g_ws_big_tiles = keep;
+    }
+    if (getenv("PROBE_D16") && s.taps == 1 && s.N % 256 == 0 && s.N >= 512 && p.A16) {
+      // D16-only layer with column sums: fp32 two-phase epilogue vs binary16 one-phase epilogue of the 256x256 kernel
+      static uint16_t* D16b = nullptr; static float* CS = nullptr;
+      if (!D16b) { CK(hipMalloc(&D16b, maxD * 2)); CK(hipMalloc(&CS, ((50688 + 63) / 64 + 2) * 2 * 1536 * 4)); }
+      ConvGemmParams q = p; q.D = nullptr; q.D16 = D16b; q.ldd16 = s.N; q.colsum = CS;
+      const size_t nout = (size_t)s.M * s.N, ncs = (size_t)((s.M + 63) / 64) * 2 * s.N;
+      std::vector<uint16_t> o0(nout), o1(nout); std::vector<float> c0(ncs), c1(ncs);
+      const int keepb = g_ws_big_tiles; g_ws_big_tiles = 3;
+      for (int rep = 0; rep < 2; ++rep) {
+        g_ws_epi16 = 0;
+        CK(hipMemset(D16b, 0xff, nout * 2)); CK(hipMemset(CS, 0, ncs * 4));
+        CK(launch_conv_gemm(q, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(o0.data(), D16b, nout * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c0.data(), CS, ncs * 4, hipMemcpyDeviceToHost));
+        g_ws_epi16 = 1;
+        CK(hipMemset(D16b, 0xff, nout * 2)); CK(hipMemset(CS, 0, ncs * 4));
+        CK(launch_conv_gemm(q, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(o1.data(), D16b, nout * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), CS, ncs * 4, hipMemcpyDeviceToHost));
+        size_t nd = 0; for (size_t i = 0; i < nout; ++i) nd += o0[i] != o1[i];
+        double wc = 0; for (size_t i = 0; i < ncs; ++i) { const double e = fabs((double)c0[i] - c1[i]) / (fabs((double)c0[i]) + 64.0); if (e > wc) wc = e; }
+        printf("  d16[%d] %s: %zu of %zu halfs differ; colsum worst rel %.3e\n", rep, s.name, nd, nout, wc);
+      }
+      for (int e16 = 0; e16 < 2; ++e16) {
+        g_ws_epi16 = e16;
+        for (int i = 0; i < 3; ++i) CK(launch_conv_gemm(q, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; ++i) CK(launch_conv_gemm(q, 0));
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms2; CK(hipEventElapsedTime(&ms2, e0, e1));
+        printf("  d16 %s epi16=%d: %8.1f us\n", s.name, e16, ms2 * 50.0);
+      }
+      g_ws_epi16 = 0; g_ws_big_tiles = keepb;
     }
     if (getenv("PROBE_HASH") && s.taps == 1) {
       // full-output hash over repeated launches: equal across tile shapes (same k order) and across runs

@@ -1179,9 +1179,10 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
 // i.e. every piece is in flight for ~5 barrier intervals (~3000 cycles) before its first reader, which
 // covers the ~1500-cycle LDS-DMA round trip that the 2-stage loop above waits for.  Reads happen one
 // phase after the wait + barrier that retires their data (MI355X guide: nothing else orders LDS-DMA).
+constexpr int P8_CONST_OFF = 2 * 128 * (128 + 4) * 4;      // behind the stage buffers / transpose regions
 constexpr size_t f16_p8_lds_bytes() {
   const size_t stages = 2 * 4 * 16384, epi = 2 * (size_t)128 * (128 + 4) * 4;
-  return stages > epi ? stages : epi;
+  return (stages > epi ? stages : epi) + 3 * 256 * 4;      // + per-channel constants of the binary16 epilogue
 }
 
 template <int N>
@@ -1196,6 +1197,104 @@ __device__ __forceinline__ void raw_barrier() {
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 #endif
+}
+
+// Binary16 one-phase epilogue of the 256x256 kernel for layers that only leave a binary16 tensor (D16, no
+// D / D2 / per-row operands, act none or ReLU).  The two-phase fp32 transpose above costs a K = 512 tile more
+// than its K loop; here bias / ReLU / BN are applied in registers on the C^T blocks (a lane owns 4
+// consecutive channels of one pixel, so the per-channel constants are one f32x4 each), the values are
+// converted and the WHOLE tile is transposed as halfs ([256][264]: 135 KB), then every thread stores
+// 16-byte runs of finished rows.  Column sums (ConvGemmParams::colsum) are taken from the stored binary16
+// values -- per (64-row group, image part, column), 16 row phases folded through LDS in a fixed order.
+__device__ __forceinline__ void p8_epilogue_f16(const ConvGemmParams& p, f32x16 (&acc)[4][2], char* ldsb,
+                                                int m0, int n0, int tid) {
+  constexpr int YS = 264;                         // halfs per LDS row (528 B: 16-byte aligned rows)
+  _Float16* Y = reinterpret_cast<_Float16*>(ldsb);
+  const float* kc = reinterpret_cast<const float*>(ldsb + P8_CONST_OFF);   // [bias | scale | shift][256]
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int in = 0; in < 2; ++in)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = wc * 64 + in * 32 + 8 * g + 4 * lh;
+      // per-channel constants of this tile's 256 columns: put into LDS by the kernel before its K loop
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(&kc[col]);
+      const f32x4 ps = *reinterpret_cast<const f32x4*>(&kc[256 + col]);
+      const f32x4 pb = *reinterpret_cast<const f32x4*>(&kc[512 + col]);
+#pragma unroll
+      for (int im = 0; im < 4; ++im) {
+        f32x4 v = (f32x4){acc[im][in][4 * g], acc[im][in][4 * g + 1], acc[im][in][4 * g + 2],
+                          acc[im][in][4 * g + 3]} + bias;
+        if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (p.post_scale) v = v * ps + pb;
+        f16x4 hv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+        const int row = wr * 128 + im * 32 + li;
+        *reinterpret_cast<f16x4*>(&Y[row * YS + col]) = hv;
+      }
+    }
+  __syncthreads();
+  const int c8 = tid & 31, rr = tid >> 5;         // 8-channel group, row phase (16 phases)
+  const int HW = p.Hout * p.Wout;
+  float cs[4][2][8];
+  if (p.colsum) {
+#pragma unroll
+    for (int hf = 0; hf < 4; ++hf)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs[hf][wh][q] = 0.f;
+  }
+  uint16_t* dst = p.D16 + p.d_off + n0 + c8 * 8;
+#pragma unroll
+  for (int hf = 0; hf < 4; ++hf) {
+    const int mh = m0 + hf * 64;
+    const int rb = (mh / HW + 1) * HW - mh;       // rows >= rb of this 64-row group belong to the next image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rr + 16 * i;
+      const int row = hf * 64 + rl;
+      const int m = m0 + row;
+      if (m < p.M) {
+        const f16x8 hv = *reinterpret_cast<const f16x8*>(&Y[row * YS + c8 * 8]);
+        *reinterpret_cast<f16x8*>(dst + (long long)m * p.ldd16) = hv;
+        if (p.colsum) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (rl < rb) cs[hf][0][q] += (float)hv[q]; else cs[hf][1][q] += (float)hv[q];
+          }
+        }
+      }
+    }
+  }
+  if (p.colsum) {
+    __syncthreads();                              // everyone is done reading Y
+    float* red = reinterpret_cast<float*>(ldsb);  // [hw = hf*2 + which (8)][rr (16)][256]
+#pragma unroll
+    for (int hf = 0; hf < 4; ++hf)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh) {
+        float* r = &red[((hf * 2 + wh) * 16 + rr) * 256 + c8 * 8];
+        *reinterpret_cast<f32x4*>(r) = (f32x4){cs[hf][wh][0], cs[hf][wh][1], cs[hf][wh][2], cs[hf][wh][3]};
+        *reinterpret_cast<f32x4*>(r + 4) = (f32x4){cs[hf][wh][4], cs[hf][wh][5], cs[hf][wh][6], cs[hf][wh][7]};
+      }
+    __syncthreads();
+    for (int o = tid; o < 8 * 256; o += 512) {
+      const int hw = o >> 8, col = o & 255;
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sacc += red[(hw * 16 + q) * 256 + col];
+      const int hf = hw >> 1;
+      if (m0 + hf * 64 < p.M)
+        p.colsum[((long long)((m0 + hf * 64) / 64) * 2 + (hw & 1)) * p.N + n0 + col] = sacc;
+    }
+  }
 }
 
 // CONV = true: convolution form (binary16 channels-last maps, Cin % 64 == 0 so that a K-tile lies inside one
@@ -1223,6 +1322,14 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int nk = p.K / 64;
+  if (!CONV && p.epi16 && tid < 192) {
+    // binary16 epilogue: bias / BN scale / BN shift of this tile's columns -> LDS (read after many barriers)
+    const int which = tid >> 6, c = (tid & 63) * 4;
+    f32x4 v = which == 1 ? (f32x4){1.f, 1.f, 1.f, 1.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* src = which == 0 ? p.bias : (which == 1 ? p.post_scale : p.post_shift);
+    if (src) v = *reinterpret_cast<const f32x4*>(src + n0 + c);
+    *reinterpret_cast<f32x4*>(ldsb + P8_CONST_OFF + (which * 256 + c) * 4) = v;
+  }
 
   // DMA sources of this lane: half-tile h, piece 2 wave + j -> local rows 8 (2 wave + j) + lane / 8
   int a_off32[2][2], w_off32[2][2];
@@ -1386,6 +1493,11 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
   if (wr == 0) raw_barrier();
   __syncthreads();
   WS_MARK(2)
+  if (!CONV && p.epi16) {
+    p8_epilogue_f16(p, acc, ldsb, m0, n0, tid);
+    WS_MARK(3)
+    return;
+  }
   // four 128x128 quadrants, each owned by two wavefronts (a 1 x 2 grid of 128x64); the two quadrants
   // of a row half run together on separate transpose regions
   const int qn = wc >> 1;
@@ -1471,6 +1583,7 @@ static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t str
 // tile-shape switch for the big f16 GEMMs (env WS_BIG_TILES at first use; tools/gemm_probe flips it)
 int g_ws_big_tiles = -1;
 int g_ws_big_conv = -1;       // the same for the convolution form (env WS_BIG_CONV)
+int g_ws_epi16 = -1;          // binary16 one-phase epilogue of the 256x256 kernel (env WS_EPI16)
 
 template <int PREC>
 static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
@@ -1558,6 +1671,10 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * (big >= 3 ? 4 : 8)) main_tiles_m = tiles_m;
       ConvGemmParams mainb = p;
       if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
+      // D16-only layers finish through the binary16 one-phase epilogue (WS_EPI16=0: the fp32 two-phase one)
+      if (g_ws_epi16 < 0) { const char* ev = getenv("WS_EPI16"); g_ws_epi16 = ev ? atoi(ev) : 1; }
+      mainb.epi16 = g_ws_epi16 && big >= 2 && p.D16 && !p.D && !p.D2 && p.act != ACT_TANH && (p.ldd16 & 7) == 0 &&
+                    (p.d_off & 7) == 0 && (!p.colsum || p.Hout * p.Wout >= 64);
       hipError_t e = big >= 2 ? launch_f16_p8<false>(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
       if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
       ConvGemmParams rest = p;

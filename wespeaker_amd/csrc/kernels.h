@@ -54,6 +54,8 @@ struct ConvGemmParams {
                                               // and image part -> pool_partial[ceil(M/64)*2][N][4]
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
+  int epi16;                                  // set by the dispatcher: the 256x256 kernel finishes a D16-only
+                                              // layer through its binary16 one-phase epilogue
 };
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 
