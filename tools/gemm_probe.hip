@@ -199,6 +199,14 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms2; CK(hipEventElapsedTime(&ms2, e0, e1));
         printf("  d16 %s epi16=%d: %8.1f us\n", s.name, e16, ms2 * 50.0);
+#ifdef WS_TRACE
+        {
+          unsigned long long tr2[64 * 8];
+          CK(hipMemcpy(tr2, trace_buffer_address(), sizeof(tr2), hipMemcpyDeviceToHost));
+          printf("    marks (epi16=%d): prologue %lld  loop %lld  epilogue %lld\n", e16, (long long)(tr2[63 * 8 + 1] - tr2[63 * 8]),
+                 (long long)(tr2[63 * 8 + 2] - tr2[63 * 8 + 1]), (long long)(tr2[63 * 8 + 3] - tr2[63 * 8 + 2]));
+        }
+#endif
       }
       g_ws_epi16 = 0; g_ws_big_tiles = keepb;
     }
