@@ -81,7 +81,6 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                               float* lds, int m0, int n0, int tid, bool active = true,
                                               int stid = -1) {
-  constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
