@@ -527,6 +527,24 @@ def test_full_size_ecapa1024_f16_spot_check():
     assert _rel_err(model.extract(fe, wav)[rows].cpu().numpy(), ref).max() < 5e-4
 
 
+def test_ragged_batch_partial_tile_f16():
+    """250 x 2 s utterances: 49 500 rows = 193.4 tiles of 256 -- the last tile of every 256x256-kernel launch
+    is partial (row clamps in the LDS-DMA, masked stores and column sums in the binary16 epilogue)."""
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, max_batch=250, max_frames=198)
+    fe = Frontend(16000, 80)
+    wav = device_wavs(250, 32000, model.device, 3)
+    model.set_precision("f16")
+    full = model.extract(fe, wav)
+    rows = [0, 100, 248, 249]
+    small = torch.cat([model.extract(fe, wav[i:i + 1]) for i in rows])
+    assert _rel_err(full[rows].cpu().numpy(), small.cpu().numpy()).max() < F16_REL_TOL
+    assert _cos_err(full[rows].cpu().numpy(), small.cpu().numpy()).max() < 1e-5
+    assert bool(torch.isfinite(full).all())
+
+
 def test_full_size_resnet34_f16_spot_check():
     """configs[2] (ResNet34) at 512 x 2 s on the f16 back-end: the only size at which its 256-wide 3x3
     layers run on the convolution form of the phase-staggered 256x256 kernel (>= 65 536 output pixels);
