@@ -36,7 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from wespeaker_amd import Frontend, NativeSpeakerModel, TwoCovPLDA, parallel, synth  # noqa: E402
+from wespeaker_amd import Frontend, NativeSpeakerModel, TwoCovPLDA, parallel  # noqa: E402
+from fixtures import synth
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 F16_MFMA_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
@@ -221,7 +222,7 @@ def main():
     plda_info = None
     if rank == 0:
         p = synth.synth_plda(192, seed=7)
-        plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
+        plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
         n_emb = 10000
         emb_tab, _ = synth.synth_embeddings(2 * n_emb, 192, seed=11)
         emb_tab = torch.from_numpy(emb_tab).to(device)

@@ -343,3 +343,30 @@ def write_plda_training_files(fix, out_dir):
         for k, v in zip(fix["adapt_names"], fix["adapt"]):
             w(k, v)
     return paths
+
+
+# ------------------------------------------------------------------ Kaldi <Plda> model files
+def write_kaldi_plda(path, mu, transform, psi, binary=True, double=True):
+    """A Kaldi `<Plda>` object the way Kaldi's Plda::Write lays it out (the format
+    wespeaker/utils/plda/kaldi_utils.py:24-55 reads): token, mean vector, transform matrix, psi
+    vector, closing token.  The reference has no writer; this exists to build test fixtures."""
+    import struct
+    mu, transform, psi = (np.asarray(a, dtype=np.float64) for a in (mu, transform, psi))
+    if binary:
+        dt, vt, mt = ("<f8", b"DV ", b"DM ") if double else ("<f4", b"FV ", b"FM ")
+
+        def vec(v):
+            return vt + b"\x04" + struct.pack("<i", v.shape[0]) + v.astype(dt).tobytes()
+
+        with open(path, "wb") as f:
+            f.write(b"\0B<Plda> " + vec(mu))
+            f.write(mt + b"\x04" + struct.pack("<i", transform.shape[0]) + b"\x04" +
+                    struct.pack("<i", transform.shape[1]) + transform.astype(dt).tobytes())
+            f.write(vec(psi) + b"</Plda> ")
+        return
+    fmt = lambda row: " ".join(repr(float(x)) for x in row)      # noqa: E731
+    with open(path, "w") as f:
+        f.write("<Plda>  [ " + fmt(mu) + " ]\n [\n")
+        for i, row in enumerate(transform):
+            f.write("  " + fmt(row) + (" ]\n" if i == transform.shape[0] - 1 else "\n"))
+        f.write(" [ " + fmt(psi) + " ]\n</Plda> ")

@@ -27,6 +27,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only the entry points below are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#define WS_API __attribute__((visibility("default")))
+#else
+#define WS_API
+#endif
+
 #define WS_OK 0
 #define WS_ERR_INVALID_ARG (-1)
 #define WS_ERR_UNKNOWN_MODEL (-2)
@@ -48,24 +55,24 @@ typedef struct ws_plda ws_plda;         /* two-covariance PLDA scorer on one GPU
 typedef void* ws_stream;                /* hipStream_t */
 
 /* ------------------------------------------------------------------------------------ misc */
-int ws_version(void);
-const char* ws_last_error(void);
+WS_API int ws_version(void);
+WS_API const char* ws_last_error(void);
 /* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):
  * 1 + (N - 400) / 160 at 16 kHz; 0 if N < frame length. */
-int ws_num_frames(int num_samples, int sample_rate);
+WS_API int ws_num_frames(int num_samples, int sample_rate);
 
 /* -------------------------------------------------------------------------------- frontend */
 /* Replaces torchaudio.compliance.kaldi.fbank as called at cli/speaker.py:92-97 and
  * dataset/processor.py:518-525 (+ CMN cli/speaker.py:98-99, dataset_utils.py:19-26); native twin
  * runtime/core/frontend/fbank.h:33-97 (constructor: mel banks, window).  dither is always 0. */
-int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out);
-void ws_frontend_destroy(ws_frontend* fe);
+WS_API int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out);
+WS_API void ws_frontend_destroy(ws_frontend* fe);
 /* wav: DEVICE (B, wav_stride) samples, the first num_samples of each row are used.
  * scale multiplies samples on load (1.0 for int16-range input; 32768.0 reproduces
  * processor.py:516 `waveform * (1 << 15)` for [-1,1] floats).
  * feats: DEVICE (B, T, num_mel_bins) float32, T = ws_num_frames(num_samples).
  * cmn != 0 subtracts the per-utterance mean over T from every mel bin. */
-int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num_samples,
+WS_API int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num_samples,
              int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
              ws_stream stream);
 
@@ -76,25 +83,31 @@ int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num
  * reference's state_dict key names (e.g. "layer2.se_res2block.1.convs.3.weight"); unknown keys
  * ("projection.*", "*.num_batches_tracked") are ignored like strict=False does.  Returns the
  * native twin of runtime/core/speaker/speaker_model.h:25-32 (SpeakerModel). */
-int ws_engine_create(const char* model_name, int feat_dim, int embed_dim, int device_id,
+WS_API int ws_engine_create(const char* model_name, int feat_dim, int embed_dim, int device_id,
                      ws_engine** out);
 /* data: HOST float32, C-contiguous, ndim <= 4.  Returns 1 if the key was consumed, 0 if ignored. */
-int ws_engine_set_tensor(ws_engine* eng, const char* key, const float* data, int ndim,
+WS_API int ws_engine_set_tensor(ws_engine* eng, const char* key, const float* data, int ndim,
                          const int64_t* shape);
 /* Checks that every required tensor arrived (WS_ERR_MISSING_TENSOR names the first missing key),
  * folds/re-lays-out the weights, uploads them and allocates workspace for max_batch utterances
  * of max_frames frames per forward chunk (larger batches are processed in chunks). */
-int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames);
-void ws_engine_destroy(ws_engine* eng);
-int ws_engine_embed_dim(const ws_engine* eng);
-int ws_engine_feat_dim(const ws_engine* eng);
+WS_API int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames);
+/* Re-sizes the workspace of a finalized engine (weights stay): the reference accepts utterances of any
+ * length (cli/speaker.py:125-167 has no cap), so callers grow the engine when a longer one arrives.
+ * Synchronises the device (earlier launches may still use the old workspace). */
+WS_API int ws_engine_reserve(ws_engine* eng, int max_batch, int max_frames);
+WS_API int ws_engine_max_batch(const ws_engine* eng);
+WS_API int ws_engine_max_frames(const ws_engine* eng);
+WS_API void ws_engine_destroy(ws_engine* eng);
+WS_API int ws_engine_embed_dim(const ws_engine* eng);
+WS_API int ws_engine_feat_dim(const ws_engine* eng);
 /* Replaces model(feats)[-1] (cli/speaker.py:163-166; bin/extract.py:133-135):
  * feats DEVICE (B, T, feat_dim) float32 (already CMN'd) -> emb DEVICE (B, embed_dim) float32. */
-int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, float* emb,
+WS_API int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, float* emb,
                ws_stream stream);
 /* Fused Speaker.extract_embedding_from_pcm (cli/speaker.py:156-166): wav -> fbank -> CMN ->
  * forward, feature tensor kept inside the engine's workspace. */
-int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
+WS_API int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
                ws_stream stream);
 /* Polyphase windowed-sinc resampling of one channel: the arithmetic of
@@ -102,7 +115,7 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
  * (cli/speaker.py:157-160).  orig / new are the rates divided by their gcd; kernel DEVICE float32
  * [new][2 * width + orig] is the filter bank (host-built: wespeaker_amd.audio.resample_kernel);
  * x DEVICE float32[n_in]; y DEVICE float32[n_out], n_out = ceil(new * n_in / orig). */
-int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int new_rate, int width,
+WS_API int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int new_rate, int width,
                 float* y, int64_t n_out, ws_stream stream);
 
 /* Chunk-and-average extraction of ONE utterance, the native runtime's
@@ -115,7 +128,7 @@ int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int
  * chunk holding every frame).  wav DEVICE (num_samples) int16 or float32 as in ws_fbank;
  * emb DEVICE float32[embed_dim].  Returns the number of chunks (>= 1) or a negative WS_ERR_*.
  * Grows an engine-owned scratch on first use / larger input (synchronises then). */
-int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
+WS_API int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
                        int num_samples, int samples_per_chunk, float scale, int window_type,
                        float* emb, ws_stream stream);
 
@@ -134,9 +147,9 @@ int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav
 #define WS_PREC_FP32 0
 #define WS_PREC_F16X3 1
 #define WS_PREC_F16 2
-int ws_engine_set_precision(ws_engine* eng, int mode);
+WS_API int ws_engine_set_precision(ws_engine* eng, int mode);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
-double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
+WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 
 /* Measurement hooks (bench.py roofline leg; no reference counterpart -- the reference only has the
  * wall-clock Timer of runtime/core/utils/timer.h:22-36).  While enabled, every kernel launch of
@@ -147,42 +160,42 @@ double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
  * `on` is a bit mask of the classes to record (0 = off, 0xF = all, 1 = only the dominant GEMM):
  * timing events between kernels cost a few per cent of throughput, so the headline run records
  * only the dominant kernel.  Returns the number of classes. */
-int ws_engine_profile_enable(ws_engine* eng, int on);
-int ws_engine_profile_read(ws_engine* eng, double* ms, double* flops, double* bytes, int* launches);
+WS_API int ws_engine_profile_enable(ws_engine* eng, int on);
+WS_API int ws_engine_profile_read(ws_engine* eng, double* ms, double* flops, double* bytes, int* launches);
 
 /* ------------------------------------------------------------------------------------ PLDA */
 /* Replaces TwoCovPLDA.load_model's in-memory state (utils/plda/two_cov_plda.py:341-363):
  * mu, psi, offset HOST float64[dim]; transform HOST float64[dim*dim] row-major. */
-int ws_plda_create(int dim, const double* mu, const double* transform, const double* psi,
+WS_API int ws_plda_create(int dim, const double* mu, const double* transform, const double* psi,
                    const double* offset, int normalize_length, int device_id, ws_plda** out);
-void ws_plda_destroy(ws_plda* plda);
+WS_API void ws_plda_destroy(ws_plda* plda);
 /* eval_sv pre-processing for enrollment models (two_cov_plda.py:216-235): rows of emb are grouped
  * contiguously, group g = rows [group_offsets[g], group_offsets[g+1]).  Per group: subtract
  * mean_vec (HOST float64[dim] or NULL), mean over rows, length-norm of the mean if
  * normalize_length, transform_embedding.  emb DEVICE float32 (n_rows, dim); group_offsets DEVICE
  * int32[n_groups+1]; out DEVICE float64 (n_groups, dim). */
-int ws_plda_prepare_enroll(ws_plda* plda, const float* emb, const int32_t* group_offsets,
+WS_API int ws_plda_prepare_enroll(ws_plda* plda, const float* emb, const int32_t* group_offsets,
                            int n_groups, const double* mean_vec, double* out, ws_stream stream);
 /* eval_sv pre-processing for test utterances (two_cov_plda.py:237-244) == transform_embedding
  * (:156-163) after optional mean subtraction / length-norm.  emb DEVICE float32 (n, dim);
  * out DEVICE float64 (n, dim). */
-int ws_plda_prepare_test(ws_plda* plda, const float* emb, int n, const double* mean_vec,
+WS_API int ws_plda_prepare_test(ws_plda* plda, const float* emb, int n, const double* mean_vec,
                          double* out, ws_stream stream);
 /* TwoCovPLDA.transform_embedding (two_cov_plda.py:156-163) verbatim: y = transform x + offset, then
  * y *= sqrt(D)/|y| iff normalize_length.  x DEVICE float64 (n, dim); out DEVICE float64 (n, dim). */
-int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_stream stream);
+WS_API int ws_plda_transform(ws_plda* plda, const double* x, int n, double* out, ws_stream stream);
 /* Dense LLR matrix: log_likelihood_ratio (two_cov_plda.py:165-184) for every (enroll i, test j).
  * enroll DEVICE float64 (n_enroll, dim) transformed; n_sessions DEVICE int32[n_enroll] (the `n`
  * argument: 1 if multisession_avg else #utts, :219-222), or NULL when every model has the same
  * count n_uniform > 0 (multisession_avg=True => n_uniform = 1): the score is then one dim-long
  * contraction plus a per-model and a per-test constant; test DEVICE float64 (n_test, dim);
  * out DEVICE float64 (n_enroll, n_test). */
-int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+WS_API int ws_plda_llr_matrix(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
                        int n_uniform, int n_enroll, const double* test, int n_test, double* out,
                        ws_stream stream);
 /* Explicit trial list (the eval_sv trial loop :246-256): out[p] = LLR(enroll[idx_e[p]],
  * test[idx_t[p]], n_sessions[idx_e[p]]).  idx_* DEVICE int32[num_trials]; out DEVICE float64. */
-int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
+WS_API int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sessions,
                       int n_uniform, int n_enroll, const double* test, int n_test,
                       const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
                       ws_stream stream);
@@ -197,8 +210,8 @@ int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t* n_sess
  * sum_c sum_{i in c} (y_i - mu_c)(y_i - mu_c)^T with y = normalised (x - mean_vec);
  * scratch DEVICE float64[>= ws_plda_stats_scratch(n, dim)].  The D x D algebra of the EM steps
  * (inv / cholesky / eigh, :116-154) stays with the caller in float64. */
-int64_t ws_plda_stats_scratch(int n, int dim);
-int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets, int n_groups,
+WS_API int64_t ws_plda_stats_scratch(int n, int dim);
+WS_API int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets, int n_groups,
                   const double* mean_vec, int normalize_length, double* class_mean, double* scatter,
                   double* scratch, int64_t scratch_doubles, ws_stream stream);
 
@@ -208,7 +221,7 @@ int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets
  * x DEVICE (n, d_in) float32 (x_is_f64 = 0) or float64 (1); sub DEVICE float64[d_in] or NULL;
  * M DEVICE float64 (d_in, d_out) row-major or NULL (identity, d_out must equal d_in);
  * out DEVICE float64 (n, d_out).  The LDA / mean statistics come from ws_plda_stats. */
-int ws_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub, const double* M,
+WS_API int ws_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* sub, const double* M,
                    int d_out, int normalize, double* out, ws_stream stream);
 
 /* ------------------------------------------------------------------ cosine scoring + AS-norm
@@ -216,33 +229,33 @@ int ws_rows_affine(const void* x, int x_is_f64, int n, int d_in, const double* s
  * (trials_cosine_score) and wespeaker/bin/score_norm.py:26-36,93-115 (get_mean_std + the
  * normalisation loop).  A "unit table" holds mean-subtracted, L2-normalised embeddings as
  * (ws_cos_table_rows(n), ws_cos_table_ld(dim)) float32, zero padded on both axes. */
-int ws_cos_table_rows(int n);   /* n rounded up to a multiple of 4 */
-int ws_cos_table_ld(int dim);   /* dim rounded up to a multiple of 32 (floats per row) */
+WS_API int ws_cos_table_rows(int n);   /* n rounded up to a multiple of 4 */
+WS_API int ws_cos_table_ld(int dim);   /* dim rounded up to a multiple of 32 (floats per row) */
 /* emb DEVICE float32 (n, dim) dense; mean_vec DEVICE float32[dim] or NULL (score.py:44-53:
  * emb - mean_vec); unit DEVICE table as above (written in full, padding zeroed); mag DEVICE
  * float32[n] or NULL receives |emb - mean_vec| (the enroll_mag/test_mag columns, score_norm.py:107). */
-int ws_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit, float* mag,
+WS_API int ws_cos_prepare(const float* emb, const float* mean_vec, int n, int dim, float* unit, float* mag,
                    ws_stream stream);
 /* out[p] = <unit_a[idx_a[p]], unit_b[idx_b[p]]> = cosine_similarity (score.py:62-63).
  * idx_* DEVICE int32[num_trials]; out DEVICE float32[num_trials]. */
-int ws_cos_pairs(const float* unit_a, const float* unit_b, int dim, const int32_t* idx_a,
+WS_API int ws_cos_pairs(const float* unit_a, const float* unit_b, int dim, const int32_t* idx_a,
                  const int32_t* idx_b, int64_t num_trials, float* out, ws_stream stream);
 /* Dense cosine matrix out[i][j] = <unit_a[i], unit_b[j]> (score_norm.py:29 np.matmul(emb, cohort.T))
  * on the exact-fp32 MFMA GEMM.  out DEVICE float32 (n_a, ldo), ldo >= ws_cos_table_rows(n_b);
  * columns n_b..ws_cos_table_rows(n_b)-1 receive zeros. */
-int ws_cos_matrix(const float* unit_a, int n_a, const float* unit_b, int n_b, int dim, float* out,
+WS_API int ws_cos_matrix(const float* unit_a, int n_a, const float* unit_b, int n_b, int dim, float* out,
                   int ldo, ws_stream stream);
 /* get_mean_std (score_norm.py:26-36): for every row of `unit`, mean and population standard
  * deviation (np.std) of its min(top_n, n_cohort) largest cosine scores against the cohort
  * (asnorm: top_n; snorm: top_n >= n_cohort).  scratch DEVICE float32[scratch_floats] holds score
  * rows in flight; it needs at least 128 * ws_cos_table_rows(n_cohort) floats and the rows are
  * processed in as few chunks as it allows.  mean, sd DEVICE float32[n]. */
-int ws_cohort_stats(const float* unit, int n, const float* unit_cohort, int n_cohort, int dim,
+WS_API int ws_cohort_stats(const float* unit, int n, const float* unit_cohort, int n_cohort, int dim,
                     int top_n, float* scratch, int64_t scratch_floats, float* mean, float* sd,
                     ws_stream stream);
 /* score_norm.py:100-103: out[p] = 0.5 * ((s[p] - e_mean[ie]) / e_sd[ie] + (s[p] - t_mean[it]) / t_sd[it]).
  * All DEVICE; score/out float32[num_trials]. */
-int ws_asnorm_pairs(const float* score, const int32_t* idx_e, const int32_t* idx_t,
+WS_API int ws_asnorm_pairs(const float* score, const int32_t* idx_e, const int32_t* idx_t,
                     const float* e_mean, const float* e_sd, const float* t_mean, const float* t_sd,
                     int64_t num_trials, float* out, ws_stream stream);
 

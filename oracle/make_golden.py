@@ -4,7 +4,7 @@ REFERENCE ITSELF in this container.
 
   python oracle/make_golden.py          # needs /root/reference; writes tests/golden/
 
-What is recorded (all seeds live in wespeaker_amd/synth.py, inputs are regenerated from them):
+What is recorded (all seeds live in fixtures/synth.py, inputs are regenerated from them):
   * ecapa_ref.npz   -- embeddings of the reference's own nn.Modules
                        (wespeaker/models/ecapa_tdnn.py, imported from /root/reference) for the four
                        ECAPA constructors on synthetic utterances 0..1, weights = synth seed 42.
@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import ref_shim  # noqa: E402
 from oracle.fbank import speaker_features  # noqa: E402
-from wespeaker_amd import synth  # noqa: E402
+from fixtures import synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -218,14 +218,33 @@ def make_score():
           "asnorm range", out["mean/asnorm"][:, 0].min(), out["mean/asnorm"][:, 0].max())
 
 
+def make_kaldi_plda():
+    """Kaldi <Plda> files (float and double binary, text) written by fixtures.synth.write_kaldi_plda and
+    read back by the REFERENCE's own read_plda (utils/plda/kaldi_utils.py:24-109; only kaldi_io's
+    trivial open_or_fd is stubbed -- the binary parsing is the reference's code)."""
+    ku = ref_shim.ref_module("wespeaker.utils.plda.kaldi_utils")
+    ku.open_or_fd = lambda f: open(f, "rb")
+    p = synth.synth_plda(6, seed=13)
+    out = {}
+    for tag, kw in (("f32", dict(double=False)), ("f64", dict(double=True))):
+        path = os.path.join(GOLD, "kaldi_plda_%s.bin" % tag)
+        synth.write_kaldi_plda(path, p["mu"], p["transform"], p["psi"], binary=True, **kw)
+        mu, tr, psi = ku.read_plda(path)
+        out[tag + "/mu"], out[tag + "/transform"], out[tag + "/psi"] = mu, tr, psi
+    synth.write_kaldi_plda(os.path.join(GOLD, "kaldi_plda.txt"), p["mu"], p["transform"], p["psi"],
+                           binary=False)
+    np.savez_compressed(os.path.join(GOLD, "kaldi_plda_ref.npz"), **out)
+    print("kaldi plda: dim", out["f64/mu"].shape[0], "f32 vs f64 max diff",
+          np.abs(out["f32/transform"] - out["f64/transform"]).max())
+
+
+SECTIONS = {"fbank": make_fbank, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
+            "plda": make_plda, "score": make_score, "plda_train": make_plda_train,
+            "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda}
+
 if __name__ == "__main__":
     assert ref_shim.available(), "needs /root/reference"
     os.makedirs(GOLD, exist_ok=True)
-    make_fbank()
-    make_ecapa()
-    make_resnet_campplus()
-    make_plda()
-    make_score()
-    make_plda_train()
-    make_embd_proc()
+    for name in (sys.argv[1:] or list(SECTIONS)):       # python oracle/make_golden.py [section ...]
+        SECTIONS[name]()
     print("golden fixtures written to", GOLD)

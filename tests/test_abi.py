@@ -66,3 +66,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_only_the_c_abi_is_exported():
+    """-fvisibility=hidden + a version script: the dynamic symbol table holds ws_* and nothing else
+    (no C++ internals, no kernel handles)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE,
+                         text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert syms and all(s.startswith("ws_") for s in syms), [s for s in syms if not s.startswith("ws_")][:5]
+    assert set(syms) == set(_header_functions())

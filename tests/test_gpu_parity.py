@@ -13,7 +13,7 @@ import torch
 from oracle import ecapa as oecapa
 from oracle import fbank as ofbank
 from oracle import plda as oplda
-from wespeaker_amd import synth
+from fixtures import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -221,8 +221,19 @@ def test_ecapa_batch_invariance_chunking_and_ragged_lengths():
         f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
         got = model(torch.from_numpy(f))[-1].cpu().numpy()
         assert _rel_err(got, oecapa.ecapa_forward(sd, f).numpy()).max() < REL_TOL
-    with pytest.raises(Exception):
-        model(torch.zeros(1, 401, 80))                                    # over capacity: loud
+    # raw C-ABI: over the finalized capacity is a loud WS_ERR_CAPACITY ...
+    from wespeaker_amd import _lib
+    big = torch.zeros(1, model.max_frames + 1, 80, device="cuda")
+    out = torch.empty(1, 192, device="cuda")
+    assert _lib.lib().ws_forward(model._h, _lib.ptr(big), 1, model.max_frames + 1, _lib.ptr(out), None) == -7
+    # ... and the Python wrapper re-sizes the workspace instead (the reference has no length cap,
+    # cli/speaker.py:125-167): a 8 s utterance through an engine finalized for 4 s
+    f = np.random.RandomState(7).randn(2, 801, 80).astype(np.float32)
+    got = model(torch.from_numpy(f))[-1].cpu().numpy()
+    assert model.max_frames >= 801
+    assert _rel_err(got, oecapa.ecapa_forward(sd, f).numpy()).max() < REL_TOL
+    got = model(torch.from_numpy(feats[:3]))[-1].cpu().numpy()           # still fine after the re-size
+    assert _rel_err(got, ref[:3]).max() < REL_TOL
     assert model(torch.zeros(0, 100, 80))[-1].shape == (0, 192)           # empty batch
 
 
@@ -271,7 +282,7 @@ def test_speaker_api_end_to_end(tmp_path):
 def test_plda_matches_oracle_and_reference_golden(normalize_length, golden_dir):
     from wespeaker_amd import TwoCovPLDA
     p = synth.synth_plda(192, seed=7, normalize_length=normalize_length)
-    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
     emb, _ = synth.synth_embeddings(40, 192, seed=11)
     g = np.load(os.path.join(golden_dir, "plda_ref.npz"))
     tag = "nl%d" % int(normalize_length)
@@ -303,7 +314,7 @@ def test_plda_large_tables_take_the_gemm_paths(normalize_length):
     session counts take different contraction lengths (D vs 2D).  All must agree with the oracle."""
     from wespeaker_amd import TwoCovPLDA
     p = synth.synth_plda(192, seed=7, normalize_length=normalize_length)
-    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
     emb, _ = synth.synth_embeddings(700, 192, seed=3)
     mean = emb.mean(0).astype(np.float64)
     t_t = plda.prepare_test(emb[:300], mean).cpu().numpy()
@@ -327,7 +338,7 @@ def test_plda_large_tables_take_the_gemm_paths(normalize_length):
 def test_score_plda_and_eval_sv_files(tmp_path, normalize_length, multisession_avg):
     from wespeaker_amd import TwoCovPLDA, kaldi_io, score_plda
     p = synth.synth_plda(64, seed=3, normalize_length=normalize_length)
-    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], normalize_length)
     emb, spk = synth.synth_embeddings(60, 64, seed=5, num_speakers=6)
     enroll = {}
     for i in range(30):
@@ -575,7 +586,7 @@ def test_full_size_plda_one_million_trials():
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
     from wespeaker_amd import TwoCovPLDA
     p = synth.synth_plda(192, seed=7)
-    plda = TwoCovPLDA(p["mu"], p["transform"], p["psi"], p["offset"], False)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False)
     emb, _ = synth.synth_embeddings(4000, 192, seed=21)
     e_t = plda.prepare_test(emb[:2000])
     t_t = plda.prepare_test(emb[2000:])

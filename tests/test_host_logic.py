@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from wespeaker_amd import audio, kaldi_io, parallel, synth
+from wespeaker_amd import audio, kaldi_io, parallel
+from fixtures import synth
 
 
 def test_synth_is_deterministic():
@@ -94,3 +95,71 @@ def test_world_size_2_gather_on_gloo(n_total):
         assert p.exitcode == 0
     for rank, ok, shape in res:
         assert ok and shape == (n_total, 3), (rank, ok, shape)
+
+
+# ------------------------------------------------------------------------- PLDA model files
+def test_kaldi_plda_reader_matches_reference_reader(golden_dir):
+    """read_kaldi_plda against what the REFERENCE's read_plda (utils/plda/kaldi_utils.py:24-109)
+    returned for the same committed files (oracle/make_golden.py kaldi_plda); the text form has no
+    reference-side run (kaldi_io._read_mat_ascii is third-party) and is held to the same arrays."""
+    from wespeaker_amd.plda import TwoCovPLDA, read_kaldi_plda
+    g = np.load(os.path.join(golden_dir, "kaldi_plda_ref.npz"))
+    for tag in ("f32", "f64"):
+        mu, tr, psi = read_kaldi_plda(os.path.join(golden_dir, "kaldi_plda_%s.bin" % tag))
+        assert mu.dtype == tr.dtype == psi.dtype == np.float64
+        assert np.array_equal(mu, g[tag + "/mu"]) and np.array_equal(tr, g[tag + "/transform"])
+        assert np.array_equal(psi, g[tag + "/psi"])
+    mu, tr, psi = read_kaldi_plda(os.path.join(golden_dir, "kaldi_plda.txt"))
+    assert np.array_equal(mu, g["f64/mu"]) and np.array_equal(tr, g["f64/transform"])
+    assert np.array_equal(psi, g["f64/psi"])
+    # load_model(from_kaldi=True): offset = -transform @ mu (two_cov_plda.py:344-347)
+    plda = TwoCovPLDA.load_model(os.path.join(golden_dir, "kaldi_plda_f64.bin"), from_kaldi=True)
+    assert plda.dim == 6 and np.allclose(plda.offset, -g["f64/transform"] @ g["f64/mu"], atol=0)
+    assert plda.normalize_length is False
+
+
+def test_kaldi_plda_reader_rejects_damaged_files(tmp_path, golden_dir):
+    from wespeaker_amd.plda import read_kaldi_plda
+    raw = open(os.path.join(golden_dir, "kaldi_plda_f64.bin"), "rb").read()
+    for name, data in (("trunc", raw[:-20]), ("noend", raw[:-8] + b"garbage "), ("tag", raw.replace(b"DM ", b"XM "))):
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(ValueError):
+            read_kaldi_plda(str(p))
+    p = tmp_path / "other"
+    p.write_bytes(b"\0B<Nnet> ")
+    with pytest.raises(ValueError):
+        read_kaldi_plda(str(p))
+
+
+def test_plda_model_roundtrip_keeps_the_callers_file_name(tmp_path):
+    """Reference recipes pass suffix-less names (${exp_dir}/plda, exp/plda_adapt): save_model must
+    write exactly that path and load_model must read it back."""
+    from wespeaker_amd.plda import TwoCovPLDA
+    p = synth.synth_plda(8, seed=3, normalize_length=True)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], True, True)
+    for name in ("plda", "plda_adapt.npz", "model.h5"):
+        path = str(tmp_path / name)
+        plda.save_model(path)
+        assert os.path.exists(path) and not os.path.exists(path + ".npz")
+        back = TwoCovPLDA.load_model(path)
+        for k in ("mu", "transform", "psi", "offset"):
+            assert np.array_equal(getattr(back, k), getattr(plda, k))
+        assert back.normalize_length is True and back.subtract_train_set_mean is True
+    (tmp_path / "junk").write_bytes(b"not a model at all")
+    with pytest.raises(ValueError):
+        TwoCovPLDA.load_model(str(tmp_path / "junk"))
+
+
+def test_twocovplda_constructor_keeps_the_reference_positional_order():
+    """two_cov_plda.py:68-73: (scp_file, utt2spk_file, embed_dim, subtract_train_set_mean,
+    normalize_length); trained parameters are keyword-only here."""
+    import inspect
+    from wespeaker_amd.plda import TwoCovPLDA
+    sig = list(inspect.signature(TwoCovPLDA.__init__).parameters.values())[1:]
+    assert [p.name for p in sig[:5]] == ["scp_file", "utt2spk_file", "embed_dim",
+                                         "subtract_train_set_mean", "normalize_length"]
+    assert all(p.kind == inspect.Parameter.KEYWORD_ONLY for p in sig[5:])
+    bare = TwoCovPLDA(None, None, 32, True, False)
+    assert bare.dim == 32 and bare.subtract_train_set_mean and not bare.normalize_length
+    assert bare.mu.shape == (32,) and bare.transform.shape == (32, 32)

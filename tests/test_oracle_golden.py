@@ -12,7 +12,7 @@ from oracle import ecapa as oecapa
 from oracle import fbank as ofbank
 from oracle import plda as oplda
 from oracle import ref_shim
-from wespeaker_amd import synth
+from fixtures import synth
 
 
 def test_fbank_restatement_vs_reference_native(golden_dir):

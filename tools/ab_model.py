@@ -16,7 +16,8 @@ import wespeaker_amd._lib as L
 if sys.argv[5] == "old":
     L.LIB_PATH = os.path.join(root, "tools/bin/libws_old.so")
 import torch
-from wespeaker_amd import Frontend, NativeSpeakerModel, synth
+from wespeaker_amd import Frontend, NativeSpeakerModel
+from fixtures import synth
 from bench import device_wavs
 name, ed, batch, prec = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 dev = torch.device("cuda:0")

@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import ecapa as oecapa, fbank as ofbank
-from wespeaker_amd import NativeSpeakerModel, synth
+from wespeaker_amd import NativeSpeakerModel
+from fixtures import synth
 
 def rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)

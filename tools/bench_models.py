@@ -7,7 +7,8 @@ wav resident in HBM -> fbank -> CMN -> forward, both GEMM back-ends.  One JSON l
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from wespeaker_amd import Frontend, NativeSpeakerModel, synth
+from wespeaker_amd import Frontend, NativeSpeakerModel
+from fixtures import synth
 from bench import device_wavs
 
 CASES = [  # (model, embed_dim, batch, chunk)

@@ -18,7 +18,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from wespeaker_amd import score as wscore, synth  # noqa: E402
+from wespeaker_amd import score as wscore  # noqa: E402
+from fixtures import synth
 
 
 def timed(fn, reps=10, warmup=2):

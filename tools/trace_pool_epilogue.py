@@ -14,7 +14,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import wespeaker_amd._lib as L
 L.LIB_PATH = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools/bin/libws_trace.so")
 import torch
-from wespeaker_amd import Frontend, NativeSpeakerModel, synth
+from wespeaker_amd import Frontend, NativeSpeakerModel
+from fixtures import synth
 from bench import device_wavs
 dev = torch.device("cuda:0")
 fe = Frontend(16000, 80, device=dev)

@@ -2,7 +2,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from wespeaker_amd import Frontend, NativeSpeakerModel, synth
+from wespeaker_amd import Frontend, NativeSpeakerModel
+from fixtures import synth
 from bench import device_wavs
 dev = torch.device("cuda:0")
 sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)

@@ -17,7 +17,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libwespeaker_amd.so")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+         "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -66,7 +67,13 @@ def build(force=False, verbose=True):
             raise RuntimeError("compile failed: %s\n%s" % (" ".join(cmd), out))
     need_link = bool(jobs) or not os.path.exists(LIB) or force
     if need_link:
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        # only the C-ABI of include/wespeaker_amd.h leaves the library (kernel handles and every internal
+        # C++ symbol stay local)
+        vmap = os.path.join(OBJDIR, "exports.map")
+        with open(vmap, "w") as f:
+            f.write("{ global: ws_*; local: *; };\n")
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vmap,
+               "-o", LIB] + objs
         rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError("link failed:\n" + out)

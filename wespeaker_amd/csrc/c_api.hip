@@ -213,6 +213,23 @@ int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames) {
   return WS_OK;
 }
 
+int ws_engine_reserve(ws_engine* eng, int max_batch, int max_frames) {
+  if (!eng || max_batch <= 0 || max_frames <= 0) {
+    set_error("ws_engine_reserve: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_engine_reserve: engine not finalized"); return WS_ERR_STATE; }
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  return eng->model->reserve(max_batch, max_frames);
+}
+
+int ws_engine_max_batch(const ws_engine* eng) {
+  return eng && eng->finalized ? eng->model->max_batch() : WS_ERR_INVALID_ARG;
+}
+int ws_engine_max_frames(const ws_engine* eng) {
+  return eng && eng->finalized ? eng->model->max_frames() : WS_ERR_INVALID_ARG;
+}
+
 void ws_engine_destroy(ws_engine* eng) {
   if (!eng) return;
   delete eng->model;

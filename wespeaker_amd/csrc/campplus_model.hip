@@ -131,7 +131,12 @@ struct CamppModel : ModelBase {
                            "xvector.dense.nonlinear.batchnorm", "", &dense, /*fold_affine=*/false)))
         return err;
     }
+    if ((err = upload_weights())) return err;
+    return reserve(max_batch, max_frames);
+  }
 
+  int reserve(int max_batch, int max_frames) override {
+    int err = 0;
     maxB = max_batch; maxT = max_frames;
     const size_t img = (size_t)maxB * feat_dim * maxT * 32;        // FCM full-resolution activation
     const int Tp = (maxT - 1) / 2 + 1;
@@ -145,7 +150,7 @@ struct CamppModel : ModelBase {
            o_colsum = take(((Mp + 63) / 64 + 2) * 2 * 128),
            o_part = take((size_t)kSplitK * maxB * embed_dim),
            o_feats = take((size_t)maxB * maxT * feat_dim);
-    if ((err = upload_and_alloc(total))) return err;
+    if ((err = alloc_workspace(total))) return err;
     float* base = ws.as<float>();
     fa = base + o_fa; fb = base + o_fb; fc = base + o_fc; xbuf = base + o_x; xbuf2 = base + o_x2;
     colsum = base + o_colsum;

@@ -179,6 +179,8 @@ struct Model {
   virtual bool wants(const std::string& key) const = 0;
   virtual int finalize(const std::map<std::string, HostTensor>& sd, int max_batch,
                        int max_frames) = 0;
+  // re-size the workspace of a finalized model (synchronises the device)
+  virtual int reserve(int max_batch, int max_frames) = 0;
   virtual int forward(const float* feats, int batch, int frames, float* emb,
                       hipStream_t stream) = 0;
   virtual double flops(int batch, int frames) const = 0;

@@ -96,7 +96,14 @@ struct EcapaModel : ModelBase {
       final_lin.b = arena.add(B);
       final_lin.has_b = true;
     }
+    if ((err = upload_weights())) return err;
+    return reserve(max_batch, max_frames);
+  }
 
+  // workspace layout for chunks of max_batch utterances x max_frames frames (re-callable:
+  // ws_engine_reserve grows it when a longer utterance arrives)
+  int reserve(int max_batch, int max_frames) override {
+    int err = 0;
     maxB = max_batch; maxT = max_frames;
     const size_t M = (size_t)maxB * maxT;
     size_t total = 0;
@@ -108,7 +115,7 @@ struct EcapaModel : ModelBase {
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
            o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C + C + 512) + 1) / 2),   // binary16 copies (f16 back-end)
            o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
-    if ((err = upload_and_alloc(total))) return err;
+    if ((err = alloc_workspace(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
     h = base + o_h; att = base + o_att; e = base + o_e; se_s = base + o_s; stats = base + o_stats;

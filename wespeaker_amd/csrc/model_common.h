@@ -197,13 +197,18 @@ struct ModelBase : Model {
                      [=](int n, int, int ci) { return (size_t)n * Cin + ci; }, has_bias, "", "", out);
   }
 
-  int upload_and_alloc(size_t ws_floats) {
+  int upload_weights() {
     hipError_t he = arena.upload();
     if (he != hipSuccess) {
       set_error("weight upload failed: %s", hipGetErrorString(he));
       return WS_ERR_HIP;
     }
-    he = ws.alloc(ws_floats * sizeof(float));
+    return 0;
+  }
+  // (re)allocates the workspace; earlier launches may still be using the old one
+  int alloc_workspace(size_t ws_floats) {
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = ws.alloc(ws_floats * sizeof(float));
     if (he != hipSuccess) {
       set_error("workspace allocation of %zu MB failed: %s", (ws_floats * 4) >> 20,
                 hipGetErrorString(he));

@@ -112,10 +112,15 @@ struct ResNetModel : ModelBase {
       seg1.scale = seg_bn_scale; seg1.shift = seg_bn_shift;     // relu -> BN(affine=False) epilogue
       if ((err = pack_linear(sd, "seg_2", embed_dim, embed_dim, true, &seg2))) return err;
     }
+    if ((err = upload_weights())) return err;
+    return reserve(max_batch, max_frames);
+  }
 
+  int reserve(int max_batch, int max_frames) override {
+    int err = 0;
     maxB = max_batch; maxT = max_frames;
     // largest activation: stage-1 output (F x T x 32*exp); scratch planes are never larger
-    const size_t act = (size_t)maxB * feat_dim * maxT * (size_t)(m * exp);
+    const size_t act = (size_t)maxB * feat_dim * maxT * (size_t)(32 * exp);
     size_t total = 0;
     auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
     size_t ob[4];
@@ -123,7 +128,7 @@ struct ResNetModel : ModelBase {
     size_t o_pool = take((size_t)maxB * 2 * stats_dim),
            o_part = take((size_t)kSplitK * maxB * embed_dim), o_emba = take((size_t)maxB * embed_dim),
            o_feats = take((size_t)maxB * maxT * feat_dim);
-    if ((err = upload_and_alloc(total))) return err;
+    if ((err = alloc_workspace(total))) return err;
     float* base = ws.as<float>();
     for (int i = 0; i < 4; ++i) buf[i] = base + ob[i];
     pooled = base + o_pool; partial = base + o_part; emb_a = base + o_emba; feats_ws = base + o_feats;

@@ -109,6 +109,7 @@ class NativeSpeakerModel:
             if not used:
                 self.ignored_keys.append(key)
         _lib.check(L.ws_engine_finalize(h, self.max_batch, self.max_frames), "ws_engine_finalize")
+        self._rows_budget = self.max_batch * self.max_frames
         self.precision = "fp32"
 
     def __del__(self):
@@ -160,10 +161,20 @@ class NativeSpeakerModel:
         return {n: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i])
                 for i, n in enumerate(self.PROFILE_CLASSES)}
 
+    def reserve(self, max_batch, max_frames):
+        """Re-size the engine workspace (ws_engine_reserve; synchronises the device)."""
+        _lib.check(_lib.lib().ws_engine_reserve(self._h, int(max_batch), int(max_frames)),
+                   "ws_engine_reserve")
+        self.max_batch, self.max_frames = int(max_batch), int(max_frames)
+
     def _ensure_capacity(self, frames):
+        """The reference takes utterances of any length (cli/speaker.py:125-167): when one exceeds the
+        finalized capacity the workspace is re-laid-out for it, keeping rows (= max_batch x max_frames,
+        i.e. the memory footprint) about constant -- longer utterances run in smaller chunks."""
         if frames > self.max_frames:
-            raise _lib.NativeError("utterance has %d frames, engine capacity is %d (pass max_frames)"
-                                   % (frames, self.max_frames))
+            rows = self._rows_budget
+            new_frames = -(-int(frames * 1.25) // 100) * 100
+            self.reserve(max(1, min(self.max_batch, rows // new_frames)), new_frames)
 
     def embed(self, feats: torch.Tensor) -> torch.Tensor:
         """(B, T, F) float32 -> (B, E) float32 on the GPU."""

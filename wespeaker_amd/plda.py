@@ -14,6 +14,7 @@ EM training / adaptation (two_cov_plda.py:38-154,258-309): `TwoCovPLDA(scp_file=
 D x D algebra in numpy float64 (wespeaker_amd/plda_train.py).
 """
 import ctypes
+import os
 import struct
 from collections import OrderedDict
 from ctypes import c_void_p
@@ -32,9 +33,10 @@ def _f64(x):
 
 class TwoCovPLDA:
 
-    def __init__(self, mu=None, transform=None, psi=None, offset=None, normalize_length=False,
-                 subtract_train_set_mean=False, embed_dim=256, device=None, scp_file=None,
-                 utt2spk_file=None):
+    def __init__(self, scp_file=None, utt2spk_file=None, embed_dim=256, subtract_train_set_mean=False,
+                 normalize_length=False, *, mu=None, transform=None, psi=None, offset=None, device=None):
+        """Positional parameters are the reference's (two_cov_plda.py:68-73); the in-memory parameters
+        of a trained model are keyword-only (see `from_params`)."""
         self.normalize_length = bool(normalize_length)
         self.subtract_train_set_mean = bool(subtract_train_set_mean)
         self.dim = int(embed_dim if mu is None else np.asarray(mu).shape[0])
@@ -55,6 +57,14 @@ class TwoCovPLDA:
             self.dim = self.stats.dim
             self.B, self.W = np.eye(self.dim), np.eye(self.dim)
             self.mu = self.stats.sum_ / self.stats.class_weight
+
+    @classmethod
+    def from_params(cls, mu, transform, psi, offset=None, normalize_length=False,
+                    subtract_train_set_mean=False, device=None):
+        """A trained model from its parameters (what load_model builds attribute by attribute in the
+        reference, two_cov_plda.py:341-363)."""
+        return cls(normalize_length=normalize_length, subtract_train_set_mean=subtract_train_set_mean,
+                   mu=mu, transform=transform, psi=psi, offset=offset, device=device)
 
     # ---------------------------------------------------------------- training (host f64 on GPU stats)
     def em_one_iter(self):
@@ -80,7 +90,7 @@ class TwoCovPLDA:
         mu, tr, psi, off = plda_train.adapt_parameters(self.mu, self.transform, self.psi, rows,
                                                        self.normalize_length, ac_scale, wc_scale,
                                                        self._device)
-        return TwoCovPLDA(mu, tr, psi, off, device=self._device)
+        return TwoCovPLDA.from_params(mu, tr, psi, off, device=self._device)
 
     # ------------------------------------------------------------------------------ native handle
     @property
@@ -116,26 +126,51 @@ class TwoCovPLDA:
     def load_model(model_name, from_kaldi=False, device=None):
         if from_kaldi:
             mu, tr, psi = read_kaldi_plda(model_name)
-            return TwoCovPLDA(mu, tr, psi, -1.0 * np.matmul(tr, mu), device=device)
-        if str(model_name).endswith(".npz"):
-            with np.load(model_name) as f:
-                return TwoCovPLDA(f["mu"], f["transform"], f["psi"], f["offset"],
-                                  bool(f["normalize_length"]), bool(f["subtract_train_set_mean"]),
-                                  device=device)
+            return TwoCovPLDA.from_params(mu, tr, psi, -1.0 * np.matmul(tr, mu), device=device)
+        # the format is read off the file's magic, not its name: save_model keeps the caller's exact
+        # path (reference recipes pass suffix-less names such as ${exp_dir}/plda)
+        path = str(model_name)
+        if not os.path.exists(path) and os.path.exists(path + ".npz"):
+            path = path + ".npz"
+        with open(path, "rb") as fh:
+            magic = fh.read(8)
+        if magic[:2] == b"PK":                       # zip container = numpy .npz
+            with np.load(path) as f:
+                return TwoCovPLDA.from_params(f["mu"], f["transform"], f["psi"], f["offset"],
+                                              bool(f["normalize_length"]),
+                                              bool(f["subtract_train_set_mean"]), device=device)
+        if magic != b"\x89HDF\r\n\x1a\n":
+            raise ValueError("%s is neither a .npz nor an HDF5 PLDA model" % path)
+        model_name = path
         try:
             import h5py
         except ImportError as e:
             raise ImportError("reading the reference's HDF5 PLDA models needs h5py (not installed); "
                               "use .npz or from_kaldi=True") from e
         with h5py.File(model_name, "r") as f:
-            return TwoCovPLDA(f.get("mu")[()], f.get("transform")[()], f.get("psi")[()],
-                              f.get("offset")[()], bool(f.get("normalize_length")[()]),
-                              bool(f.get("subtract_train_set_mean")[()]), device=device)
+            return TwoCovPLDA.from_params(f.get("mu")[()], f.get("transform")[()], f.get("psi")[()],
+                                          f.get("offset")[()], bool(f.get("normalize_length")[()]),
+                                          bool(f.get("subtract_train_set_mean")[()]), device=device)
 
     def save_model(self, output_file_name):
-        np.savez(output_file_name, mu=self.mu, transform=self.transform, psi=self.psi,
-                 offset=self.offset, normalize_length=int(self.normalize_length),
-                 subtract_train_set_mean=int(self.subtract_train_set_mean))
+        """Writes exactly `output_file_name` (np.savez on a path would append '.npz'): HDF5 like the
+        reference (two_cov_plda.py:311-339) when h5py is importable, numpy's .npz container otherwise;
+        load_model tells them apart by the file magic."""
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(output_file_name, "w") as f:
+                for k in ("mu", "transform", "psi", "offset"):
+                    f.create_dataset(k, data=getattr(self, k))
+                f.create_dataset("normalize_length", data=int(self.normalize_length))
+                f.create_dataset("subtract_train_set_mean", data=int(self.subtract_train_set_mean))
+            return
+        with open(output_file_name, "wb") as fh:
+            np.savez(fh, mu=self.mu, transform=self.transform, psi=self.psi,
+                     offset=self.offset, normalize_length=int(self.normalize_length),
+                     subtract_train_set_mean=int(self.subtract_train_set_mean))
 
     # ------------------------------------------------------------------------- device primitives
     def _dev(self, x, dtype):
@@ -300,30 +335,64 @@ def score_plda(plda: TwoCovPLDA, enroll_embeddings, test_embeddings, trials,
 
 # ------------------------------------------------------------------------------- Kaldi <Plda>
 def read_kaldi_plda(path):
-    """Binary Kaldi `<Plda>` (mean vector, transform matrix, psi vector; float or double) as read
-    by utils/plda/kaldi_utils.py:24-55."""
+    """Kaldi `<Plda>` object (mean vector, transform matrix, psi vector), binary (float or double
+    payloads) or text, with the layout utils/plda/kaldi_utils.py:24-55 reads:
+        binary:  '\\0B' '<Plda> ' vec mat vec '</Plda> '   (vec = 'FV '|'DV ' \\4 <i32 n> data;
+                                                           mat = 'FM '|'DM ' \\4 <i32 r> \\4 <i32 c> data)
+        text:    '<Plda> ' ' [ m ... ]\\n' ' [\\n  row\\n  row ]\\n' ' [ psi ... ]\\n' '</Plda> '
+    Returns float64 (mu, transform, psi)."""
     with open(path, "rb") as fd:
-        if fd.read(2) != b"\0B":
-            raise NotImplementedError("text-format Kaldi PLDA is not supported; convert to binary")
-        if fd.read(7) != b"<Plda> ":
-            raise ValueError("not a Kaldi <Plda> file: " + str(path))
+        head = fd.read(2)
+        if head == b"\0B":
+            if fd.read(7) != b"<Plda> ":
+                raise ValueError("not a Kaldi <Plda> file: " + str(path))
 
-        def vec():
-            tag = fd.read(3)
-            size = {b"FV ": 4, b"DV ": 8}[tag]
-            assert fd.read(1) == b"\x04"
-            n = struct.unpack("<i", fd.read(4))[0]
-            return np.frombuffer(fd.read(n * size), dtype="<f4" if size == 4 else "<f8").astype(np.float64)
+            def payload(tags, n_dims):
+                tag = fd.read(3)
+                if tag not in tags:
+                    raise ValueError("unexpected Kaldi data tag %r in %s" % (tag, path))
+                size = 4 if tag[:1] == b"F" else 8
+                dims = []
+                for _ in range(n_dims):
+                    if fd.read(1) != b"\x04":
+                        raise ValueError("bad int-size byte in " + str(path))
+                    dims.append(struct.unpack("<i", fd.read(4))[0])
+                count = int(np.prod(dims))
+                buf = fd.read(count * size)
+                if len(buf) != count * size:
+                    raise ValueError("truncated Kaldi <Plda> file: " + str(path))
+                return np.frombuffer(buf, dtype="<f4" if size == 4 else "<f8").astype(np.float64).reshape(dims)
 
-        def mat():
-            tag = fd.read(3)
-            size = {b"FM ": 4, b"DM ": 8}[tag]
-            assert fd.read(1) == b"\x04"
-            r = struct.unpack("<i", fd.read(4))[0]
-            assert fd.read(1) == b"\x04"
-            c = struct.unpack("<i", fd.read(4))[0]
-            return np.frombuffer(fd.read(r * c * size),
-                                 dtype="<f4" if size == 4 else "<f8").astype(np.float64).reshape(r, c)
+            mu = payload((b"FV ", b"DV "), 1)
+            tr = payload((b"FM ", b"DM "), 2)
+            psi = payload((b"FV ", b"DV "), 1)
+            tail = fd.read(8)
+        else:
+            if head + fd.read(5) != b"<Plda> ":
+                raise ValueError("not a Kaldi <Plda> file: " + str(path))
 
-        mu, tr, psi = vec(), mat(), vec()
+            def numbers(line):
+                return [float(t) for t in line.decode().replace("[", " ").replace("]", " ").split()]
+
+            mu = np.array(numbers(fd.readline()), dtype=np.float64)
+            rows = []
+            opened = False
+            while True:                         # " [" then one row per line, the last one closed by "]"
+                line = fd.readline()
+                if not line:
+                    raise ValueError("truncated Kaldi <Plda> text file: " + str(path))
+                opened = opened or b"[" in line
+                vals = numbers(line)
+                if vals:
+                    rows.append(vals)
+                if opened and b"]" in line:
+                    break
+            tr = np.array(rows, dtype=np.float64)
+            psi = np.array(numbers(fd.readline()), dtype=np.float64)
+            tail = fd.read(8)
+        if tail != b"</Plda> ":
+            raise ValueError("missing </Plda> terminator in " + str(path))
+    if tr.shape != (mu.shape[0], mu.shape[0]) or psi.shape != mu.shape:
+        raise ValueError("inconsistent <Plda> dimensions in %s: mean %s transform %s psi %s"
+                         % (path, mu.shape, tr.shape, psi.shape))
     return mu, tr, psi

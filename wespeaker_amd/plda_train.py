@@ -187,14 +187,15 @@ def adapt_parameters(mu, transform, psi, adp_rows, normalize_length, ac_scale=0.
 # ------------------------------------------------------- bin/train_plda.py, bin/adapt_plda.py
 def train_plda(scp_path, utt2spk, indim, exp_dir, iter=5, type="2cov"):   # noqa: A002 (reference flag names)
     """bin/train_plda.py: --type 2cov --scp_path --utt2spk --indim --exp_dir --iter.
-    Saves `exp_dir/plda.npz` (the reference writes HDF5 `exp_dir/plda`; h5py is not required here)."""
+    Saves `exp_dir/plda` like the reference (HDF5 when h5py is importable, else numpy's .npz container
+    under the same name; TwoCovPLDA.load_model sniffs the format)."""
     import os
     from .plda import TwoCovPLDA
     if type != "2cov":
         raise ValueError("only the kaldi 2cov version is supported (as in the reference)")
     plda = TwoCovPLDA(scp_file=scp_path, utt2spk_file=utt2spk, embed_dim=indim)
     plda.train(iter)
-    path = os.path.join(exp_dir, "plda.npz")
+    path = os.path.join(exp_dir, "plda")
     plda.save_model(path)
     return path
 
