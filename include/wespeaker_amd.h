@@ -204,14 +204,15 @@ WS_API int ws_plda_llr_pairs(ws_plda* plda, const double* enroll, const int32_t*
  * The N x D^2 part of TwoCovPLDA training / adaptation: PldaStats.add_samples over every speaker
  * (two_cov_plda.py:48-66) after the constructor's pre-processing (:95-107: subtract the train-set
  * mean, optional length normalisation), and -- with one group -- the mean / np.cov of adapt() (:261-275).
- * emb DEVICE float32 (n, dim), rows grouped by class: class c = rows [group_offsets[c],
+ * emb DEVICE (n, dim) float32 (emb_is_f64 = 0) or float64 (1: rows that already went through a link of
+ * the embedding-processing chain, which the reference keeps in float64), rows grouped by class: class c = rows [group_offsets[c],
  * group_offsets[c+1]); group_offsets DEVICE int32[n_groups+1]; mean_vec DEVICE float64[dim] or NULL;
  * class_mean DEVICE float64 (n_groups, dim) <- mu_c; scatter DEVICE float64 (dim, dim) <-
  * sum_c sum_{i in c} (y_i - mu_c)(y_i - mu_c)^T with y = normalised (x - mean_vec);
  * scratch DEVICE float64[>= ws_plda_stats_scratch(n, dim)].  The D x D algebra of the EM steps
  * (inv / cholesky / eigh, :116-154) stays with the caller in float64. */
 WS_API int64_t ws_plda_stats_scratch(int n, int dim);
-WS_API int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets, int n_groups,
+WS_API int ws_plda_stats(const void* emb, int emb_is_f64, int n, int dim, const int32_t* group_offsets, int n_groups,
                   const double* mean_vec, int normalize_length, double* class_mean, double* scatter,
                   double* scratch, int64_t scratch_doubles, ws_stream stream);
 

@@ -163,3 +163,24 @@ def test_twocovplda_constructor_keeps_the_reference_positional_order():
     bare = TwoCovPLDA(None, None, 32, True, False)
     assert bare.dim == 32 and bare.subtract_train_set_mean and not bare.normalize_length
     assert bare.mu.shape == (32,) and bare.transform.shape == (32, 32)
+
+
+def test_chain_string_parser_known_answers():
+    """The grammar of wespeaker/utils/embedding_processing.py:23-67 (its own docstring example first);
+    checked live against the reference function when /root/reference is present."""
+    from wespeaker_amd.embedding_processing import chain_string_to_dict
+    example = ("mean-subtract --scp mean1_xvector.scp | length-norm | lda  --scp lda_xvector.scp "
+               "--utt2spk utt2spk --dim 100 | length-norm")
+    assert chain_string_to_dict(example) == [
+        ["mean-subtract", {"scp": "mean1_xvector.scp"}], ["length-norm", {}],
+        ["lda", {"scp": "lda_xvector.scp", "utt2spk": "utt2spk", "dim": "100"}], ["length-norm", {}]]
+    assert chain_string_to_dict(None) == []
+    assert chain_string_to_dict("lda --dim=20 --eps 1e-5") == [["lda", {"dim": "20", "eps": "1e-5"}]]
+    with pytest.raises(AssertionError):
+        chain_string_to_dict("lda --dim")
+    from oracle import ref_shim
+    if ref_shim.available():
+        ref = ref_shim.ref_module("wespeaker.utils.embedding_processing").chain_string_to_dict
+        for c in (example, "whitening | length-norm ", " length-norm", "mean-subtract --scp a|length-norm",
+                  "lda --dim=20 --scp  x --utt2spk=u --eps 1e-5"):
+            assert chain_string_to_dict(c) == ref(c)

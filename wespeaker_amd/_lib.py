@@ -52,7 +52,7 @@ SIGNATURES = {
     "ws_plda_llr_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ws_plda_stats_scratch": (c_int64, [c_int, c_int]),
-    "ws_plda_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+    "ws_plda_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int64, c_void_p]),
     "ws_rows_affine": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_void_p]),

@@ -546,7 +546,7 @@ int64_t ws_plda_stats_scratch(int n, int dim) {
   return plda_stats_scratch_doubles(n, dim);
 }
 
-int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets, int n_groups,
+int ws_plda_stats(const void* emb, int emb_is_f64, int n, int dim, const int32_t* group_offsets, int n_groups,
                   const double* mean_vec, int normalize_length, double* class_mean, double* scatter,
                   double* scratch, int64_t scratch_doubles, ws_stream stream) {
   if (!emb || !group_offsets || !class_mean || !scatter || !scratch || n <= 0 || dim <= 0 ||
@@ -559,7 +559,7 @@ int ws_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets
               (long long)scratch_doubles, (long long)plda_stats_scratch_doubles(n, dim));
     return WS_ERR_CAPACITY;
   }
-  WS_HIP_CHECK(launch_plda_stats(emb, n, dim, group_offsets, n_groups, mean_vec, normalize_length,
+  WS_HIP_CHECK(launch_plda_stats(emb, emb_is_f64, n, dim, group_offsets, n_groups, mean_vec, normalize_length,
                                  class_mean, scatter, scratch, (hipStream_t)stream));
   return WS_OK;
 }

@@ -201,7 +201,7 @@ hipError_t launch_conv3x3_direct(const ConvGemmParams& p, hipStream_t stream);
 
 // -------- PLDA training statistics (plda_train.hip; two_cov_plda.py:48-66,95-107,261-275)
 int64_t plda_stats_scratch_doubles(int n, int dim);
-hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets,
+hipError_t launch_plda_stats(const void* emb, int emb_is_f64, int n, int dim, const int32_t* group_offsets,
                              int n_groups, const double* mean_vec, int normalize_length,
                              double* class_mean, double* scatter, double* scratch,
                              hipStream_t stream);

@@ -362,10 +362,14 @@ __global__ __launch_bounds__(256) void plda_llr_pairs_kernel(
     const double* ea = EA + (long long)i * K;
     const double* tt = TT + (long long)j * K;
     double s = 0.0;
-    for (int k = sub * 2; k < K; k += 32) {
-      const double2 a = *reinterpret_cast<const double2*>(ea + k);
-      const double2 t = *reinterpret_cast<const double2*>(tt + k);
-      s += a.x * t.x + a.y * t.y;
+    if (K & 1) {        // odd row length: rows are only 8-byte aligned, no double2 gathers
+      for (int k = sub; k < K; k += 16) s += ea[k] * tt[k];
+    } else {
+      for (int k = sub * 2; k < K; k += 32) {
+        const double2 a = *reinterpret_cast<const double2*>(ea + k);
+        const double2 t = *reinterpret_cast<const double2*>(tt + k);
+        s += a.x * t.x + a.y * t.y;
+      }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);

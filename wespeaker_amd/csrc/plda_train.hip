@@ -28,7 +28,8 @@ __device__ __forceinline__ double wave_sum_dt(double v) {
 }
 
 // one wavefront per row: s_i; one workgroup (4 waves) handles 4 rows
-__global__ __launch_bounds__(256) void stats_rowscale_kernel(const float* __restrict__ emb, int n,
+template <typename T>
+__global__ __launch_bounds__(256) void stats_rowscale_kernel(const T* __restrict__ emb, int n,
                                                              int dim,
                                                              const double* __restrict__ mean_vec,
                                                              int normalize, double* __restrict__ scale) {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void stats_rowscale_kernel(const float* __rest
   if (row >= n) return;
   double s = 1.0;
   if (normalize) {
-    const float* x = emb + (long long)row * dim;
+    const T* x = emb + (long long)row * dim;
     double ss = 0.0;
     for (int d = lane; d < dim; d += 64) {
       const double v = (double)x[d] - (mean_vec ? mean_vec[d] : 0.0);
@@ -49,8 +50,9 @@ __global__ __launch_bounds__(256) void stats_rowscale_kernel(const float* __rest
 }
 
 // one workgroup per class: mu_c and the class index of its rows
+template <typename T>
 __global__ __launch_bounds__(256) void stats_class_mean_kernel(
-    const float* __restrict__ emb, int dim, const int32_t* __restrict__ group_offsets,
+    const T* __restrict__ emb, int dim, const int32_t* __restrict__ group_offsets,
     const double* __restrict__ mean_vec, const double* __restrict__ scale,
     double* __restrict__ class_mean, int32_t* __restrict__ row_class) {
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -69,8 +71,9 @@ constexpr int TS = 64 + 16;      // LDS row stride in doubles: rows k, k+1 land 
                                  // (16 columns x 2 rows) of a 32-lane ds_read_b64 phase cover 64 banks
 
 // grid = (tiles_d * tiles_d, Z); block = 256.  partial[z][D][D].
+template <typename T>
 __global__ __launch_bounds__(256) void stats_scatter_kernel(
-    const float* __restrict__ emb, int n, int dim, const double* __restrict__ mean_vec,
+    const T* __restrict__ emb, int n, int dim, const double* __restrict__ mean_vec,
     const double* __restrict__ scale, const double* __restrict__ class_mean,
     const int32_t* __restrict__ row_class, int rows_per_z, double* __restrict__ partial) {
   __shared__ double Ys[2][TK * TS];          // [operand][row k][64 columns]
@@ -161,28 +164,42 @@ int64_t plda_stats_scratch_doubles(int n, int dim) {
   return (int64_t)n + (int64_t)z * dim * dim + ((int64_t)n + 1) / 2 + 8;
 }
 
-hipError_t launch_plda_stats(const float* emb, int n, int dim, const int32_t* group_offsets,
-                             int n_groups, const double* mean_vec, int normalize_length,
-                             double* class_mean, double* scatter, double* scratch,
-                             hipStream_t stream) {
+template <typename T>
+static hipError_t launch_plda_stats_t(const T* emb, int n, int dim, const int32_t* group_offsets,
+                                      int n_groups, const double* mean_vec, int normalize_length,
+                                      double* class_mean, double* scatter, double* scratch,
+                                      hipStream_t stream) {
   if (n <= 0 || n_groups <= 0) return hipSuccess;
   const int Z = scatter_splits(n, dim);
   double* scale = scratch;
   double* partial = scale + n;
   int32_t* row_class = reinterpret_cast<int32_t*>(partial + (long long)Z * dim * dim);
-  hipLaunchKernelGGL(stats_rowscale_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, emb, n, dim,
+  hipLaunchKernelGGL(stats_rowscale_kernel<T>, dim3((n + 3) / 4), dim3(256), 0, stream, emb, n, dim,
                      mean_vec, normalize_length, scale);
-  hipLaunchKernelGGL(stats_class_mean_kernel, dim3(n_groups), dim3(256), 0, stream, emb, dim,
+  hipLaunchKernelGGL(stats_class_mean_kernel<T>, dim3(n_groups), dim3(256), 0, stream, emb, dim,
                      group_offsets, mean_vec, scale, class_mean, row_class);
   const int tiles = (dim + 63) / 64;
   int rows_per_z = (n + Z - 1) / Z;
   rows_per_z = (rows_per_z + TK - 1) / TK * TK;
-  hipLaunchKernelGGL(stats_scatter_kernel, dim3(tiles * tiles, Z), dim3(256), 0, stream, emb, n, dim,
+  hipLaunchKernelGGL(stats_scatter_kernel<T>, dim3(tiles * tiles, Z), dim3(256), 0, stream, emb, n, dim,
                      mean_vec, scale, class_mean, row_class, rows_per_z, partial);
   const long long count = (long long)dim * dim;
   hipLaunchKernelGGL(stats_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
                      partial, Z, count, scatter);
   return hipGetLastError();
+}
+
+// emb: float32 rows (extractor output) or float64 rows (output of an earlier embedding-processing link,
+// which the reference keeps in float64: utils/embedding_processing.py:132-178)
+hipError_t launch_plda_stats(const void* emb, int emb_is_f64, int n, int dim, const int32_t* group_offsets,
+                             int n_groups, const double* mean_vec, int normalize_length,
+                             double* class_mean, double* scatter, double* scratch,
+                             hipStream_t stream) {
+  if (emb_is_f64)
+    return launch_plda_stats_t(reinterpret_cast<const double*>(emb), n, dim, group_offsets, n_groups,
+                               mean_vec, normalize_length, class_mean, scatter, scratch, stream);
+  return launch_plda_stats_t(reinterpret_cast<const float*>(emb), n, dim, group_offsets, n_groups,
+                             mean_vec, normalize_length, class_mean, scatter, scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

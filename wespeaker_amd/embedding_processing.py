@@ -22,21 +22,29 @@ from . import _lib, plda_train
 from .kaldi_io import VectorWriter, read_vec_scp
 
 
+_OPTION = re.compile(r"--\s*([^\s=]+)\s*[=\s]\s*(\S+)\s*")
+
+
 def chain_string_to_dict(chain_string=None):
-    """embedding_processing.py:23-67."""
-    links = chain_string.split('|') if chain_string is not None else []
-    a = []
-    for link in links:
-        x = link.split('--')
-        method = x.pop(0).strip(' ')
-        args_and_values = {}
-        for xx in x:
-            xx = re.sub("=", " ", xx)
-            xx = re.sub(" +", " ", xx).strip(' ').split(' ')
-            assert len(xx) == 2
-            args_and_values[xx[0]] = xx[1]
-        a.append([method, args_and_values])
-    return a
+    """'mean-subtract --scp a.scp | lda --scp b.scp --utt2spk u --dim 100 | length-norm' ->
+    [['mean-subtract', {'scp': 'a.scp'}], ['lda', {...}], ['length-norm', {}]]: links are separated
+    by '|', every option is `--name value` or `--name=value`, values stay strings
+    (same grammar and return structure as embedding_processing.py:23-67)."""
+    if chain_string is None:
+        return []
+    parsed = []
+    for piece in chain_string.split("|"):
+        head, dashes, tail = piece.partition("--")
+        options = {}
+        pos, tail = 0, dashes + tail
+        while pos < len(tail):
+            hit = _OPTION.match(tail, pos)
+            if hit is None:
+                raise AssertionError("malformed option in chain link %r" % piece)
+            options[hit.group(1)] = hit.group(2)
+            pos = hit.end()
+        parsed.append([head.strip(" "), options])
+    return parsed
 
 
 def _apply_link(embd, sub=None, M=None, normalize=False):
@@ -76,7 +84,7 @@ class Lda:
         counts = np.array([m.shape[0] for m in mats])
         offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         rows = current_chain(np.vstack(mats))
-        means, scatter = plda_train.gpu_stats(rows.astype(np.float32), offs)
+        means, scatter = plda_train.gpu_stats(rows, offs)          # float64 rows stay float64
         print("  #speakers: {}, #used {}, #skipped {} (only having one utterances)".format(
             len(embeddings_dict), len(mats), n_skipped))
         if equal_speaker_weight:
@@ -92,21 +100,22 @@ class Lda:
         return mean, between, within
 
     def __init__(self, args, current_chain=None):
+        """Attributes `m` (global mean) and `lda` (D x dim projection) as in the reference (:132-178):
+        the within-class covariance is whitened through its own eigen-decomposition (eigenvalues
+        floored at eps x the largest, as Kaldi does), the between-class covariance is diagonalised in
+        that whitened space, and the `dim` leading directions are mapped back."""
         import scipy.linalg as spl
-        print(" LDA")
-        dim = int(args['dim'])
-        eps = float(args['eps']) if 'eps' in args else 1e-6
-        self.m, BC, WC = self.compute_mean_and_lda_scatter_matrices(args['scp'], args['utt2spk'],
-                                                                    current_chain=current_chain)
-        E, M = spl.eigh(WC)
-        E_floor = np.max(E) * eps                    # floor like Kaldi (:147-150)
-        E[E < E_floor] = E_floor
-        T1 = np.dot(np.diag(1 / np.sqrt(E)), M.T)
-        BC = np.dot(np.dot(T1, BC), T1.T)
-        D, lda = spl.eigh(BC)
-        self.lda = np.dot(T1.T, lda[:, -dim:])
-        print("  Input dimension: {}, output dimension: {}, sum of all eigenvalues {:.2f}, sum of kept "
-              "eigenvalues {:.2f}".format(len(D), dim, np.sum(D), np.sum(D[-dim:])))
+        out_dim = int(args['dim'])
+        floor_ratio = float(args.get('eps', 1e-6))
+        self.m, between, within = self.compute_mean_and_lda_scatter_matrices(
+            args['scp'], args['utt2spk'], current_chain=current_chain)
+        w_val, w_vec = spl.eigh(within)
+        w_val = np.maximum(w_val, w_val.max() * floor_ratio)
+        whiten = w_vec / np.sqrt(w_val)                   # columns scaled: whiten.T @ within @ whiten = I
+        b_val, b_vec = spl.eigh(whiten.T @ between @ whiten)      # ascending eigenvalues
+        self.lda = whiten @ b_vec[:, -out_dim:]
+        print("LDA: %d -> %d dimensions; between-class eigenvalue mass kept %.2f of %.2f"
+              % (b_val.shape[0], out_dim, b_val[-out_dim:].sum(), b_val.sum()))
 
     def __call__(self, embd):
         return _apply_link(embd, sub=self.m, M=self.lda)
@@ -135,7 +144,7 @@ class MeanSubtraction:
             current_chain = lambda e: e  # noqa: E731
         e = np.vstack(list(read_vec_scp(args['scp']).values()))
         rows = np.asarray(current_chain(e))
-        means, _ = plda_train.gpu_stats(rows.astype(np.float32), [0, rows.shape[0]])
+        means, _ = plda_train.gpu_stats(rows, [0, rows.shape[0]])
         self.mean = means[0]
 
     def __call__(self, embd):
@@ -147,38 +156,46 @@ class EmbeddingProcessingChain:
                     'mean-subtract': MeanSubtraction}
 
     def __init__(self, chain=None):
+        # `chain_of_classes` is the pickled attribute of the reference (:232-244) -- name kept so that
+        # chains saved by either implementation load in the other
         self.chain_of_classes = []
-        for m, a in chain_string_to_dict(chain):
-            print("Method: {}".format(m))
-            print("Argument: {}".format(a))
-            self.chain_of_classes.append(self.string2class[m](a, self))
+        for method, options in chain_string_to_dict(chain):
+            self.chain_of_classes.append(self._build(method, options))
+
+    def _build(self, method, options):
+        if method not in self.string2class:
+            raise KeyError("unknown embedding-processing link %r (known: %s)"
+                           % (method, ", ".join(sorted(self.string2class))))
+        print("embedding processing: building link %r with %s" % (method, options))
+        return self.string2class[method](options, self)
 
     def __call__(self, embd):
-        for c in self.chain_of_classes:
-            embd = c(embd)
+        for link in self.chain_of_classes:
+            embd = link(embd)
         return embd
 
     def save(self, path, data_format='pickle'):
-        print("Saving embedding processing chain to {}".format(path))
         with open(path, 'wb') as f:
             pickle.dump(self.chain_of_classes, f)
+        print("embedding processing: %d links written to %s" % (len(self.chain_of_classes), path))
 
     def load(self, path, data_format='pickle'):
-        print("Loading embedding processing chain from {}".format(path))
         with open(path, 'rb') as f:
             self.chain_of_classes = pickle.load(f)
+        print("embedding processing: %d links read from %s" % (len(self.chain_of_classes), path))
 
     def update_link(self, link_no_to_replace, new_link):
-        nl = chain_string_to_dict(new_link)
-        assert len(nl) == 1, "Length of new chain must be one."
-        m, a = nl[0]
-        old, self.chain_of_classes = self.chain_of_classes, []
-        for i, ol in enumerate(old):
-            if i != link_no_to_replace:
-                self.chain_of_classes.append(ol)
-            else:
-                print("Replacing link number {} ({}) with".format(i, ol))
-                self.chain_of_classes.append(self.string2class[m](a, self))
+        """Rebuild ONE link in place (:246-271); the replacement is estimated on the output of the
+        links in front of it, so it is constructed against the truncated chain."""
+        spec = chain_string_to_dict(new_link)
+        assert len(spec) == 1, "Length of new chain must be one."
+        if not 0 <= link_no_to_replace < len(self.chain_of_classes):
+            return
+        method, options = spec[0]
+        tail = self.chain_of_classes[link_no_to_replace + 1:]
+        self.chain_of_classes = self.chain_of_classes[:link_no_to_replace]
+        self.chain_of_classes.append(self._build(method, options))
+        self.chain_of_classes.extend(tail)
 
 
 # --------------------------------------------------- bin/prep_embd_proc.py, bin/apply_embd_proc.py

@@ -33,11 +33,14 @@ def _device(device=None):
 
 
 def gpu_stats(rows, group_offsets, mean_vec=None, normalize_length=False, device=None):
-    """rows (N, D) float32 grouped by class, group_offsets int32[C+1] -> (class_mean (C, D),
-    offset_scatter (D, D)) numpy float64, computed by ws_plda_stats."""
+    """rows (N, D) float32 or float64 (kept as is: the reference's chain stays in float64) grouped by
+    class, group_offsets int32[C+1] -> (class_mean (C, D), offset_scatter (D, D)) numpy float64,
+    computed by ws_plda_stats."""
     dev = _device(device)
     L = _lib.lib()
-    x = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(dev)
+    rows = np.asarray(rows)
+    is64 = rows.dtype == np.float64
+    x = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64 if is64 else np.float32)).to(dev)
     n, dim = int(x.shape[0]), int(x.shape[1])
     offs = torch.from_numpy(np.ascontiguousarray(group_offsets, dtype=np.int32)).to(dev)
     n_groups = int(offs.numel()) - 1
@@ -49,7 +52,7 @@ def gpu_stats(rows, group_offsets, mean_vec=None, normalize_length=False, device
     need = int(L.ws_plda_stats_scratch(n, dim))
     scratch = torch.empty((need,), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.ws_plda_stats(_lib.ptr(x), n, dim, _lib.ptr(offs), n_groups,
+        _lib.check(L.ws_plda_stats(_lib.ptr(x), int(is64), n, dim, _lib.ptr(offs), n_groups,
                                    _lib.ptr(mv) if mv is not None else None, int(bool(normalize_length)),
                                    _lib.ptr(cm), _lib.ptr(sc), _lib.ptr(scratch), need,
                                    _lib.current_stream_ptr(dev)), "ws_plda_stats")
