@@ -8,10 +8,13 @@ Follows runtime/core/speaker/speaker_engine.cc in /root/reference:
                                       cyclic tiling of an utterance shorter than one chunk)
   :140-159  ExtractEmbedding         (sum of chunk embeddings / chunk count)
 
-PARITY UNPINNED for the cutting rule: the reference has no golden vectors for it and
-SpeakerEngine cannot be compiled here (its constructor needs ONNXRuntime / MNN), so this file is a
-restatement checked by reading only.  The fbank and the model forward underneath ARE pinned
-(oracle/fbank.py, oracle/ecapa.py).
+Pinned: the reference's own speaker_engine.cc + feature_pipeline.cc + fbank.h are compiled in place
+into oracle/_ref/libref_engine.so (oracle/Makefile, oracle/ref_engine_wrap.cc; only the ONNX/MNN
+model back-end is replaced, through the reference's own SpeakerModel interface, by the pinned
+oracle/ecapa.py forward) and run by oracle/make_golden.py -> tests/golden/chunked_ref.npz: chunk
+counts, averaged embeddings and the padded chunk tensors of six cases (head-frame completion,
+cyclic tiling, exact multiple, full mode, short chunks, one-frame tail).
+tests/test_oracle_golden.py holds this restatement to them.
 """
 import numpy as np
 

@@ -23,6 +23,11 @@ What is recorded (all seeds live in fixtures/synth.py, inputs are regenerated fr
                        fixture and applied to 24 probe embeddings.
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
+  * kaldi_plda_*.bin / .txt + kaldi_plda_ref.npz -- Kaldi <Plda> files and what the reference's own
+                       read_plda returns for them.
+  * chunked_ref.npz -- the reference's own native SpeakerEngine (speaker_engine.cc, built into
+                       oracle/_ref/libref_engine.so) on synthetic utterances: chunk counts, averaged
+                       embeddings, the padded chunk tensors.
 The GPU box has no /root/reference; tests there compare against these committed files.
 """
 import ctypes
@@ -238,9 +243,68 @@ def make_kaldi_plda():
           np.abs(out["f32/transform"] - out["f64/transform"]).max())
 
 
+CHUNK_CASES = [  # (utt seed, num_samples, samples_per_chunk)
+    (200, 48000, 32000),     # 298 frames: one full 198-frame chunk + 100 frames completed with head frames
+    (201, 20000, 32000),     # 123 frames < one chunk: cyclic tiling
+    (202, 63600, 32000),     # 396 frames: exactly two chunks, no partial one
+    (203, 40000, 0),         # full mode
+    (204, 70000, 16000),     # 98-frame chunks: 4 full + a partial one
+    (205, 32160, 32000),     # 199 frames: one full chunk + ONE frame
+]
+
+
+def ref_engine_extract(pcm, samples_per_chunk, forward, emb_dim, capture=None):
+    """The reference's SpeakerEngine::ExtractEmbedding (oracle/_ref/libref_engine.so) with `forward`
+    ((1, T, 80) float32 -> (1, E)) standing in for the ONNX model.  capture: list that receives the
+    (T, 80) chunk tensors exactly as the engine hands them to the model (after its ApplyMean)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_engine.so"))
+    CB = ctypes.CFUNCTYPE(None, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int,
+                          ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_void_p)
+    calls = []
+
+    def cb(feats, T, D, emb, E, _user):
+        f = np.ctypeslib.as_array(feats, shape=(T, D)).copy()
+        calls.append(f)
+        out = np.asarray(forward(f[None]), dtype=np.float32).reshape(-1)
+        ctypes.memmove(emb, out.ctypes.data, 4 * E)
+
+    lib.ref_engine_extract.restype = ctypes.c_int
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    avg = np.zeros(emb_dim, np.float32)
+    n = lib.ref_engine_extract(pcm.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(pcm.shape[0]), 80, 16000,
+                               emb_dim, ctypes.c_int(samples_per_chunk), CB(cb), None,
+                               avg.ctypes.data_as(ctypes.c_void_p))
+    # ExtractFeature ran once for the count and once inside ExtractEmbedding: the model saw n chunks
+    assert len(calls) == n, (len(calls), n)
+    if capture is not None:
+        capture.extend(calls)
+    return avg, n
+
+
+def make_chunked():
+    """chunked_ref.npz -- the reference's own native SpeakerEngine (runtime/core/speaker/
+    speaker_engine.cc:63-159 + frontend/feature_pipeline.cc + fbank.h, compiled into
+    oracle/_ref/libref_engine.so) run on synthetic utterances, with the pinned ECAPA oracle as the
+    model behind its SpeakerModel interface: chunk count, averaged embedding, and for the two
+    padding cases the chunk tensors the engine hands to the model."""
+    from oracle import ecapa as oecapa
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in
+          synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42).items()}
+    forward = lambda f: oecapa.ecapa_forward(sd, f).numpy()      # noqa: E731
+    out = {"cases": np.array(CHUNK_CASES)}
+    for i, (seed, n, spc) in enumerate(CHUNK_CASES):
+        cap = []
+        emb, n_chunks = ref_engine_extract(synth.synth_wav(seed, n), spc, forward, 192, cap)
+        out["%d/emb" % i] = emb
+        out["%d/n_chunks" % i] = np.array(n_chunks)
+        out["%d/last_chunk" % i] = cap[-1]            # the padded / completed chunk (or the only one)
+        print("chunked case", (seed, n, spc), "->", n_chunks, "chunks of", cap[0].shape[0], "frames")
+    np.savez_compressed(os.path.join(GOLD, "chunked_ref.npz"), **out)
+
+
 SECTIONS = {"fbank": make_fbank, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
             "plda": make_plda, "score": make_score, "plda_train": make_plda_train,
-            "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda}
+            "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda, "chunked": make_chunked}
 
 if __name__ == "__main__":
     assert ref_shim.available(), "needs /root/reference"

@@ -736,6 +736,24 @@ def test_extract_chunked_matches_oracle(frontend, seconds, samples_per_chunk):
     assert _rel_err(emb.cpu().numpy(), ref) <= 2e-3
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "f16"])
+def test_extract_chunked_matches_reference_engine_golden(frontend, golden_dir, prec):
+    """ws_extract_chunked against the reference's OWN SpeakerEngine::ExtractEmbedding
+    (speaker_engine.cc:83-159 compiled into oracle/_ref, model = the pinned ECAPA oracle;
+    tests/golden/chunked_ref.npz): chunk counts equal, embeddings inside the north_star bar on every
+    back-end (the reference engine sits on its native float-FFT fbank: 1.7e-4 log-mel noise)."""
+    g = np.load(os.path.join(golden_dir, "chunked_ref.npz"))
+    sd, model = _engine("ECAPA_TDNN_GLOB_c512")
+    model.set_precision(prec)
+    for i, (seed, n, spc) in enumerate(g["cases"]):
+        wav = synth.synth_wav(int(seed), int(n))
+        emb, n_chunks = model.extract_chunked(frontend, torch.from_numpy(wav), int(spc))
+        assert n_chunks == int(g["%d/n_chunks" % i])
+        e, ref = emb.cpu().numpy(), g["%d/emb" % i]
+        assert _cos_err(e[None], ref[None]) <= COS_TOL, (i, prec)
+        assert _rel_err(e, ref) <= (2e-3 if prec != "f16" else 3e-3), (i, prec, _rel_err(e, ref))
+
+
 def test_extract_chunked_errors(frontend):
     from wespeaker_amd._lib import NativeError
     _, model = _engine("ECAPA_TDNN_GLOB_c512")

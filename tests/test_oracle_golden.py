@@ -250,3 +250,46 @@ def test_embedding_processing_restatement_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(lda_m, g["lda_m"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(np.abs(lda).sum(0), g["lda_abs_colsum"], rtol=1e-5)
     assert np.abs(_align_signs(out, g["out"]) - g["out"]).max() <= 1e-5
+
+
+def test_chunk_rule_vs_reference_engine_golden(golden_dir):
+    """oracle/chunked.py against the reference's OWN SpeakerEngine (speaker_engine.cc:63-159 compiled
+    into oracle/_ref/libref_engine.so, run by oracle/make_golden.py chunked): chunk counts equal, the
+    padded chunk tensor within the native-fbank noise (the engine sits on the reference's float FFT),
+    averaged embeddings inside the north_star bar."""
+    from oracle import chunked
+    g = np.load(os.path.join(golden_dir, "chunked_ref.npz"))
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    for i, (seed, n, spc) in enumerate(g["cases"]):
+        feats = ofbank.speaker_features(synth.synth_wav(int(seed), int(n)), cmn=False)
+        seen = []
+
+        def forward(batch):
+            seen.append(batch)
+            return oecapa.ecapa_forward(sd, batch).numpy()
+
+        emb, n_chunks = chunked.extract_chunked(feats, 16000, int(spc), forward)
+        assert n_chunks == int(g["%d/n_chunks" % i])
+        last = seen[0][-1]
+        assert last.shape == g["%d/last_chunk" % i].shape
+        assert np.abs(last - g["%d/last_chunk" % i]).max() < 1e-3
+        ref = g["%d/emb" % i]
+        cos = 1.0 - float(np.dot(emb, ref) / (np.linalg.norm(emb) * np.linalg.norm(ref)))
+        assert cos < 1e-5 and np.linalg.norm(emb - ref) / np.linalg.norm(ref) < 2e-3, (i, cos)
+
+
+def test_reference_engine_library_runs_live(golden_dir):
+    """When oracle/_ref/libref_engine.so is present (it travels to the GPU box), the reference engine
+    itself re-produces the committed golden bit for bit with a cheap stand-in model."""
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                      "libref_engine.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_engine.so not built")
+    from oracle.make_golden import ref_engine_extract
+    g = np.load(os.path.join(golden_dir, "chunked_ref.npz"))
+    seed, n, spc = (int(v) for v in g["cases"][0])
+    cap = []
+    emb, n_chunks = ref_engine_extract(synth.synth_wav(seed, n), spc,
+                                       lambda f: f.mean(1)[:, :8], 8, cap)      # stand-in: 8 bin means
+    assert n_chunks == int(g["0/n_chunks"]) and np.array_equal(cap[-1], g["0/last_chunk"])
+    assert np.allclose(emb, np.mean([c.mean(0)[:8] for c in cap], axis=0), atol=1e-6)
