@@ -92,6 +92,11 @@ WS_API int ws_engine_set_tensor(ws_engine* eng, const char* key, const float* da
  * folds/re-lays-out the weights, uploads them and allocates workspace for max_batch utterances
  * of max_frames frames per forward chunk (larger batches are processed in chunks). */
 WS_API int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames);
+/* create + set_tensor x N + finalize from one flat weight file (wespeaker_amd.engine.save_native_model;
+ * layout in csrc/c_api.hip): what OnnxSpeakerModel(model_path) is to the reference's native runtime
+ * (runtime/core/speaker/onnx_speaker_model.cc:40-75, speaker_engine.cc:28-60) -- a caller without
+ * Python hands over a path and gets a ready engine. */
+WS_API int ws_engine_load(const char* path, int device_id, int max_batch, int max_frames, ws_engine** out);
 /* Re-sizes the workspace of a finalized engine (weights stay): the reference accepts utterances of any
  * length (cli/speaker.py:125-167 has no cap), so callers grow the engine when a longer one arrives.
  * Synchronises the device (earlier launches may still use the old workspace). */

@@ -47,6 +47,30 @@ def test_invalid_arguments_return_codes_not_aborts(built_lib):
     assert built_lib.ws_engine_embed_dim(None) == -1
 
 
+def test_engine_load_rejects_bad_files(built_lib, tmp_path):
+    h = ctypes.c_void_p()
+    assert built_lib.ws_engine_load(str(tmp_path / "absent").encode(), 0, 8, 200, ctypes.byref(h)) == -1
+    assert b"cannot open" in built_lib.ws_last_error()
+    (tmp_path / "junk").write_bytes(b"definitely not a weight file")
+    assert built_lib.ws_engine_load(str(tmp_path / "junk").encode(), 0, 8, 200, ctypes.byref(h)) == -1
+    assert b"bad magic" in built_lib.ws_last_error()
+    (tmp_path / "short").write_bytes(b"WSAMDW01\x05\x00\x00\x00ECA")
+    assert built_lib.ws_engine_load(str(tmp_path / "short").encode(), 0, 8, 200, ctypes.byref(h)) == -1
+    assert b"truncated" in built_lib.ws_last_error()
+
+
+def test_cpp_caller_is_built_against_the_c_abi_only(built_lib):
+    """extract_emb_main links libwespeaker_amd.so + the HIP runtime, nothing of Python / torch."""
+    import subprocess
+    from wespeaker_amd import build
+    if not os.path.exists(build.MAIN_BIN):
+        build.build(verbose=False)
+    needed = subprocess.run(["readelf", "-d", build.MAIN_BIN], stdout=subprocess.PIPE, text=True).stdout
+    libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
+    assert any("libwespeaker_amd" in l for l in libs)
+    assert not any("torch" in l or "python" in l for l in libs), libs
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

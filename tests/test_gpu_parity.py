@@ -754,6 +754,46 @@ def test_extract_chunked_matches_reference_engine_golden(frontend, golden_dir, p
         assert _rel_err(e, ref) <= (2e-3 if prec != "f16" else 3e-3), (i, prec, _rel_err(e, ref))
 
 
+def test_cpp_caller_of_the_c_abi(frontend, golden_dir, tmp_path):
+    """wespeaker_amd/lib/extract_emb_main (plain g++ C++, no Python, no torch; twin of the reference's
+    runtime/core/bin/extract_emb_main.cc:43-117) loads a flat weight file through ws_engine_load and
+    prints `key e0 e1 ...` per wav.scp line: same numbers as the ctypes path, and inside the bar of the
+    reference engine's golden."""
+    import subprocess
+    from wespeaker_amd import build as wbuild
+    from wespeaker_amd.engine import NativeSpeakerModel, save_native_model
+    assert os.path.exists(wbuild.MAIN_BIN), "build with python -m wespeaker_amd.build"
+    g = np.load(os.path.join(golden_dir, "chunked_ref.npz"))
+    sd, model = _engine("ECAPA_TDNN_GLOB_c512")
+    mpath = str(tmp_path / "model.wsamd")
+    save_native_model(mpath, "ECAPA_TDNN_GLOB_c512", sd, 80, 192)
+    loaded = NativeSpeakerModel.from_file(mpath, max_batch=8, max_frames=400)     # ws_engine_load via ctypes
+    assert loaded.model_name == "ECAPA_TDNN_GLOB_c512" and loaded.embed_dim == 192
+    cases = [(i, int(s), int(n)) for i, (s, n, spc) in enumerate(g["cases"]) if int(spc) == 32000]
+    lines = []
+    for i, seed, n in cases:
+        p = str(tmp_path / ("c%d.wav" % i))
+        synth.write_wav(p, synth.synth_wav(seed, n))
+        lines.append("case%d %s" % (i, p))
+    (tmp_path / "wav.scp").write_text("\n".join(lines) + "\n")
+    res = subprocess.run([wbuild.MAIN_BIN, "--wav_scp", str(tmp_path / "wav.scp"), "--speaker_model_path", mpath,
+                          "--samples_per_chunk", "32000", "--result", str(tmp_path / "emb.txt")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "RTF" in res.stderr
+    rows = [l.split() for l in open(tmp_path / "emb.txt")]
+    assert [r[0] for r in rows] == ["case%d" % i for i, _, _ in cases]
+    for r, (i, seed, n) in zip(rows, cases):
+        e = np.array([float(x) for x in r[1:]], dtype=np.float32)
+        assert e.shape == (192,)
+        via_ctypes, _ = loaded.extract_chunked(frontend, torch.from_numpy(synth.synth_wav(seed, n)), 32000)
+        assert np.array_equal(e, via_ctypes.cpu().numpy())          # %.9g round-trips float32
+        assert _cos_err(e[None], g["%d/emb" % i][None]) <= COS_TOL
+    bad = subprocess.run([wbuild.MAIN_BIN, "--wav_path", str(tmp_path / "c0.wav"), "--speaker_model_path",
+                          str(tmp_path / "wav.scp")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert bad.returncode == 1 and "bad magic" in bad.stderr
+
+
 def test_extract_chunked_errors(frontend):
     from wespeaker_amd._lib import NativeError
     _, model = _engine("ECAPA_TDNN_GLOB_c512")

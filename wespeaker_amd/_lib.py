@@ -24,6 +24,7 @@ SIGNATURES = {
     "ws_engine_create": (c_int, [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "ws_engine_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int, POINTER(c_int64)]),
     "ws_engine_finalize": (c_int, [c_void_p, c_int, c_int]),
+    "ws_engine_load": (c_int, [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "ws_engine_reserve": (c_int, [c_void_p, c_int, c_int]),
     "ws_engine_max_batch": (c_int, [c_void_p]),
     "ws_engine_max_frames": (c_int, [c_void_p]),

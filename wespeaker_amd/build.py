@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libwespeaker_amd.so")
+MAIN_BIN = os.path.join(LIBDIR, "extract_emb_main")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
@@ -77,6 +78,19 @@ def build(force=False, verbose=True):
         rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError("link failed:\n" + out)
+    # the C++ caller of the C-ABI (native twin of runtime/core/bin/extract_emb_main.cc)
+    main_src = os.path.join(CSRC, "bin", "extract_emb_main.cc")
+    if (need_link or not os.path.exists(MAIN_BIN)
+            or os.path.getmtime(MAIN_BIN) < max(os.path.getmtime(main_src), hdr_time)):
+        # a plain host compiler on purpose: the boundary is C, the caller needs no hipcc
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+               "-I" + os.path.join(rocm, "include"), main_src, "-L" + LIBDIR, "-lwespeaker_amd",
+               "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+               "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", MAIN_BIN]
+        rc, out = run(cmd)
+        if rc != 0:
+            raise RuntimeError("extract_emb_main build failed:\n" + out)
     return LIB
 
 

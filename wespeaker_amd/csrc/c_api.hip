@@ -213,6 +213,63 @@ int ws_engine_finalize(ws_engine* eng, int max_batch, int max_frames) {
   return WS_OK;
 }
 
+// Flat weight file written by wespeaker_amd.engine.save_native_model (little endian):
+//   "WSAMDW01" | i32 name_len | name | i32 feat_dim | i32 embed_dim | i32 n_tensors |
+//   n_tensors x ( i32 key_len | key | i32 ndim | i64 shape[ndim] | f32 data[prod(shape)] )
+int ws_engine_load(const char* path, int device_id, int max_batch, int max_frames, ws_engine** out) {
+  if (!path || !out || max_batch <= 0 || max_frames <= 0) {
+    set_error("ws_engine_load: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { set_error("ws_engine_load: cannot open '%s'", path); return WS_ERR_INVALID_ARG; }
+  ws_engine* eng = nullptr;
+  int rc = WS_OK;
+  auto fail = [&](int code, const char* what) {
+    set_error("ws_engine_load: %s in '%s'", what, path);
+    rc = code;
+  };
+  auto rd = [&](void* dst, size_t n) { return std::fread(dst, 1, n, f) == n; };
+  auto rd_str = [&](std::string* s) {
+    int32_t n = 0;
+    if (!rd(&n, 4) || n < 0 || n > 4096) return false;
+    s->resize(n);
+    return n == 0 || rd(&(*s)[0], n);
+  };
+  char magic[8];
+  std::string name;
+  int32_t feat_dim = 0, embed_dim = 0, n_tensors = 0;
+  if (!rd(magic, 8) || std::memcmp(magic, "WSAMDW01", 8) != 0) fail(WS_ERR_INVALID_ARG, "bad magic");
+  else if (!rd_str(&name) || !rd(&feat_dim, 4) || !rd(&embed_dim, 4) || !rd(&n_tensors, 4) || n_tensors < 0)
+    fail(WS_ERR_INVALID_ARG, "truncated header");
+  if (rc == WS_OK) rc = ws_engine_create(name.c_str(), feat_dim, embed_dim, device_id, &eng);
+  std::vector<float> data;
+  for (int t = 0; rc == WS_OK && t < n_tensors; ++t) {
+    std::string key;
+    int32_t ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    if (!rd_str(&key) || !rd(&ndim, 4) || ndim < 0 || ndim > 4 || !rd(shape, 8 * (size_t)ndim)) {
+      fail(WS_ERR_INVALID_ARG, "truncated tensor header");
+      break;
+    }
+    int64_t numel = 1;
+    for (int d = 0; d < ndim; ++d) numel *= shape[d];
+    if (numel < 0 || numel > (int64_t)1 << 31) { fail(WS_ERR_SHAPE, "implausible tensor size"); break; }
+    data.resize((size_t)numel);
+    if (numel && !rd(data.data(), 4 * (size_t)numel)) { fail(WS_ERR_INVALID_ARG, "truncated tensor data"); break; }
+    const int r = ws_engine_set_tensor(eng, key.c_str(), data.data(), ndim, shape);
+    if (r < 0) rc = r;
+  }
+  std::fclose(f);
+  if (rc == WS_OK) rc = ws_engine_finalize(eng, max_batch, max_frames);
+  if (rc != WS_OK) {
+    ws_engine_destroy(eng);
+    return rc;
+  }
+  *out = eng;
+  return WS_OK;
+}
+
 int ws_engine_reserve(ws_engine* eng, int max_batch, int max_frames) {
   if (!eng || max_batch <= 0 || max_frames <= 0) {
     set_error("ws_engine_reserve: invalid argument");

@@ -80,8 +80,53 @@ class Frontend:
         return feats
 
 
+def save_native_model(path, model_name, state_dict, feat_dim=80, embed_dim=None):
+    """Write the flat weight file ws_engine_load reads (the native runtime's counterpart of an
+    exported .onnx: callers without Python -- wespeaker_amd/csrc/bin/extract_emb_main.cc -- load it).
+    Only floating-point tensors are written, under the reference's state_dict names."""
+    import struct
+    embed_dim = int(embed_dim or DEFAULT_EMBED_DIM.get(model_name[:5], 256))
+    items = []
+    for key, val in state_dict.items():
+        arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+        if arr.dtype.kind == "f" and arr.ndim <= 4:
+            items.append((key, np.ascontiguousarray(arr, dtype="<f4")))
+    with open(path, "wb") as f:
+        name = model_name.encode()
+        f.write(b"WSAMDW01" + struct.pack("<i", len(name)) + name)
+        f.write(struct.pack("<iii", int(feat_dim), embed_dim, len(items)))
+        for key, arr in items:
+            k = key.encode()
+            f.write(struct.pack("<i", len(k)) + k + struct.pack("<i", arr.ndim))
+            f.write(struct.pack("<%dq" % arr.ndim, *arr.shape))
+            f.write(arr.tobytes())
+    return path
+
+
 class NativeSpeakerModel:
     """The engine behind `Speaker.model`."""
+
+    @classmethod
+    def from_file(cls, path, device=None, max_batch=64, max_frames=400):
+        """Engine from a flat weight file (save_native_model) through ws_engine_load."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device) if device is not None else default_device()
+        h = c_void_p()
+        _lib.check(_lib.lib().ws_engine_load(str(path).encode(), self.device.index or 0, int(max_batch),
+                                             int(max_frames), ctypes.byref(h)), "ws_engine_load")
+        self._h = h
+        with open(path, "rb") as f:
+            f.seek(8)
+            n = int.from_bytes(f.read(4), "little")
+            self.model_name = f.read(n).decode()
+        self.feat_dim = _lib.lib().ws_engine_feat_dim(h)
+        self.embed_dim = _lib.lib().ws_engine_embed_dim(h)
+        self.frontend_type = "fbank"
+        self.max_batch, self.max_frames = int(max_batch), int(max_frames)
+        self._rows_budget = self.max_batch * self.max_frames
+        self.ignored_keys = []
+        self.precision = "fp32"
+        return self
 
     def __init__(self, model_name: str, state_dict, feat_dim=80, embed_dim=None, device=None,
                  max_batch=64, max_frames=400, **unused_model_args):
