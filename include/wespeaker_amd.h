@@ -42,6 +42,7 @@ extern "C" {
 #define WS_ERR_HIP (-5)
 #define WS_ERR_STATE (-6)
 #define WS_ERR_CAPACITY (-7)
+#define WS_ERR_RANGE (-8) /* binary16 back-end: an activation left the binary16 range */
 
 #define WS_WINDOW_HAMMING 0 /* Speaker default, cli/speaker.py:50 */
 #define WS_WINDOW_POVEY 1   /* Speaker.set_window_type('povey'), cli/speaker.py:66-67 */
@@ -146,13 +147,20 @@ WS_API int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, 
  *   WS_PREC_F16     operands rounded to binary16, ONE MFMA pass, fp32 accumulation -- the arithmetic
  *                   of the reference's own GPU deployment (TensorRT fp16, runtime/server/x86_gpu):
  *                   ~5e-4 relative on the embedding, 1 - cos ~ 4e-7 against the fp32 reference
- *                   (the 1e-4 bar holds with > 100x margin); inputs must stay inside the binary16
- *                   range (65504), which int16-scale fbank + CMN features do.
+ *                   (the 1e-4 bar holds with > 100x margin); inputs and activations must stay inside
+ *                   the binary16 range (65504), which int16-scale fbank + CMN features and BN-normalised
+ *                   activations do -- ws_engine_check_range reports a checkpoint that does not.
  * May be switched at any time between forwards. */
 #define WS_PREC_FP32 0
 #define WS_PREC_F16X3 1
 #define WS_PREC_F16 2
 WS_API int ws_engine_set_precision(ws_engine* eng, int mode);
+/* Range guard of WS_PREC_F16 / WS_PREC_F16X3: a checkpoint whose activations pass 65504 turns them into
+ * inf, which reaches the embedding as inf / NaN.  Every forward in those modes ends with a tiny kernel
+ * that counts non-finite embedding values into a host-visible counter; this call synchronises `stream`,
+ * returns WS_ERR_RANGE (message in ws_last_error) if any were produced since the last call, else WS_OK,
+ * and clears the counter.  (The reference's fp32 path has no such limit: switch to WS_PREC_FP32.) */
+WS_API int ws_engine_check_range(ws_engine* eng, ws_stream stream);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 
@@ -160,8 +168,9 @@ WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
  * wall-clock Timer of runtime/core/utils/timer.h:22-36).  While enabled, every kernel launch of
  * ws_forward/ws_extract is bracketed by HIP events on the launch stream.  ws_engine_profile_read
  * synchronises them and fills 4-element arrays indexed by kernel class
- * (0 = fp32-MFMA conv-GEMM 128x128 tile, 1 = 128x64 tile, 2 = reductions/element-wise,
- * 3 = split-K GEMM): summed milliseconds, algorithmic FLOPs, algorithmic bytes, launch counts.
+ * (0 = conv/linear GEMM launches with N > 64 -- whichever tile / back-end kernel the dispatcher picks:
+ * the dominant class, 1 = narrow GEMMs (N <= 64) and the fused Res2 chain, 2 = reductions / element-wise
+ * / frontend, 3 = split-K GEMMs): summed milliseconds, algorithmic FLOPs, algorithmic bytes, launch counts.
  * `on` is a bit mask of the classes to record (0 = off, 0xF = all, 1 = only the dominant GEMM):
  * timing events between kernels cost a few per cent of throughput, so the headline run records
  * only the dominant kernel.  Returns the number of classes. */

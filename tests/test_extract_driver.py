@@ -1,0 +1,184 @@
+"""CPU: the batch-extraction driver (wespeaker_amd/extract.py = tools/extract_embedding.sh +
+wespeaker/bin/extract.py) with a host stand-in for the GPU call: list formats, the `split -l` rule,
+length bucketing with list-order output, the random-crop cohort mode, per-job ark/scp + merged scp +
+extract.result, and the 2-rank gloo run against the single-rank run, bit for bit."""
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fixtures import synth
+from wespeaker_amd import extract as wx
+from wespeaker_amd import kaldi_io, parallel
+
+
+def _fake_rows(batch):
+    """Row-wise deterministic 'embedding' (independent of the batch a row travels in)."""
+    x = batch.to(torch.float64)
+    return torch.stack([x.mean(1), x.std(1), x[:, 0], x[:, -1],
+                        torch.full((x.shape[0],), float(x.shape[1]), dtype=torch.float64),
+                        x.abs().sum(1) % 977.0], 1).to(torch.float32).numpy()
+
+
+def _make_corpus(d, n=23):
+    lengths = [16000 + 1600 * (i % 4) for i in range(n)]          # 4 distinct lengths, interleaved
+    lines_raw, lines_scp = [], []
+    for i, L in enumerate(lengths):
+        p = os.path.join(d, "u%02d.wav" % i)
+        synth.write_wav(p, synth.synth_wav(300 + i, L))
+        lines_raw.append(json.dumps({"key": "utt%02d" % i, "wav": p, "spk": "s%d" % (i % 3)}))
+        lines_scp.append("utt%02d %s" % (i, p))
+    return lengths, lines_raw, lines_scp
+
+
+def test_split_rule_is_the_scripts_split_minus_l():
+    # tools/extract_embedding.sh:40-42: subfile_num = data_num / nj + 1 (integer division), split -l
+    assert wx.split_rule(100, 4) == [(0, 26), (26, 52), (52, 78), (78, 100)]
+    assert wx.split_rule(8, 4) == [(0, 3), (3, 6), (6, 8), (8, 8)]       # last job gets no file
+    for n, nj in [(4874, 8), (7, 8), (1, 1), (0, 2), (1000, 16)]:
+        spans = wx.split_rule(n, nj)
+        assert [i for lo, hi in spans for i in range(lo, hi)] == list(range(n))
+    assert wx.chunk_samples(200, 16000) == 32240                          # dataset.py:237-241
+
+
+def test_whole_utterance_mode_buckets_by_length_and_keeps_list_order(tmp_path):
+    lengths, lines_raw, lines_scp = _make_corpus(str(tmp_path))
+    seen = []
+
+    def fn(batch):
+        seen.append(tuple(batch.shape))
+        return _fake_rows(batch)
+
+    ex = wx.HostExtractor(fn, 6)
+    keys, emb = wx.extract_entries(wx.iter_entries("raw", lines_raw), ex, batch_size=1, max_batch=4, num_workers=3)
+    assert keys == ["utt%02d" % i for i in range(23)]
+    ref = np.concatenate([_fake_rows(torch.from_numpy(synth.synth_wav(300 + i, L))[None]) for i, L in enumerate(lengths)])
+    assert np.array_equal(emb, ref)
+    assert all(b <= 4 for b, _ in seen) and max(b for b, _ in seen) == 4           # real batches
+    assert {n for _, n in seen} == set(lengths)                                     # never mixed lengths
+    keys2, emb2 = wx.extract_entries(wx.iter_entries("scp", lines_scp), ex, batch_size=1, max_batch=64)
+    assert keys2 == keys and np.array_equal(emb2, emb)
+    # bounded host buffering: a tiny budget forces early flushes, same result
+    keys3, emb3 = wx.extract_entries(wx.iter_entries("raw", lines_raw), ex, max_batch=64, max_buffered_samples=40000)
+    assert keys3 == keys and np.array_equal(emb3, emb)
+    assert wx.extract_entries(iter(()), ex)[1].shape == (0, 6)
+
+
+def test_shard_lists_and_pipe_commands(tmp_path):
+    lengths, lines_raw, _ = _make_corpus(str(tmp_path), n=6)
+    shard = str(tmp_path / "shards_000.tar")
+    with tarfile.open(shard, "w") as tar:
+        for i in range(6):
+            for suffix, data in (("wav", open(str(tmp_path / ("u%02d.wav" % i)), "rb").read()),
+                                 ("spk", ("s%d" % i).encode())):
+                info = tarfile.TarInfo("utt%02d.%s" % (i, suffix))
+                info.size = len(data)
+                tar.addfile(info, io.BytesIO(data))
+    ex = wx.HostExtractor(_fake_rows, 6)
+    keys_s, emb_s = wx.extract_entries(wx.iter_entries("shard", [shard]), ex, max_batch=8)
+    keys_r, emb_r = wx.extract_entries(wx.iter_entries("raw", lines_raw), ex, max_batch=8)
+    assert keys_s == keys_r and np.array_equal(emb_s, emb_r)
+    piped = [json.dumps({"key": "p0", "wav": "cat %s |" % (tmp_path / "u00.wav"), "spk": "x"})]
+    _, emb_p = wx.extract_entries(wx.iter_entries("raw", piped), ex)
+    assert np.array_equal(emb_p[0], emb_r[0])
+    with pytest.raises(NotImplementedError):
+        list(wx.iter_entries("feat", ["x"]))
+
+
+def test_random_chunk_cohort_mode(tmp_path):
+    """bin/extract.py:95 + dataset.py:235-242: batch_size > 1 -> every utterance becomes ONE random crop of
+    ((num_frms-1)*10+25) ms, tiled first when shorter (processor.get_random_chunk)."""
+    paths = []
+    for i, L in enumerate([48000, 20000, 32240, 9000]):
+        p = str(tmp_path / ("c%d.wav" % i))
+        synth.write_wav(p, synth.synth_wav(400 + i, L))
+        paths.append("c%d %s" % (i, p))
+    got = []
+    ex = wx.HostExtractor(lambda b: (got.append(b.clone()), _fake_rows(b))[1], 6)
+    keys, emb = wx.extract_entries(wx.iter_entries("scp", paths), ex, batch_size=16, chunk_len=32240, seed=5)
+    assert len(got) == 1 and got[0].shape == (4, 32240)                   # one equal-length batch
+    w0 = torch.from_numpy(synth.synth_wav(400, 48000))
+    s0 = wx.crop_start("c0", 48000, 32240, 5)
+    assert 0 <= s0 <= 48000 - 32240 and torch.equal(got[0][0], w0[s0:s0 + 32240])
+    w1 = torch.from_numpy(synth.synth_wav(401, 20000))
+    assert torch.equal(got[0][1], torch.cat([w1, w1])[:32240])           # tiled, then cut
+    assert torch.equal(got[0][2], torch.from_numpy(synth.synth_wav(402, 32240)))   # exact length: start 0
+    w3 = torch.from_numpy(synth.synth_wav(403, 9000))
+    assert torch.equal(got[0][3], w3.repeat(4)[:32240])
+    keys_b, emb_b = wx.extract_entries(wx.iter_entries("scp", paths), ex, batch_size=16, chunk_len=32240, seed=5)
+    assert np.array_equal(emb, emb_b)                                     # seeded: runs repeat
+    _, emb_c = wx.extract_entries(wx.iter_entries("scp", paths), ex, batch_size=16, chunk_len=32240, seed=6)
+    assert not np.array_equal(emb[0], emb_c[0])
+
+
+def test_frontend_config_is_checked_loudly():
+    ok = {"model": "ECAPA_TDNN_GLOB_c512", "dataset_args": {"resample_rate": 16000, "fbank_args":
+          {"num_mel_bins": 80, "frame_shift": 10, "frame_length": 25, "dither": 1.0}}}
+    assert wx.check_frontend_config(ok) == {"resample_rate": 16000, "num_mel_bins": 80, "num_frms": 200}
+    for bad in ({"frontend": "s3prl"}, {"fbank_args": {"frame_shift": 20}}, {"cmvn": False},
+                {"cmvn_args": {"norm_var": True}}):
+        with pytest.raises(NotImplementedError):
+            wx.check_frontend_config({"dataset_args": bad})
+
+
+def _job_worker(rank, world, port, embed_dir, lines, q):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                          WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        parallel.init_distributed(backend="gloo")
+    out = wx.run_jobs(lines, "raw", embed_dir, lambda: wx.HostExtractor(_fake_rows, 6), nj=4, rank=rank,
+                      world=world, max_batch=4, gather=True, wavs_num=len(lines), store_dir="vox1")
+    q.put((rank, out[0], out[1]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_run_writes_the_same_files_as_one_rank(tmp_path):
+    """extract_embedding.sh semantics on 2 ranks (gloo): per-job ark/scp, merged xvector.scp in job order,
+    extract.result -- identical bytes to the single-rank run; gather=True hands every rank all rows."""
+    _, lines_raw, _ = _make_corpus(str(tmp_path), n=23)
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world, tag in ((1, "one"), (2, "two")):
+        d = str(tmp_path / tag)
+        q = ctx.Queue()
+        port = 29950 + os.getpid() % 40
+        procs = [ctx.Process(target=_job_worker, args=(r, world, port, d, lines_raw, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[tag] = res
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    for j in range(4):
+        a = open(os.path.join(one, "xvector_%03d.ark" % j), "rb").read()
+        b = open(os.path.join(two, "xvector_%03d.ark" % j), "rb").read()
+        assert a == b and len(a) > 0
+        assert open(os.path.join(one, "log", "split_%03d" % j)).read() == open(os.path.join(two, "log", "split_%03d" % j)).read()
+    all_ark = b"".join(open(os.path.join(two, "xvector_%03d.ark" % j), "rb").read() for j in range(4))
+    single = kaldi_io.read_vec_scp(os.path.join(one, "xvector.scp"))
+    merged = kaldi_io.read_vec_scp(os.path.join(two, "xvector.scp"))
+    assert list(merged) == list(single) == ["utt%02d" % i for i in range(23)]
+    assert all(np.array_equal(merged[k], single[k]) for k in single)
+    assert len(all_ark) == sum(os.path.getsize(os.path.join(one, "xvector_%03d.ark" % j)) for j in range(4))
+    assert open(os.path.join(two, "extract.result")).read() == "Successfully extract embedding for vox1\n"
+    keys1, emb1 = results["one"][0][1], results["one"][0][2]
+    for rank, keys, emb in results["two"]:
+        assert keys == keys1 and np.array_equal(emb, emb1), rank
+    assert np.array_equal(emb1, np.stack(list(single.values())))
+
+
+def test_count_mismatch_is_reported_like_the_script(tmp_path):
+    _, lines_raw, _ = _make_corpus(str(tmp_path), n=5)
+    msg = wx.run_jobs(lines_raw, "raw", str(tmp_path / "o"), lambda: wx.HostExtractor(_fake_rows, 6), nj=2,
+                      wavs_num=6, store_dir="vox1")
+    assert msg == "Failed to extract embedding for vox1"

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ws_extract_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_void_p]),
     "ws_engine_set_precision": (c_int, [c_void_p, c_int]),
+    "ws_engine_check_range": (c_int, [c_void_p, c_void_p]),
     "ws_engine_profile_enable": (c_int, [c_void_p, c_int]),
     "ws_engine_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ws_engine_flops": (c_double, [c_void_p, c_int, c_int]),

@@ -417,6 +417,18 @@ int ws_engine_set_precision(ws_engine* eng, int mode) {
   return r;
 }
 
+int ws_engine_check_range(ws_engine* eng, ws_stream stream) {
+  if (!eng || !eng->finalized) { set_error("ws_engine_check_range: invalid argument"); return WS_ERR_INVALID_ARG; }
+  WS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  const int n = eng->model->take_nonfinite();
+  if (n > 0) {
+    set_error("binary16 range exceeded: %d non-finite embedding values since the last check (an "
+              "activation passed 65504 in the f16 / f16x3 back-end; use WS_PREC_FP32 for this model)", n);
+    return WS_ERR_RANGE;
+  }
+  return WS_OK;
+}
+
 int ws_engine_profile_enable(ws_engine* eng, int on) {
   if (!eng) { set_error("ws_engine_profile_enable: invalid argument"); return WS_ERR_INVALID_ARG; }
   eng->model->prof.enabled = on != 0;

@@ -184,6 +184,9 @@ struct Model {
   virtual int forward(const float* feats, int batch, int frames, float* emb,
                       hipStream_t stream) = 0;
   virtual double flops(int batch, int frames) const = 0;
+  // non-finite embedding values produced by the binary16 back-ends since the last call (reads and
+  // clears the host-mapped counter; the caller has synchronised the stream)
+  virtual int take_nonfinite() = 0;
   virtual int set_precision(int mode) = 0;   // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
   virtual float* feats_workspace() = 0;      // (max_batch, max_frames, feat_dim) floats
   virtual int max_batch() const = 0;

@@ -276,7 +276,7 @@ struct EcapaModel : ModelBase {
                             emb + (size_t)b0 * embed_dim, st);
       if (r) return r;
     }
-    return 0;
+    return range_guard(emb, batch, st);
   }
 
   double flops(int batch, int T) const override {

@@ -319,6 +319,26 @@ __global__ __launch_bounds__(256) void chunk_average_kernel(const float* __restr
   avg[e] = s / (float)n;
 }
 
+// Range guard of the binary16 back-ends: counts non-finite outputs into a (host-mapped) counter.  The
+// counter is only touched when something IS non-finite, so the normal path costs one tiny launch.
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long long n,
+                                                              int* __restrict__ counter) {
+  int bad = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    bad += !(fabsf(v) <= 3.402823466e38f);          // inf or NaN
+  }
+  if (bad) atomicAdd_system(counter, bad);
+}
+
+hipError_t launch_count_nonfinite(const float* x, long long n, int* counter, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, counter);
+  return hipGetLastError();
+}
+
 hipError_t launch_chunk_average(const float* emb, int n, int E, float* avg, hipStream_t stream) {
   hipLaunchKernelGGL(chunk_average_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, emb, n, E, avg);
   return hipGetLastError();

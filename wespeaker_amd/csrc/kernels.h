@@ -166,6 +166,8 @@ hipError_t launch_im2col_f16(const float* feats, int B, int T, int F, int taps, 
 hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int n_full, int n_chunks,
                                float* dst, hipStream_t stream);
 hipError_t launch_chunk_average(const float* emb, int n, int E, float* avg, hipStream_t stream);
+// *counter += number of non-finite values among x[0..n) (counter: device-visible, system-scope atomics)
+hipError_t launch_count_nonfinite(const float* x, long long n, int* counter, hipStream_t stream);
 
 // ---- PLDA (float64)
 hipError_t launch_plda_prepare(const void* emb, int emb_is_f64, const int32_t* group_offsets,

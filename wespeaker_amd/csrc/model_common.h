@@ -48,6 +48,24 @@ struct ModelBase : Model {
     gemm_precision = mode;
     return WS_OK;
   }
+  // ---- range guard of the binary16 back-ends (activations beyond 65504 become inf and surface as
+  // non-finite embeddings): a host-mapped counter bumped by a tiny kernel after every forward
+  int* nonfinite_host = nullptr;
+  int* nonfinite_dev = nullptr;
+  ~ModelBase() override {
+    if (nonfinite_host) (void)hipHostFree(nonfinite_host);
+  }
+  int range_guard(const float* emb, int batch, hipStream_t st) {
+    if (gemm_precision == 0 || !nonfinite_dev) return 0;
+    WS_LAUNCH(launch_count_nonfinite(emb, (long long)batch * embed_dim, nonfinite_dev, st));
+    return 0;
+  }
+  int take_nonfinite() override {
+    if (!nonfinite_host) return 0;
+    const int n = *reinterpret_cast<volatile int*>(nonfinite_host);
+    *reinterpret_cast<volatile int*>(nonfinite_host) = 0;
+    return n;
+  }
   float* feats_workspace() override { return feats_ws; }
   int max_batch() const override { return maxB; }
   int max_frames() const override { return maxT; }
@@ -198,7 +216,16 @@ struct ModelBase : Model {
   }
 
   int upload_weights() {
-    hipError_t he = arena.upload();
+    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&nonfinite_host), sizeof(int), hipHostMallocMapped);
+    if (he == hipSuccess) {
+      *nonfinite_host = 0;
+      he = hipHostGetDevicePointer(reinterpret_cast<void**>(&nonfinite_dev), nonfinite_host, 0);
+    }
+    if (he != hipSuccess) {
+      set_error("range-guard counter allocation failed: %s", hipGetErrorString(he));
+      return WS_ERR_HIP;
+    }
+    he = arena.upload();
     if (he != hipSuccess) {
       set_error("weight upload failed: %s", hipGetErrorString(he));
       return WS_ERR_HIP;

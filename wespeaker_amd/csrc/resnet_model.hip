@@ -216,7 +216,7 @@ struct ResNetModel : ModelBase {
                             emb + (size_t)b0 * embed_dim, st);
       if (r) return r;
     }
-    return 0;
+    return range_guard(emb, batch, st);
   }
 
   double flops(int batch, int T) const override {

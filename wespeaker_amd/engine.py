@@ -185,11 +185,21 @@ class NativeSpeakerModel:
         self.precision = {v: k for k, v in self.PRECISIONS.items()}[code]
         return self
 
+    def check_range(self):
+        """Binary16 back-ends only: synchronise the current stream and raise NativeError if an activation
+        left the binary16 range since the last check (ws_engine_check_range).  No-op in fp32."""
+        if self.precision != "fp32":
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_engine_check_range(self._h, _lib.current_stream_ptr(self.device)),
+                           "ws_engine_check_range")
+
     def flops(self, batch, frames) -> float:
         return float(_lib.lib().ws_engine_flops(self._h, int(batch), int(frames)))
 
-    PROFILE_CLASSES = ("conv_gemm_f32_128x128", "conv_gemm_f32_128x64", "reduce_elementwise",
-                       "conv_gemm_f32_splitk")
+    # kernel classes of ws_engine_profile_read: every conv/linear GEMM launch with N > 64 (whatever tile
+    # and back-end the dispatcher picks: the dominant class), the narrow ones (N <= 64, fused Res2 chain),
+    # reductions / element-wise / frontend, split-K GEMMs of the M = B layers
+    PROFILE_CLASSES = ("gemm_main", "gemm_narrow", "reduce_elementwise", "gemm_splitk")
 
     def profile(self, on):
         """on: False/0 = off, True = all kernel classes, int = bit mask (1 = dominant GEMM only)."""

@@ -1,0 +1,495 @@
+"""Batch extraction driver: data list -> per-job `xvector_XXX.ark/scp` -> merged `xvector.scp`.
+
+The MI355X twin of the reference's batch path
+    tools/extract_embedding.sh:39-67      split the list into nj contiguous sub-lists, job k -> GPU k % G,
+                                          `cat xvector_*.scp > xvector.scp`, count check -> extract.result
+    wespeaker/bin/extract.py:33-139       one job: config + checkpoint -> Dataset -> model -> ark,scp writer
+    wespeaker/dataset/dataset.py:136-268  the test-time pipeline (no shuffle / filter / augmentation):
+                                          parse -> resample -> [random_chunk] -> fbank; CMN applied in extract.py
+    examples/voxceleb/v2/local/extract_vox.sh:31   vox2_dev cohort: batch 16 of random 200-frame crops;
+                                                   test sets: whole utterances (batch_size 1)
+with the same flags, file names and on-disk formats, run as ONE process per GPU:
+
+    python -m torch.distributed.run --nproc-per-node G -m wespeaker_amd.extract \
+        --exp_dir exp/X --model_path exp/X/models/avg_model.pt --data_type raw \
+        --data_list data/vox1/raw.list --store_dir vox1 --wavs_num 4874 --batch_size 1 --nj 8
+
+What is different by design (MI355X-first, not a translation):
+  * whole-utterance mode is still "batch_size 1" in its RESULT (every utterance is embedded on its own
+    frames), but utterances of equal length are stacked into one device batch, so the engine sees real
+    batches instead of launch-bound single rows; the output order is the list order;
+  * file decode runs on host threads ahead of the GPU, PCM goes through rotating pinned buffers and a copy
+    stream (H2D of batch i+1 overlaps the forward of batch i), embeddings come back through pinned memory;
+  * fbank + CMN + forward are one C-ABI call (ws_extract) on int16 PCM resident in HBM;
+  * rank r runs jobs r, r+G, ... of the nj sub-lists; the only collective is the optional all_gather of
+    the embeddings (`gather=True`: every rank gets all rows in list order, e.g. for PLDA scoring on rank 0).
+The random crops of the cohort mode use a seeded per-utterance generator (the reference draws from the
+unseeded global `random` in DataLoader workers, i.e. is not reproducible; the crop length rule is the same).
+"""
+import io
+import json
+import os
+import subprocess
+import tarfile
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+import yaml
+
+from . import parallel
+from .audio import load_wav
+from .kaldi_io import VectorWriter
+
+AUDIO_SUFFIXES = ("flac", "mp3", "m4a", "ogg", "opus", "wav", "wma")     # dataset/processor.py:33
+
+
+# ----------------------------------------------------------------------------------- list handling
+def read_lists(list_file):
+    """dataset/lmdb_data or file_utils.read_lists: one entry per non-empty line."""
+    with open(list_file, "r", encoding="utf8") as f:
+        return [line.rstrip("\n") for line in f if line.strip()]
+
+
+def split_rule(n_lines, nj):
+    """tools/extract_embedding.sh:40-42: `split -l $((data_num / nj + 1))` -> [lo, hi) per job
+    (contiguous; the last jobs may be short or empty, exactly like the files split writes)."""
+    per = n_lines // nj + 1
+    return [(min(n_lines, j * per), min(n_lines, (j + 1) * per)) for j in range(nj)]
+
+
+def _read_audio_entry(wav):
+    """processor.parse_raw.read_audio (:129-136): a path, or a shell command ending in '|'."""
+    if wav.endswith("|"):
+        data = subprocess.run(wav[:-1], shell=True, stdout=subprocess.PIPE, check=True).stdout
+        return load_wav(io.BytesIO(data), normalize=False)
+    return load_wav(wav, normalize=False)
+
+
+def iter_entries(data_type, lines):
+    """-> (key, loader) pairs in list order; loader() -> ((C, N) int16/float tensor, sample_rate).
+    raw: json lines {key, wav, spk} (processor.parse_raw); scp: `key path`; shard: tar files of
+    key.wav/key.spk members (processor.tar_file_and_group) -- a shard's members are read when reached."""
+    if data_type == "raw":
+        for line in lines:
+            obj = json.loads(line)
+            yield obj["key"], (lambda w=obj["wav"]: _read_audio_entry(w))
+    elif data_type == "scp":
+        for line in lines:
+            key, path = line.strip().split(None, 1)
+            yield key, (lambda w=path: _read_audio_entry(w))
+    elif data_type == "shard":
+        for line in lines:
+            with tarfile.open(line.strip(), mode="r:*") as tar:
+                for info in tar:
+                    pos = info.name.rfind(".")
+                    if pos <= 0 or info.name[pos + 1:] not in AUDIO_SUFFIXES:
+                        continue
+                    data = tar.extractfile(info).read()
+                    yield info.name[:pos], (lambda d=data: load_wav(io.BytesIO(d), normalize=False))
+    else:
+        raise NotImplementedError("data_type %r (raw / scp / shard are on the MI355X path; 'feat' lists of "
+                                  "precomputed Kaldi features are not)" % data_type)
+
+
+def crop_start(key, data_len, chunk_len, seed):
+    """Start of the random crop of `key` (processor.get_random_chunk:315-347 draws
+    random.randint(0, data_len - chunk_len)); seeded per utterance so that runs repeat."""
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
+    return int(rng.integers(0, data_len - chunk_len + 1))
+
+
+def random_chunk(pcm, key, chunk_len, seed):
+    """get_random_chunk: crop if long enough, else tile (`repeat`) and cut to chunk_len."""
+    n = pcm.shape[0]
+    if n >= chunk_len:
+        s = crop_start(key, n, chunk_len, seed)
+        return pcm[s:s + chunk_len]
+    reps = chunk_len // n + 1
+    return pcm.repeat(reps)[:chunk_len]
+
+
+# ------------------------------------------------------------------------------ the overlapped engine
+class GpuExtractor:
+    """(B, N) int16 host batches -> (B, E) float32 host rows through ws_extract, with rotating pinned
+    staging buffers, a copy stream for H2D and non-blocking D2H: batch i+1 uploads while batch i computes."""
+
+    def __init__(self, model, frontend, window_type="hamming", depth=2):
+        self.model, self.frontend, self.window_type = model, frontend, window_type
+        self.device = model.device
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.depth = depth
+        self._slots = [dict(pin=None, dev=None, ready=None, free=None) for _ in range(depth)]
+        self._turn = 0
+        self.embed_dim = model.embed_dim
+
+    def submit(self, batch_cpu: torch.Tensor):
+        """Enqueue one batch; returns a handle whose .result() is the (B, E) numpy array."""
+        slot = self._slots[self._turn % self.depth]
+        self._turn += 1
+        B, N = batch_cpu.shape
+        if batch_cpu.dtype != torch.int16:                   # 8- / 32-bit files arrive as int16-range floats
+            batch_cpu = batch_cpu.to(torch.float32)
+        nbytes = B * N * batch_cpu.element_size()
+        if slot["free"] is not None:
+            slot["free"].synchronize()                       # the forward that read this slot has finished
+        if slot["pin"] is None or slot["pin"].numel() < nbytes:
+            slot["pin"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+            slot["dev"] = torch.empty(slot["pin"].numel(), dtype=torch.uint8, device=self.device)
+        pin = slot["pin"][:nbytes].view(batch_cpu.dtype).view(B, N)
+        pin.copy_(batch_cpu)
+        dev = slot["dev"][:nbytes].view(batch_cpu.dtype).view(B, N)
+        with torch.cuda.stream(self.copy_stream):
+            dev.copy_(pin, non_blocking=True)
+            uploaded = torch.cuda.Event()
+            uploaded.record(self.copy_stream)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(uploaded)
+        emb = self.model.extract(self.frontend, dev, window_type=self.window_type)
+        slot["free"] = torch.cuda.Event()
+        slot["free"].record(main)
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32).pin_memory()
+        out.copy_(emb, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(main)
+        return _Pending(out, done)
+
+    def finish(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.model.check_range()
+
+
+class _Pending:
+    def __init__(self, out, event):
+        self._out, self._event = out, event
+
+    def result(self):
+        self._event.synchronize()
+        return self._out.numpy()
+
+
+class HostExtractor:
+    """Same submit()/finish() protocol around any callable (B, N) tensor -> (B, E) array: the CPU tests use it
+    to exercise list handling, bucketing, sharding and file output without a GPU."""
+
+    def __init__(self, fn, embed_dim):
+        self.fn, self.embed_dim = fn, embed_dim
+
+    def submit(self, batch_cpu):
+        out = np.asarray(self.fn(batch_cpu), dtype=np.float32)
+        return _Done(out)
+
+    def finish(self):
+        pass
+
+
+class _Done:
+    def __init__(self, out):
+        self._out = out
+
+    def result(self):
+        return self._out
+
+
+# ------------------------------------------------------------------------------------- one job
+def _prefetch(pool, fn, items, depth):
+    """fn(item) results in item order with at most `depth` items decoded ahead of the consumer
+    (Executor.map would submit the whole list -- and hold every decoded waveform -- at once)."""
+    from collections import deque
+    q = deque()
+    for it in items:
+        q.append(pool.submit(fn, it))
+        if len(q) >= depth:
+            yield q.popleft().result()
+    while q:
+        yield q.popleft().result()
+
+
+def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=32240, max_batch=256,
+                    resample_rate=16000, num_workers=4, seed=0, resample_fn=None,
+                    max_buffered_samples=64 << 20):
+    """Embeddings of `entries` ((key, loader) pairs) in list order -> (keys, (n, E) float32).
+
+    whole_utt (default: batch_size == 1, the rule of bin/extract.py:95): every utterance on all of its
+    samples; equal-length utterances share a device batch of up to max_batch rows.  Otherwise every
+    utterance is cut/tiled to chunk_len samples (random_chunk) and batches hold max(batch_size, ...) rows
+    -- the batch size does not change any row's value, so the cohort mode also fills up to max_batch.
+    Utterances waiting for a full bucket hold at most max_buffered_samples samples in host memory."""
+    if whole_utt is None:
+        whole_utt = batch_size == 1
+    keys, rows = [], {}
+    pending = []                       # (indices, handle)
+    buckets = {}                       # (length, dtype) -> (indices, tensors)
+    buffered = 0
+
+    def load(item):
+        idx, (key, loader) = item
+        pcm, sr = loader()
+        pcm = pcm[0]
+        if sr != resample_rate:
+            if resample_fn is None:
+                raise RuntimeError("%s is sampled at %d Hz, expected %d (no resampler given)" % (key, sr, resample_rate))
+            pcm = resample_fn(pcm, sr, resample_rate)
+        if not whole_utt:
+            pcm = random_chunk(pcm, key, chunk_len, seed)
+        return idx, key, pcm
+
+    def flush(length):
+        idxs, tensors = buckets.pop(length)
+        pending.append((idxs, extractor.submit(torch.stack(tensors))))
+
+    def drain(keep):
+        while len(pending) > keep:
+            idxs, handle = pending.pop(0)
+            emb = handle.result()
+            for k, i in enumerate(idxs):
+                rows[i] = emb[k].copy()
+
+    workers = max(1, num_workers)
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        # file decode runs ahead of the GPU on the pool; results arrive in list order
+        for idx, key, pcm in _prefetch(pool, load, enumerate(entries), depth=4 * workers):
+            keys.append(key)
+            n = int(pcm.shape[0])
+            b = buckets.setdefault((n, pcm.dtype), ([], []))
+            b[0].append(idx)
+            b[1].append(pcm)
+            buffered += n
+            if len(b[0]) >= max_batch:
+                buffered -= n * len(b[0])
+                flush((n, pcm.dtype))
+                drain(keep=2)
+            elif buffered > max_buffered_samples:
+                for length in sorted(buckets, key=lambda t: t[0]):
+                    flush(length)
+                    drain(keep=2)
+                buffered = 0
+        for length in sorted(buckets, key=lambda t: t[0]):
+            flush(length)
+            drain(keep=2)
+        drain(keep=0)
+    extractor.finish()
+    n = len(keys)
+    emb = np.stack([rows[i] for i in range(n)]) if n else np.zeros((0, extractor.embed_dim), np.float32)
+    return keys, emb
+
+
+def write_ark_scp(keys, emb, embed_ark):
+    """bin/extract.py:105-111,137-139: `ark,scp:<embed_ark>,<embed_ark[:-3]>scp`, absolute ark path."""
+    d = os.path.dirname(embed_ark)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    embed_ark = os.path.abspath(embed_ark)
+    embed_scp = embed_ark[:-3] + "scp"
+    with VectorWriter(embed_ark, embed_scp) as w:
+        for k, e in zip(keys, emb):
+            w(k, e)
+    return embed_scp
+
+
+# ----------------------------------------------------------------------------- config + model
+def load_config(config, **overrides):
+    """utils.parse_config_or_kwargs (utils/utils.py:37-51): yaml keys, overridden by keyword arguments."""
+    with open(config) as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    return dict(cfg, **overrides)
+
+
+def check_frontend_config(configs):
+    """The test-time dataset settings this driver implements; anything else is refused loudly."""
+    ds = dict(configs.get("dataset_args") or {})
+    if ds.get("frontend", "fbank") != "fbank":
+        raise NotImplementedError("frontend %r: only 'fbank' is on the MI355X hot path" % ds.get("frontend"))
+    fb = dict(ds.get("fbank_args") or {})
+    if fb.get("frame_length", 25) != 25 or fb.get("frame_shift", 10) != 10:
+        raise NotImplementedError("fbank frame_length/frame_shift other than 25/10 ms")
+    if not ds.get("cmvn", True):
+        raise NotImplementedError("cmvn: False (the fused ws_extract path always subtracts the mean)")
+    cm = dict(ds.get("cmvn_args") or {})
+    if not cm.get("norm_mean", True) or cm.get("norm_var", False):
+        raise NotImplementedError("cmvn_args other than norm_mean=True, norm_var=False")
+    return {"resample_rate": int(ds.get("resample_rate", 16000)),
+            "num_mel_bins": int(fb.get("num_mel_bins", 80)),
+            "num_frms": int(ds.get("num_frms", 200))}
+
+
+def chunk_samples(num_frms, resample_rate, frame_shift=10, frame_length=25):
+    """dataset.py:237-241: ((num_frms - 1) * frame_shift + frame_length) * resample_rate // 1000."""
+    return ((num_frms - 1) * frame_shift + frame_length) * resample_rate // 1000
+
+
+def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_frames=400, precision="fp32"):
+    """get_speaker_model(...)(**model_args) + load_checkpoint (bin/extract.py:66-77) on the native engine."""
+    from .engine import Frontend, NativeSpeakerModel
+    from .speaker import _load_state_dict
+    fc = check_frontend_config(configs)
+    margs = dict(configs.get("model_args") or {})
+    margs.pop("pooling_func", None)
+    feat_dim = int(margs.pop("feat_dim", fc["num_mel_bins"]))
+    embed_dim = margs.pop("embed_dim", None)
+    sd = _load_state_dict(model_path)
+    model = NativeSpeakerModel(configs["model"], sd, feat_dim=feat_dim, embed_dim=embed_dim, device=device,
+                               max_batch=max_batch, max_frames=max_frames)
+    model.set_precision(precision)
+    fe = Frontend(fc["resample_rate"], feat_dim, device=model.device)
+    return GpuExtractor(model, fe), fc
+
+
+def _gpu_resampler(device):
+    from .audio import resample
+
+    def fn(pcm, sr, target):
+        return resample(pcm.to(torch.float), sr, target, device).cpu()
+    return fn
+
+
+# ------------------------------------------------------------------------------------ entry points
+def extract(config="conf/config.yaml", **kwargs):
+    """ONE job = wespeaker/bin/extract.py: flags model_path, data_type, data_list, embed_ark, batch_size,
+    num_workers (+ precision, max_batch extensions).  Writes embed_ark and its .scp; returns (keys, emb)."""
+    configs = load_config(config, **kwargs)
+    batch_size = int(configs.get("batch_size", 1))
+    extractor, fc = build_gpu_extractor(configs, configs["model_path"], device=configs.get("device"),
+                                        max_batch=int(configs.get("max_batch", 256)),
+                                        precision=configs.get("precision", "fp32"))
+    lines = read_lists(configs["data_list"])
+    keys, emb = extract_entries(
+        iter_entries(configs["data_type"], lines), extractor, batch_size=batch_size,
+        chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
+        max_batch=int(configs.get("max_batch", 256)), resample_rate=fc["resample_rate"],
+        num_workers=int(configs.get("num_workers", 4)), seed=int(configs.get("seed", 0)),
+        resample_fn=_gpu_resampler(extractor.device))
+    write_ark_scp(keys, emb, configs["embed_ark"])
+    return keys, emb
+
+
+def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, batch_size=1, chunk_len=32240,
+             max_batch=256, resample_rate=16000, num_workers=4, seed=0, resample_fn=None, gather=False,
+             wavs_num=None, store_dir=""):
+    """tools/extract_embedding.sh on `world` ranks: job j of the nj contiguous sub-lists runs on rank
+    j % world and writes embed_dir/xvector_{j:03d}.ark/.scp (+ log/split_{j:03d}); after a barrier rank 0
+    concatenates the scp files in job order into xvector.scp, compares the count with wavs_num and writes
+    extract.result with the reference's two messages.  gather=True additionally returns, on every rank,
+    (keys, (N, E) embeddings) of the whole list in list order through ONE all_gather of padded blocks."""
+    import torch.distributed as dist
+    log_dir = os.path.join(embed_dir, "log")
+    os.makedirs(log_dir, exist_ok=True)
+    spans = split_rule(len(lines), nj)
+    extractor = None
+    my_keys, my_emb = [], []
+    for j, (lo, hi) in enumerate(spans):
+        if j % world != rank:
+            continue
+        with open(os.path.join(log_dir, "split_%03d" % j), "w") as f:
+            f.write("".join(l + "\n" for l in lines[lo:hi]))
+        if hi <= lo:
+            continue                                # `split` writes no file for an empty tail job
+        if extractor is None:
+            extractor = make_extractor()
+        keys, emb = extract_entries(iter_entries(data_type, lines[lo:hi]), extractor, batch_size=batch_size,
+                                    chunk_len=chunk_len, max_batch=max_batch, resample_rate=resample_rate,
+                                    num_workers=num_workers, seed=seed, resample_fn=resample_fn)
+        write_ark_scp(keys, emb, os.path.join(embed_dir, "xvector_%03d.ark" % j))
+        my_keys.append((j, keys))
+        my_emb.append((j, emb))
+    multi = world > 1 and dist.is_initialized()
+    if multi:
+        dist.barrier()
+    result = None
+    if rank == 0:
+        merged = os.path.join(embed_dir, "xvector.scp")
+        count = 0
+        with open(merged, "w") as out:
+            for j in range(nj):
+                p = os.path.join(embed_dir, "xvector_%03d.scp" % j)
+                if os.path.exists(p):
+                    with open(p) as f:
+                        for line in f:
+                            out.write(line)
+                            count += 1
+        ok = wavs_num is None or count == int(wavs_num)
+        result = ("Successfully extract embedding for %s" if ok else "Failed to extract embedding for %s") % store_dir
+        with open(os.path.join(embed_dir, "extract.result"), "w") as f:
+            f.write(result + "\n")
+        print(result)
+    if not gather:
+        return result
+    # ---- all ranks: the whole list in list order (job j sits at rows [lo_j, hi_j) for raw/scp lists)
+    E = extractor.embed_dim if extractor is not None else 0
+    if multi:
+        e_t = torch.tensor([E])
+        dist.all_reduce(e_t, op=dist.ReduceOp.MAX)
+        E = int(e_t.item())
+    local = np.concatenate([e for _, e in my_emb]) if my_emb else np.zeros((0, E), np.float32)
+    local_keys = [k for _, ks in my_keys for k in ks]
+    if not multi:
+        return local_keys, local
+    counts = torch.zeros(world, dtype=torch.int64)
+    counts[rank] = local.shape[0]
+    dist.all_reduce(counts)
+    per = int(counts.max().item())
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    block = torch.zeros((per, E), dtype=torch.float32, device=dev)
+    block[:local.shape[0]] = torch.from_numpy(local).to(dev)
+    full = parallel.gather_rows(block, per * world).cpu().numpy()
+    key_lists = [None] * world
+    dist.all_gather_object(key_lists, [(j, ks) for j, ks in my_keys])
+    # rank r's block holds its jobs in increasing j; re-assemble in job order
+    pieces = {}
+    for r in range(world):
+        off = 0
+        for j, ks in key_lists[r]:
+            pieces[j] = (ks, full[r * per + off: r * per + off + len(ks)])
+            off += len(ks)
+    keys = [k for j in sorted(pieces) for k in pieces[j][0]]
+    emb = np.concatenate([pieces[j][1] for j in sorted(pieces)]) if pieces else np.zeros((0, E), np.float32)
+    return keys, emb
+
+
+def main(argv=None):
+    """Flags of tools/extract_embedding.sh (+ --config, --precision, --max_batch)."""
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--exp_dir", default="exp/XVEC")
+    ap.add_argument("--config", default=None, help="default: <exp_dir>/config.yaml")
+    ap.add_argument("--model_path", default="avg_model.pt")
+    ap.add_argument("--data_type", default="shard", choices=["shard", "raw", "scp"])
+    ap.add_argument("--data_list", default="shard.list")
+    ap.add_argument("--wavs_num", type=int, default=None)
+    ap.add_argument("--store_dir", default="")
+    ap.add_argument("--batch_size", "--batch-size", type=int, default=1)
+    ap.add_argument("--num_workers", "--num-workers", type=int, default=4)
+    ap.add_argument("--nj", type=int, default=0, help="number of sub-lists (default: the number of ranks)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "f16"])
+    ap.add_argument("--max_batch", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", default=None, help="accepted for compatibility; ranks map to LOCAL_RANK")
+    args = ap.parse_args(argv)
+    rank, world, local_rank = parallel.init_distributed()
+    # WS_SHARE_GPU=1 (debug / single-GPU boxes, with WS_DIST_BACKEND=gloo): every rank uses GPU 0
+    device = torch.device("cuda", 0 if os.environ.get("WS_SHARE_GPU") else local_rank)
+    torch.cuda.set_device(device)
+    configs = load_config(args.config or os.path.join(args.exp_dir, "config.yaml"))
+    fc = check_frontend_config(configs)
+    embed_dir = os.path.join(args.exp_dir, "embeddings", args.store_dir)
+
+    def make():
+        ex, _ = build_gpu_extractor(configs, args.model_path, device=device, max_batch=args.max_batch,
+                                    precision=args.precision)
+        return ex
+
+    run_jobs(read_lists(args.data_list), args.data_type, embed_dir, make, args.nj or world, rank, world,
+             batch_size=args.batch_size, chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
+             max_batch=args.max_batch, resample_rate=fc["resample_rate"], num_workers=args.num_workers,
+             seed=args.seed, resample_fn=_gpu_resampler(device), wavs_num=args.wavs_num,
+             store_dir=args.store_dir)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

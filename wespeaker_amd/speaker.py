@@ -150,6 +150,7 @@ class Speaker:
             emb = self.model(arr_t[i:i + batch_size])
             emb = emb[-1] if isinstance(emb, tuple) else emb
             out.append(emb.detach().cpu().numpy())
+        self.model.check_range()
         return np.vstack(out)
 
     # ------------------------------------------------------------------------------ extraction
@@ -166,7 +167,9 @@ class Speaker:
         wav = pcm[0:1] if pcm.dim() == 2 else pcm.unsqueeze(0)
         fe = self._frontend(self.resample_rate)
         emb = self.model.extract(fe, wav, window_type=self.window_type)
-        return emb[0].to(torch.device("cpu"))
+        out = emb[0].to(torch.device("cpu"))
+        self.model.check_range()          # binary16 back-ends: loud if the checkpoint left their range
+        return out
 
     def extract_embedding_batch(self, wavs: torch.Tensor, sample_rate: int = 16000):
         """(B, N) equal-length utterances -> (B, E) on the GPU (the batched form of
@@ -179,29 +182,27 @@ class Speaker:
 
     def extract_embedding_list(self, scp_path: str):
         """scp of `name wav_path` lines -> (names, [np.ndarray(E)]) (speaker.py:169-178).
-        Utterances are independent, so equal-length ones are batched; the order of the output
-        follows the scp like the reference's batch-1 loop."""
-        names, wavs = [], []
-        with open(scp_path, "r") as read_scp:
-            for line in read_scp:
-                name, wav_path = line.strip().split()
-                names.append(name)
-                pcm, sr = load_wav(wav_path, normalize=self.wavform_norm)
-                if sr != self.resample_rate:
-                    from .audio import resample
-                    pcm = resample(pcm.to(torch.float), sr, self.resample_rate, self.device).cpu()
-                wavs.append(pcm[0])
-        embeddings = [None] * len(names)
-        by_len = {}
-        for i, w in enumerate(wavs):
-            by_len.setdefault((w.shape[0], w.dtype), []).append(i)
-        fe = self._frontend(self.resample_rate)
-        for (_, _), idxs in by_len.items():
-            batch = torch.stack([wavs[i] for i in idxs])
-            emb = self.model.extract(fe, batch, window_type=self.window_type).cpu().numpy()
-            for k, i in enumerate(idxs):
-                embeddings[i] = emb[k]
-        return names, embeddings
+        Utterances are independent, so equal-length ones share a device batch; file decode, H2D and
+        the forward overlap (wespeaker_amd.extract.GpuExtractor); the order of the output follows
+        the scp like the reference's batch-1 loop."""
+        from . import extract as wx
+
+        def entries():
+            with open(scp_path, "r") as read_scp:
+                for line in read_scp:
+                    if not line.strip():
+                        continue
+                    name, wav_path = line.strip().split()
+                    yield name, (lambda w=wav_path: load_wav(w, normalize=self.wavform_norm))
+
+        def resample_fn(pcm, sr, target):
+            from .audio import resample
+            return resample(pcm.to(torch.float), sr, target, self.device).cpu()
+
+        ex = wx.GpuExtractor(self.model, self._frontend(self.resample_rate), self.window_type)
+        names, emb = wx.extract_entries(entries(), ex, batch_size=1, max_batch=self.model.max_batch,
+                                        resample_rate=self.resample_rate, resample_fn=resample_fn)
+        return names, [e for e in emb]
 
     # ------------------------------------------------------------------- similarity (:180-211)
     def compute_similarity(self, audio_path1: str, audio_path2: str) -> float:
