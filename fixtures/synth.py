@@ -295,7 +295,7 @@ def synth_scoring_set(n_eval=60, n_cohort=150, dim=192, num_trials=300, seed=21)
 def write_scoring_files(fix, out_dir):
     """Write the fixture as the files the reference's score.py / score_norm.py consume."""
     import os
-    from .kaldi_io import VectorWriter
+    from wespeaker_amd.kaldi_io import VectorWriter
     os.makedirs(out_dir, exist_ok=True)
     paths = {"eval_scp": os.path.join(out_dir, "xvector.scp"),
              "cohort_scp": os.path.join(out_dir, "cohort.scp"),
@@ -329,7 +329,7 @@ def synth_plda_training_set(n=400, dim=64, num_speakers=40, n_adapt=300, seed=41
 
 def write_plda_training_files(fix, out_dir):
     import os
-    from .kaldi_io import VectorWriter
+    from wespeaker_amd.kaldi_io import VectorWriter
     os.makedirs(out_dir, exist_ok=True)
     paths = {"scp": os.path.join(out_dir, "train.scp"), "utt2spk": os.path.join(out_dir, "utt2spk"),
              "adapt_scp": os.path.join(out_dir, "adapt.scp")}

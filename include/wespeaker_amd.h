@@ -116,6 +116,23 @@ WS_API int ws_forward(ws_engine* eng, const float* feats, int batch, int num_fra
 WS_API int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                int num_samples, int64_t wav_stride, float scale, int window_type, float* emb,
                ws_stream stream);
+/* ---- ragged batches: utterances of DIFFERENT lengths in one device batch.
+ * The reference extracts test sets one utterance at a time (batch_size 1, bin/extract.py:95,
+ * cli/speaker.py:169-178) because its modules have no length argument; a batch-1 loop leaves an MI355X
+ * launch-bound.  Here utterance b occupies the first num_*[b] entries of its row of the padded
+ * (batch, max_*) tensor; the result of every row equals what the batch-1 call returns for it: padding never
+ * enters a convolution tap (it is the conv's zero padding), CMN / SE means / attentive and statistics pooling
+ * / CAM++ context segments run over the utterance's own frames (pooling_layers.py:78-85,119-144;
+ * campplus.py:108-135; ecapa_tdnn.py:120-126).  The length arrays are HOST pointers (read before the call
+ * returns). */
+WS_API int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, const int32_t* num_samples,
+                    int max_samples, int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
+                    ws_stream stream);   /* feats (batch, ws_num_frames(max_samples), bins); rows beyond an utterance's frames = 0 */
+WS_API int ws_forward_ragged(ws_engine* eng, const float* feats, int batch, int max_frames, const int32_t* num_frames,
+                      float* emb, ws_stream stream);   /* feats (batch, max_frames, feat_dim); padding rows are ignored */
+WS_API int ws_extract_ragged(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
+                      const int32_t* num_samples, int max_samples, int64_t wav_stride, float scale,
+                      int window_type, float* emb, ws_stream stream);
 /* Polyphase windowed-sinc resampling of one channel: the arithmetic of
  * torchaudio.transforms.Resample(orig_freq, new_freq) as Speaker.extract_embedding_from_pcm applies it
  * (cli/speaker.py:157-160).  orig / new are the rates divided by their gcd; kernel DEVICE float32

@@ -182,3 +182,28 @@ def test_count_mismatch_is_reported_like_the_script(tmp_path):
     msg = wx.run_jobs(lines_raw, "raw", str(tmp_path / "o"), lambda: wx.HostExtractor(_fake_rows, 6), nj=2,
                       wavs_num=6, store_dir="vox1")
     assert msg == "Failed to extract embedding for vox1"
+
+
+def test_ragged_capable_extractors_get_length_classes(tmp_path):
+    """Extractors that take padded batches (GpuExtractor: ws_extract_ragged) receive utterances whose
+    lengths lie within the tolerance of each other; exact-length extractors never see mixed lengths."""
+    lines = []
+    lengths = [16000 + 331 * i for i in range(20)]                  # 16000 .. 22289: all different
+    for i, L in enumerate(lengths):
+        p = str(tmp_path / ("g%02d.wav" % i))
+        synth.write_wav(p, synth.synth_wav(600 + i, L))
+        lines.append("utt%02d %s" % (i, p))
+    seen = []
+
+    def ragged_fn(padded, lens):
+        seen.append(list(lens))
+        return np.concatenate([_fake_rows(padded[b:b + 1, :n]) for b, n in enumerate(lens)])
+
+    ex = wx.HostExtractor(_fake_rows, 6, ragged_fn=ragged_fn)
+    keys, emb = wx.extract_entries(wx.iter_entries("scp", lines), ex, batch_size=1, max_batch=8)
+    ref = np.concatenate([_fake_rows(torch.from_numpy(synth.synth_wav(600 + i, L))[None]) for i, L in enumerate(lengths)])
+    assert keys == ["utt%02d" % i for i in range(20)] and np.array_equal(emb, ref)
+    assert seen and all(max(c) <= min(c) * 1.12 + 1 for c in seen) and sum(len(c) for c in seen) >= 15
+    ex2 = wx.HostExtractor(_fake_rows, 6)                             # no ragged support: exact lengths only
+    keys2, emb2 = wx.extract_entries(wx.iter_entries("scp", lines), ex2, batch_size=1, max_batch=8)
+    assert np.array_equal(emb2, ref)

@@ -34,6 +34,11 @@ SIGNATURES = {
     "ws_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ws_extract": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float,
                            c_int, c_void_p, c_void_p]),
+    "ws_fbank_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_float, c_int, c_int,
+                                c_void_p, c_void_p]),
+    "ws_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ws_extract_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_float,
+                                  c_int, c_void_p, c_void_p]),
     "ws_resample": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "ws_extract_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_void_p]),

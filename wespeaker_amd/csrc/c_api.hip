@@ -28,6 +28,15 @@ struct ws_frontend {
   int frame_len = 400, frame_shift = 160, fft_n = 512;
   DevBuf window_h, window_p, twiddle, mel_start, mel_len, mel_off, mel_w;
   FbankTables tables;
+  // ws_fbank_ragged: per-utterance frame counts (device) + their pinned staging
+  DevBuf frames_dev;
+  int* frames_pinned = nullptr;
+  size_t frames_cap = 0;
+  hipEvent_t frames_copied = nullptr;
+  ~ws_frontend() {
+    if (frames_pinned) (void)hipHostFree(frames_pinned);
+    if (frames_copied) (void)hipEventDestroy(frames_copied);
+  }
 };
 
 struct ws_plda {
@@ -156,6 +165,47 @@ int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num
   WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, num_samples, wav_stride, scale,
                             window_type, T, feats, st));
   if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st));
+  return WS_OK;
+}
+
+int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, const int32_t* num_samples,
+                    int max_samples, int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
+                    ws_stream stream) {
+  if (!fe || !wav || !feats || !num_samples || batch < 0 ||
+      (wav_dtype != WS_WAV_INT16 && wav_dtype != WS_WAV_FLOAT32) ||
+      (window_type != WS_WINDOW_HAMMING && window_type != WS_WINDOW_POVEY) || wav_stride < max_samples) {
+    set_error("ws_fbank_ragged: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  const int T = ws_num_frames(max_samples, fe->sample_rate);
+  if (T == 0 || batch == 0) return WS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(hipSetDevice(fe->device));
+  if ((size_t)batch > fe->frames_cap) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));
+    if (fe->frames_pinned) (void)hipHostFree(fe->frames_pinned);
+    fe->frames_pinned = nullptr;
+    const size_t cap = (size_t)batch + batch / 2 + 64;
+    WS_HIP_CHECK(fe->frames_dev.alloc(cap * sizeof(int)));
+    WS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->frames_pinned), cap * sizeof(int), 0));
+    fe->frames_cap = cap;
+    if (!fe->frames_copied) WS_HIP_CHECK(hipEventCreateWithFlags(&fe->frames_copied, hipEventDisableTiming));
+  } else {
+    WS_HIP_CHECK(hipEventSynchronize(fe->frames_copied));
+  }
+  for (int b = 0; b < batch; ++b) {
+    if (num_samples[b] < 0 || num_samples[b] > max_samples) {
+      set_error("ws_fbank_ragged: utterance %d has %d samples, max_samples is %d", b, num_samples[b], max_samples);
+      return WS_ERR_INVALID_ARG;
+    }
+    fe->frames_pinned[b] = ws_num_frames(num_samples[b], fe->sample_rate);
+  }
+  WS_HIP_CHECK(hipMemcpyAsync(fe->frames_dev.ptr, fe->frames_pinned, (size_t)batch * sizeof(int),
+                              hipMemcpyHostToDevice, st));
+  WS_HIP_CHECK(hipEventRecord(fe->frames_copied, st));
+  WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, max_samples, wav_stride, scale, window_type, T,
+                            feats, st, fe->frames_dev.as<int>()));
+  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st, fe->frames_dev.as<int>()));
   return WS_OK;
 }
 
@@ -337,6 +387,68 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
     if (r) return r;
   }
   return WS_OK;
+}
+
+int ws_forward_ragged(ws_engine* eng, const float* feats, int batch, int max_frames, const int32_t* num_frames,
+                      float* emb, ws_stream stream) {
+  if (!eng || !feats || !emb || !num_frames || batch < 0 || max_frames <= 0) {
+    set_error("ws_forward_ragged: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_forward_ragged: engine not finalized"); return WS_ERR_STATE; }
+  if (batch == 0) return WS_OK;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  return eng->model->forward_ragged(feats, batch, max_frames, num_frames, emb, (hipStream_t)stream);
+}
+
+int ws_extract_ragged(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
+                      const int32_t* num_samples, int max_samples, int64_t wav_stride, float scale,
+                      int window_type, float* emb, ws_stream stream) {
+  if (!eng || !fe || !wav || !emb || !num_samples || batch < 0 || wav_stride < max_samples ||
+      (wav_dtype != WS_WAV_INT16 && wav_dtype != WS_WAV_FLOAT32) ||
+      (window_type != WS_WINDOW_HAMMING && window_type != WS_WINDOW_POVEY)) {
+    set_error("ws_extract_ragged: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_extract_ragged: engine not finalized"); return WS_ERR_STATE; }
+  if (fe->num_bins != eng->feat_dim) {
+    set_error("ws_extract_ragged: frontend has %d mel bins, model expects %d", fe->num_bins, eng->feat_dim);
+    return WS_ERR_SHAPE;
+  }
+  if (batch == 0) return WS_OK;
+  const int T = ws_num_frames(max_samples, fe->sample_rate);
+  if (T <= 0) { set_error("ws_extract_ragged: max_samples shorter than one frame"); return WS_ERR_INVALID_ARG; }
+  if (T > eng->model->max_frames()) {
+    set_error("ws_extract_ragged: %d frames exceed the finalized capacity %d", T, eng->model->max_frames());
+    return WS_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  std::vector<int32_t> frames(batch);
+  for (int b = 0; b < batch; ++b) {
+    if (num_samples[b] < 0 || num_samples[b] > max_samples) {
+      set_error("ws_extract_ragged: utterance %d has %d samples, max_samples is %d", b, num_samples[b], max_samples);
+      return WS_ERR_INVALID_ARG;
+    }
+    frames[b] = ws_num_frames(num_samples[b], fe->sample_rate);
+  }
+  // one table for the whole call: fbank / CMN read level 0, the model every level (upload_lens rejects an
+  // utterance shorter than the model's minimum)
+  const int* lens = eng->model->upload_lens(frames.data(), batch, T, st);
+  if (!lens) return WS_ERR_INVALID_ARG;
+  const int chunk = eng->model->max_batch();
+  const size_t esz = wav_dtype == WS_WAV_INT16 ? 2 : 4;
+  float* fw = eng->model->feats_workspace();
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+    const char* w = reinterpret_cast<const char*>(wav) + (size_t)b0 * wav_stride * esz;
+    WS_HIP_CHECK(launch_fbank(fe->tables, w, wav_dtype, nb, max_samples, wav_stride, scale, window_type, T, fw,
+                              st, lens + b0));
+    WS_HIP_CHECK(launch_cmn(fw, nb, T, fe->num_bins, st, lens + b0));
+    int r = eng->model->forward_chunk_ragged(fw, nb, T, lens, batch, b0, emb + (size_t)b0 * eng->embed_dim, st);
+    if (r) return r;
+  }
+  return eng->model->finish_forward(emb, batch, st);
 }
 
 int ws_resample(const float* x, int64_t n_in, const float* kernel, int orig, int new_rate, int width,

@@ -159,7 +159,14 @@ struct CamppModel : ModelBase {
     return 0;
   }
 
-  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
+  int min_frames() const override { return 3; }
+
+  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
+    // ragged chunk: lens at full resolution (FCM head) and after the stride-2 TDNN layer (trunk); every
+    // convolution stores zeros beyond them, the context masks / TSTP run over the valid frames
+    const bool rag = ragged();
+    const int* L0 = cur_lens[0];
+    const int* L1 = cur_lens[1];
     // ---------------- FCM head (2-D, stride only along frequency)
     // f16 back-end: the head's activation maps are binary16 only and its convolutions (and the TDNN
     // layer that consumes them) run on the LDS-DMA kernel in convolution form
@@ -167,7 +174,7 @@ struct CamppModel : ModelBase {
     int H = feat_dim;
     WS_LAUNCH(other(4.0 * B * H * (double)T * 33, st, [&] {
       return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, fa, st,
-                                 f16io ? reinterpret_cast<uint16_t*>(fa) : nullptr);
+                                 f16io ? reinterpret_cast<uint16_t*>(fa) : nullptr, L0);
     }));
     auto to16 = [&](ConvGemmParams& p, const float* in, float* out, const float* res) {
       if (!f16io) { if (res) { p.residual = res; p.ldr = 32; p.r_off = 0; } return; }
@@ -184,17 +191,20 @@ struct CamppModel : ModelBase {
       if (res[i].has_sc) {
         ConvGemmParams ps = conv2d(res[i].sc, x, 32, 0, t2, 32, 0, B, H, T, s, 1, 1, 1, 0, 0, ACT_NONE);
         to16(ps, x, t2, nullptr);
+        ps.row_len = L0;
         WS_LAUNCH(gemm(ps, st));
         r = t2;
       }
       ConvGemmParams p1 = conv2d(res[i].c1, x, 32, 0, t1, 32, 0, B, H, T, s, 1, 1, 1, 1, 1, ACT_RELU);
       to16(p1, x, t1, nullptr);
+      p1.row_len = L0;
       WS_LAUNCH(gemm(p1, st));
       // conv2 writes over the block input buffer when that is no longer needed (shortcut case),
       // otherwise into t2
       float* out = res[i].has_sc ? x : t2;
       ConvGemmParams p2 = conv2d(res[i].c2, t1, 32, 0, out, 32, 0, B, Ho, T, 1, 1, 1, 1, 1, 1, ACT_RELU);
       to16(p2, t1, out, r);
+      p2.row_len = L0;
       WS_LAUNCH(gemm(p2, st));
       if (!res[i].has_sc) { float* tmp = x; x = t2; t2 = tmp; }
       H = Ho;
@@ -202,6 +212,7 @@ struct CamppModel : ModelBase {
     {   // head.conv2: 3x3 stride (2,1) + BN + ReLU  -> [b][F'][T][32]
       ConvGemmParams ph = conv2d(head_conv2, x, 32, 0, t1, 32, 0, B, H, T, 2, 1, 1, 1, 1, 1, ACT_RELU);
       to16(ph, x, t1, nullptr);
+      ph.row_len = L0;
       WS_LAUNCH(gemm(ph, st));
       H = (H - 1) / 2 + 1;
     }
@@ -213,6 +224,7 @@ struct CamppModel : ModelBase {
     {
       ConvGemmParams pt0 = conv2d(tdnn, t1, 32, 0, X, ldx, 0, B, H, T, 1, 2, 1, 1, 0, 2, ACT_RELU);
       to16(pt0, t1, nullptr, nullptr);          // binary16 input, fp32 output (the dense blocks stay fp32)
+      pt0.row_len = L1;
       WS_LAUNCH(gemm(pt0, st));
     }
     const int segs = (Tp + 99) / 100;
@@ -225,12 +237,13 @@ struct CamppModel : ModelBase {
         p1.pre_scale = arena.at(L.pre_s); p1.pre_shift = arena.at(L.pre_b);
         // one context segment (T' <= 100) and >= 64 rows per utterance: the time mean of the
         // bottleneck output comes out of this GEMM's epilogue, the mask kernel never reads hbuf
-        const bool ctx_from_colsum = segs == 1 && Tp >= 64;
+        const bool ctx_from_colsum = segs == 1 && Tp >= 64 && !rag;
         if (ctx_from_colsum) p1.colsum = colsum;
         // f16 back-end: the bottleneck output feeds only the k3 conv (and the statistics above): keep it
         // as binary16 (hbuf reused), read by the conv DMA kernel
         const bool h_half = f16io && ctx_from_colsum;
         if (h_half) { p1.D = nullptr; p1.D16 = reinterpret_cast<uint16_t*>(hbuf); p1.ldd16 = 128; }
+        p1.row_len = L1;
         WS_LAUNCH(gemm(p1, st));
         // context mask m[b][seg][32]
         WS_LAUNCH(other(ctx_from_colsum ? 0.0 : 4.0 * B * (double)Tp * 128, st, [&] {
@@ -238,12 +251,13 @@ struct CamppModel : ModelBase {
             return launch_cam_context_from_colsum(colsum, B, Tp, 128, arena.at(L.cw1), arena.at(L.cb1), 64,
                                                   arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
           return launch_cam_context(hbuf, 128, B, Tp, 128, 100, arena.at(L.cw1), arena.at(L.cb1), 64,
-                                    arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
+                                    arena.at(L.cw2), arena.at(L.cb2), 32, mask, st, L1);
         }));
         // local k3 dilated conv 128 -> 32, times the mask, appended at channel offset cin
         ConvGemmParams p2 = conv1d(L.local, hbuf, 128, 0, X, ldx, L.cin, B, Tp, kDil[k], ACT_NONE);
         p2.seg_scale = mask; p2.seg_len = 100; p2.segs_per_img = segs;
         if (h_half) { p2.A16 = reinterpret_cast<const uint16_t*>(hbuf); p2.lda16 = 128; }
+        p2.row_len = L1;
         WS_LAUNCH(gemm(p2, st));
       }
       ch += 32 * kLayers[k];
@@ -251,6 +265,7 @@ struct CamppModel : ModelBase {
       const int ld_next = k < 2 ? ch / 2 + 32 * kLayers[k + 1] : ch / 2;
       ConvGemmParams pt = conv1d(transit[k].lin, X, ldx, 0, Xn, ld_next, 0, B, Tp, 1, ACT_NONE);
       pt.pre_scale = arena.at(transit[k].pre_s); pt.pre_shift = arena.at(transit[k].pre_b);
+      pt.row_len = L1;
       WS_LAUNCH(gemm(pt, st));
       float* tmp = X; X = Xn; Xn = tmp;
       ldx = ld_next;
@@ -258,25 +273,11 @@ struct CamppModel : ModelBase {
     }
     // out_nonlinear BN-ReLU fused into TSTP, then dense 1x1 + BN(affine=False)
     WS_LAUNCH(other(8.0 * B * (double)Tp * ch, st, [&] {
-      return launch_tstp(X, ldx, B, 1, Tp, ch, arena.at(out_s), arena.at(out_b), pooled, st);
+      return launch_tstp(X, ldx, B, 1, Tp, ch, arena.at(out_s), arena.at(out_b), pooled, st, L1);
     }));
     WS_LAUNCH(gemm_splitk(conv1d(dense, pooled, 2 * ch, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
                           partial, kSplitK, st));
     return 0;
-  }
-
-  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
-    if (frames > maxT || frames < 3) {
-      set_error("num_frames %d outside the finalized capacity [3, %d]", frames, maxT);
-      return WS_ERR_CAPACITY;
-    }
-    for (int b0 = 0; b0 < batch; b0 += maxB) {
-      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
-      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
-                            emb + (size_t)b0 * embed_dim, st);
-      if (r) return r;
-    }
-    return range_guard(emb, batch, st);
   }
 
   double flops(int batch, int T) const override {

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __r
                                                                 int F, const float* __restrict__ w,
                                                                 const float* __restrict__ bias,
                                                                 float* __restrict__ out,
-                                                                uint16_t* __restrict__ out16) {
+                                                                uint16_t* __restrict__ out16,
+                                                                const int* __restrict__ lens) {
   __shared__ float in_s[ST_FH + 2][ST_TW + 2 + 1];
   __shared__ __attribute__((aligned(16))) float w_s[32 * 12];     // [c][12]: 9 taps + bias + pad
   const int t0 = blockIdx.x * ST_TW, f0 = blockIdx.y * ST_FH, b = blockIdx.z;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __r
   if (t >= T || f >= F) return;
   const long long pix = ((long long)b * F + f) * T + t;
   typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
+  const bool padded = lens && t >= lens[b];     // ragged batch: columns beyond the utterance stay zero
 #pragma unroll
   for (int c0 = 0; c0 < 32; c0 += 8) {
     float r[8];
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __r
       sacc += wa[0] * in[0] + wa[1] * in[1] + wa[2] * in[2] + wa[3] * in[3];
       sacc += wb[0] * in[4] + wb[1] * in[5] + wb[2] * in[6] + wb[3] * in[7];
       sacc += wc[0] * in[8];
-      r[q] = fmaxf(sacc, 0.f);
+      r[q] = padded ? 0.f : fmaxf(sacc, 0.f);
     }
     if (OUT16) {
       f16x8c hv;
@@ -86,15 +88,15 @@ __global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __r
 
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
                                const float* b, int C, float* out, hipStream_t stream,
-                               uint16_t* out16) {
+                               uint16_t* out16, const int* lens) {
   if (C != 32 || B <= 0) return C != 32 ? hipErrorInvalidValue : hipSuccess;
   dim3 grid((T + ST_TW - 1) / ST_TW, (F + ST_FH - 1) / ST_FH, B);
   if (out16)
     hipLaunchKernelGGL(stem_conv3x3_tile_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
-                       out16);
+                       out16, lens);
   else
     hipLaunchKernelGGL(stem_conv3x3_tile_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
-                       out16);
+                       out16, lens);
   return hipGetLastError();
 }
 
@@ -110,20 +112,22 @@ template <typename TX>
 __global__ __launch_bounds__(256) void tstp_kernel(const TX* __restrict__ x, int ldx, int F, int T,
                                                    int C, const float* __restrict__ pre_scale,
                                                    const float* __restrict__ pre_shift,
-                                                   float* __restrict__ pooled) {
+                                                   float* __restrict__ pooled,
+                                                   const int* __restrict__ lens) {
   __shared__ float red[4][64];
   const int bf = blockIdx.x, b = bf / F, f = bf - b * F;
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const bool cok = c < C;
   const TX* base = x + (long long)bf * T * ldx + (cok ? c : 0);
+  if (lens) T = lens[b];                      // ragged batch: statistics over the valid columns only
   float ps = 1.f, pb = 0.f;
   const bool pre = pre_scale != nullptr;
   if (pre && cok) { ps = pre_scale[c]; pb = pre_shift[c]; }
   float s = 0.f;
   for (int t = grp; t < T; t += 4) {
     float v = load_act(base + (long long)t * ldx);
-    if (pre) v = fmaxf(v * ps + pb, 0.f);
+    if (pre) v = relu_f(v * ps + pb);
     s += v;
   }
   red[grp][cl] = s;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void tstp_kernel(const TX* __restrict__ x, int
   float q = 0.f;
   for (int t = grp; t < T; t += 4) {
     float v = load_act(base + (long long)t * ldx);
-    if (pre) v = fmaxf(v * ps + pb, 0.f);
+    if (pre) v = relu_f(v * ps + pb);
     const float d = v - mean;
     q += d * d;
   }
@@ -148,17 +152,17 @@ __global__ __launch_bounds__(256) void tstp_kernel(const TX* __restrict__ x, int
 }
 
 hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
-                       const float* pre_shift, float* pooled, hipStream_t stream) {
+                       const float* pre_shift, float* pooled, hipStream_t stream, const int* lens) {
   hipLaunchKernelGGL(tstp_kernel<float>, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x, ldx, F, T,
-                     C, pre_scale, pre_shift, pooled);
+                     C, pre_scale, pre_shift, pooled, lens);
   return hipGetLastError();
 }
 
 hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, int C,
                            const float* pre_scale, const float* pre_shift, float* pooled,
-                           hipStream_t stream) {
+                           hipStream_t stream, const int* lens) {
   hipLaunchKernelGGL(tstp_kernel<uint16_t>, dim3(B * F, (C + 63) / 64), dim3(256), 0, stream, x16, ldx, F,
-                     T, C, pre_scale, pre_shift, pooled);
+                     T, C, pre_scale, pre_shift, pooled, lens);
   return hipGetLastError();
 }
 
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
                                                           const float* __restrict__ b1, int hidden,
                                                           const float* __restrict__ w2,
                                                           const float* __restrict__ b2, int Cout,
-                                                          float* __restrict__ mask) {
+                                                          float* __restrict__ mask,
+                                                          const int* __restrict__ lens) {
   extern __shared__ float sm[];
   float* segsum = sm;                       // [groups][segs][C]
   const int groups = 256 / C;
@@ -181,6 +186,9 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c = tid % C, grp = tid / C;
   const float* base = h + (long long)b * T * ldh + c;
+  // ragged batch: this utterance has lens[b] <= T frames, i.e. ceil(lens[b] / seg_len) segments of its
+  // own (avg_pool1d with ceil_mode on ITS length); the mask rows of the segments beyond are zeroed
+  if (lens) T = lens[b];
   if (grp < groups) {
     for (int s = 0; s < segs; ++s) {
       const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
@@ -207,6 +215,10 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
   const int lane = tid & 63, wave = tid >> 6;
   for (int s = 0; s < segs; ++s) {
     const int t0 = s * seg_len, t1 = min(T, t0 + seg_len);
+    if (t1 <= t0) {                                    // (uniform) segment beyond this utterance
+      if (tid < Cout) mask[((long long)b * segs + s) * Cout + tid] = 0.f;
+      continue;
+    }
     if (tid < C) {
       float tot = 0.f;
       for (int k = 0; k < segs; ++k) tot += segsum[k * C + tid];
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
       float v = 0.f;
       for (int k = lane; k < C; k += 64) v += wr[k] * ctx[k];
       v = wave_sum32(v);
-      if (lane == 0) hid[j] = fmaxf(v + b1[j], 0.f);
+      if (lane == 0) hid[j] = relu_f(v + b1[j]);
     }
     __syncthreads();
     if (tid < Cout) {                                  // m = sigmoid(W2 hid + b2)
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(128) void cam_context_from_colsum_kernel(
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k);
       v += w4[0] * ctx[k] + w4[1] * ctx[k + 1] + w4[2] * ctx[k + 2] + w4[3] * ctx[k + 3];
     }
-    hid[tid] = fmaxf(v, 0.f);
+    hid[tid] = relu_f(v);
   }
   __syncthreads();
   if (tid < Cout) {                              // m = sigmoid(W2 hid + b2)
@@ -284,14 +296,14 @@ hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int
 
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
                               const float* w1, const float* b1, int hidden, const float* w2,
-                              const float* b2, int Cout, float* mask, hipStream_t stream) {
+                              const float* b2, int Cout, float* mask, hipStream_t stream, const int* lens) {
   if (C > 256 || 256 % C != 0 || hidden > 128 || Cout > 64) return hipErrorInvalidValue;
   const int segs = (T + seg_len - 1) / seg_len;
   const int groups = 256 / C;
   const size_t lds = ((size_t)groups * segs * C + C + hidden) * sizeof(float);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(cam_context_kernel, dim3(B), dim3(256), lds, stream, h, ldh, T, C, seg_len, segs,
-                     w1, b1, hidden, w2, b2, Cout, mask);
+                     w1, b1, hidden, w2, b2, Cout, mask, lens);
   return hipGetLastError();
 }
 

@@ -183,6 +183,18 @@ struct Model {
   virtual int reserve(int max_batch, int max_frames) = 0;
   virtual int forward(const float* feats, int batch, int frames, float* emb,
                       hipStream_t stream) = 0;
+  // Ragged batch: utterance b has lens_host[b] <= frames valid rows (HOST array); the rows beyond are
+  // padding (their content is ignored).
+  virtual int forward_ragged(const float* feats, int batch, int frames, const int32_t* lens_host,
+                             float* emb, hipStream_t stream) = 0;
+  // Building blocks of the fused ragged extract (c_api.hip: fbank -> CMN -> forward per chunk):
+  // upload_lens validates and copies the table, returns its device address (level-major, `batch` entries
+  // per time-stride level; level 0 first) or null; forward_chunk_ragged runs rows [b0, b0 + nb) whose
+  // padding rows are already zero; finish_forward closes the call (range guard).
+  virtual const int* upload_lens(const int32_t* lens_host, int batch, int frames, hipStream_t stream) = 0;
+  virtual int forward_chunk_ragged(const float* feats, int nb, int frames, const int* lens_dev, int batch,
+                                   int b0, float* emb, hipStream_t stream) = 0;
+  virtual int finish_forward(const float* emb, int batch, hipStream_t stream) = 0;
   virtual double flops(int batch, int frames) const = 0;
   // non-finite embedding values produced by the binary16 back-ends since the last call (reads and
   // clears the host-mapped counter; the caller has synchronised the stream)

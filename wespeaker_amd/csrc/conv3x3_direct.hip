@@ -168,7 +168,7 @@ __global__ __launch_bounds__(C == 32 ? 256 : 512, 2) void conv3x3_direct_f16_ker
       for (int c = 0; c < 8; ++c) {
         float a = v[c], b = v[8 + c];
         if constexpr (C == 32) { a += bias[c]; b += bias[8 + c]; }
-        if (p.act == ACT_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+        if (p.act == ACT_RELU) { a = relu_f(a); b = relu_f(b); }
         o0[c] = (_Float16)a; o1[c] = (_Float16)b;
       }
       *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + ch0) = o0;

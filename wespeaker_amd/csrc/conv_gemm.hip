@@ -272,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         // rows >= rb (relative to this 64-row half) belong to the next image; HW >= 64 on the host
         const int mh = m0 + hf * 64;
         const int rb = (mh / HW + 1) * HW - mh;
-        const bool rowops = ROWOPS_ && (p.bias_img || p.residual || p.residual16 || p.seg_scale);
+        const bool rowops = ROWOPS_ && (p.bias_img || p.residual || p.residual16 || p.seg_scale || p.row_len);
         if (!rowops) {
           // plain layer: row by row, nothing to wait for
 #pragma unroll 4
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
             f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * ES + c4 * 4]) + bias;
             if (p.act == ACT_RELU) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              for (int q = 0; q < 4; ++q) v[q] = relu_f(v[q]);
             } else if (p.act == ACT_TANH) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
@@ -307,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
         constexpr int RPT = 64 / RPP, G = RPT < GMAX ? RPT : GMAX;
 #pragma unroll
         for (int g0 = 0; g0 < RPT; g0 += G) {
-          int mrow[G];
+          int mrow[G], rlen[G];
           f32x4 bi[G], r32[G], ss[G], vv[G];
           f16x4 r16[G];
 #pragma unroll
@@ -329,6 +329,10 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
 #pragma unroll
             for (int g = 0; g < G; ++g)
               r16[g] = *reinterpret_cast<const f16x4*>(p.residual16 + (long long)mrow[g] * p.ldr + p.r_off + n);
+          }
+          if (ROWOPS && p.row_len) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) rlen[g] = p.row_len[mrow[g] / HW];
           }
           if (ROWOPS && p.seg_scale) {
 #pragma unroll
@@ -355,13 +359,19 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
             }
             if (p.act == ACT_RELU) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              for (int q = 0; q < 4; ++q) v[q] = relu_f(v[q]);
             } else if (p.act == ACT_TANH) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
             }
             if (p.post_scale) v = v * ps + pb;
             if (ROWOPS && p.seg_scale) v *= ss[g];
+            if (ROWOPS && p.row_len) {
+              // ragged batch: pixels beyond the utterance's own width are padding -> stored as zeros, so
+              // that every later convolution tap and reduction sees the zero padding of a batch-1 run
+              const int img = m / HW;
+              if ((m - img * HW) % p.Wout >= rlen[g]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             if (p.colsum) {
               if (rl < rb) cs[hf][0] += v; else cs[hf][1] += v;
             }
@@ -596,7 +606,7 @@ void conv_gemm_kernel(const ConvGemmParams p) {
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.pre_shift + cc);
         f32x4 v = ra[i] * s4 + t4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ok ? fmaxf(v[q], 0.f) : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = ok ? relu_f(v[q]) : 0.f;
         ra[i] = v;
       }
     }
@@ -1228,7 +1238,7 @@ __device__ __forceinline__ void p8_epilogue_f16(const ConvGemmParams& p, f32x16 
                           acc[im][in][4 * g + 3]} + bias;
         if (p.act == ACT_RELU) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          for (int q = 0; q < 4; ++q) v[q] = relu_f(v[q]);
         }
         if (p.post_scale) v = v * ps + pb;
         f16x4 hv;
@@ -1620,7 +1630,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     int& bigc = g_ws_big_conv;
     if (bigc < 0) { const char* ev = getenv("WS_BIG_CONV"); bigc = ev ? atoi(ev) : 1; }
     if (bigc && p.N % 256 == 0 && p.Cin % 64 == 0 && p.K % 64 == 0 && !p.bias_img && !p.residual &&
-        !p.seg_scale && !p.colsum && !p.D2) {
+        !p.seg_scale && !p.colsum && !p.D2 && !p.row_len) {
       const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
       const long long rounds = tiles_m * tiles_n / cus;
       if (rounds >= 1) {
@@ -1661,7 +1671,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
   if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 3; }
   if (use_dma && big && p.N % 256 == 0 && p.N >= (big >= 3 ? 512 : 1024) && !p.pool_partial && !p.bias_img &&
-      !p.residual && !p.residual16 && !p.seg_scale) {
+      !p.residual && !p.residual16 && !p.seg_scale && !p.row_len) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
     const long long rounds = tiles_m * tiles_n / cus;
     if (rounds >= 1) {
@@ -1739,6 +1749,9 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.colsum && (p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
   if (p.pool_partial && (p.splitk > 1 || p.Hout * p.Wout < 64 || (!p.pool_h && !p.pool_h16) || (p.ldh & 3)))
     return hipErrorInvalidValue;
+  // ragged batches: the row mask lives in the general row-operand epilogue; the fused statistics
+  // (column sums, pooling partials) and split-K are not combined with it
+  if (p.row_len && (p.splitk > 1 || p.colsum || p.pool_partial)) return hipErrorInvalidValue;
   if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.prec == 1) {
     if (!p.Wh || !p.Wl) return hipErrorInvalidValue;
@@ -1748,7 +1761,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     if (!p.Wh) return hipErrorInvalidValue;
     static int direct = -1;
     if (direct < 0) { const char* ev = getenv("WS_DIRECT3X3"); direct = ev ? atoi(ev) : 1; }
-    if (direct && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
+    if (direct && !p.row_len && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
     return launch_prec<2>(p, stream);
   }
   return launch_prec<0>(p, stream);
@@ -1764,7 +1777,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
   if (p.bias) v += p.bias[n];
   if (p.bias_img) v += p.bias_img[(long long)(m / (p.Hout * p.Wout)) * p.N + n];
   if (p.residual) v += p.residual[(long long)m * p.ldr + p.r_off + n];
-  if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+  if (p.act == ACT_RELU) v = relu_f(v);
   else if (p.act == ACT_TANH) v = tanhf(v);
   if (p.post_scale) v = v * p.post_scale[n] + p.post_shift[n];
   p.D[(long long)m * p.ldd + p.d_off + n] = v;

@@ -126,14 +126,22 @@ struct EcapaModel : ModelBase {
     return 0;
   }
 
-  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
+  int min_frames() const override { return 1; }
+
+  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
+    // Ragged chunk (cur_lens set): utterance b owns rows [0, lens[b]) of its T-row slot.  Every conv/linear
+    // launch stores zeros in the padding rows (ConvGemmParams::row_len), the fused Res2 chain and the
+    // statistics kernels run over lens[b] rows, and the statistics that the uniform path folds into GEMM
+    // epilogues (SE column sums, context statistics, softmax-pooling partials) use their stand-alone forms.
+    const bool rag = ragged();
+    const int* L0 = cur_lens[0];
     // layer1: Conv1d(F -> C, k5, p2) -> ReLU -> BN
     // f16 back-end: the layers that feed 1x1 GEMMs also leave a binary16 copy of their output, which
     // those GEMMs read instead of the fp32 tensor (half the bytes, no conversion while staging)
     const bool f16io = gemm_precision == 2;
     // ... and with T >= 64 (SE statistics from the epilogue) the block chain out1 -> y3 -> cat lives in
     // binary16 only: the residual stream is rounded once per block like in any fp16 inference engine
-    const bool allf16 = f16io && T >= 64;
+    const bool allf16 = f16io && T >= 64 && !rag;
     {
       ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
       if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
@@ -147,6 +155,7 @@ struct EcapaModel : ModelBase {
         p0.A16 = col16; p0.lda16 = layer1.ldw; p0.lda = layer1.ldw;
         p0.K = layer1.ldw; p0.Cin = layer1.ldw; p0.kw = 1; p0.pad_w = 0; p0.dil_w = 1;
       }
+      p0.row_len = L0;
       WS_LAUNCH(gemm(p0, st));
     }
     for (int L = 0; L < 3; ++L) {
@@ -161,6 +170,7 @@ struct EcapaModel : ModelBase {
       const bool y2_half = f16io && res2_half_out_supported(w, T, d);
       if (f16io) { p.A16 = L == 0 ? out1_16 : cat16; p.lda16 = ldx; }
       if (y2_half) { p.D2_16 = y2_16; p.ldd2_16 = C; }
+      p.row_len = L0;
       WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
       if (res2_chain_supported(w, T, d)) {       // one launch, running activation kept in LDS
@@ -172,7 +182,7 @@ struct EcapaModel : ModelBase {
           r.wl[i] = reinterpret_cast<const uint16_t*>(arena.at(res2[L][i].wl));
           r.scale[i] = arena.at(res2[L][i].scale); r.shift[i] = arena.at(res2[L][i].shift);
         }
-        r.B = B; r.T = T; r.W = w; r.dil = d; r.prec = gemm_precision;
+        r.B = B; r.T = T; r.W = w; r.dil = d; r.prec = gemm_precision; r.lens = L0;
         r.y2h = y2_half ? y2_16 : nullptr; r.ldy2h = C;
         if (prof.enabled) prof.begin(1, 2.0 * B * (double)T * w * 3 * w * 7, 4.0 * B * (double)T * C * 2, st);
         hipError_t re = launch_res2_chain(r, st);
@@ -182,6 +192,7 @@ struct EcapaModel : ModelBase {
         for (int i = 0; i < 7; ++i) {
           ConvGemmParams q = conv1d(res2[L][i], y1, C, i * w, y2, C, i * w, B, T, d, ACT_RELU);
           if (i >= 1) { q.A2 = y2; q.lda2 = C; q.a2_off = (i - 1) * w; }
+          q.row_len = L0;
           WS_LAUNCH(gemm(q, st));
         }
       }
@@ -189,7 +200,8 @@ struct EcapaModel : ModelBase {
       ConvGemmParams p3 = conv1d(blk2[L], y2, C, 0, y3, C, 0, B, T, 1, ACT_RELU);
       if (y2_half) { p3.A16 = y2_16; p3.lda16 = C; }
       if (allf16) { p3.D = nullptr; p3.D16 = y3_16; p3.ldd16 = C; }
-      if (T >= 64) {
+      p3.row_len = L0;
+      if (T >= 64 && !rag) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;
         WS_LAUNCH(gemm(p3, st));
@@ -201,7 +213,7 @@ struct EcapaModel : ModelBase {
         WS_LAUNCH(gemm(p3, st));
         WS_LAUNCH(other(mc, st, [&] {
           return launch_se_pool_fc(y3, C, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                   arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
+                                   arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st, L0);
         }));
       }
       WS_LAUNCH(other(allf16 ? 1.5 * mc : 3 * mc, st, [&] {
@@ -214,7 +226,7 @@ struct EcapaModel : ModelBase {
     }
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
     // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
-    const bool stats_from_colsum = glob && T >= 64;
+    const bool stats_from_colsum = glob && T >= 64 && !rag;
     static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
     const bool h_half = allf16 && !no_fuse;
     {
@@ -222,6 +234,7 @@ struct EcapaModel : ModelBase {
       if (stats_from_colsum) pc.colsum = colsum;
       if (f16io) { pc.A16 = cat16; pc.lda16 = 3 * C; pc.D16 = h16; pc.ldd16 = 1536; }
       if (h_half) pc.D = nullptr;              // h exists as binary16 only
+      pc.row_len = L0;
       WS_LAUNCH(gemm(pc, st));
     }
     // ASTP
@@ -234,7 +247,7 @@ struct EcapaModel : ModelBase {
         if (stats_from_colsum && h_half)
           return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st);
         if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st);
-        return launch_astp_stats(h, 1536, B, T, 1536, stats, st);
+        return launch_astp_stats(h, 1536, B, T, 1536, stats, st, L0);
       }));
       ConvGemmParams cb = conv1d(pool1, stats, 3072, 0, bias_img, 128, 0, B, 1, 1, ACT_NONE);
       cb.W = arena.at(pool1.w) + 1536; cb.Wh += 1536; cb.Wl += 1536; cb.K = 3072; cb.Cin = 3072;
@@ -242,8 +255,9 @@ struct EcapaModel : ModelBase {
       a1.bias = nullptr;
       a1.bias_img = bias_img;
     }
+    a1.row_len = L0;
     WS_LAUNCH(gemm(a1, st));
-    if (T >= 64 && !no_fuse) {
+    if (T >= 64 && !no_fuse && !rag) {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
       ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
       l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer
@@ -256,27 +270,13 @@ struct EcapaModel : ModelBase {
     } else {
       WS_LAUNCH(gemm(conv1d(pool2, att, 128, 0, e, 1536, 0, B, T, 1, ACT_NONE), st));
       WS_LAUNCH(other(8.0 * B * (double)T * 1536, st, [&] {
-        return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st);
+        return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st, L0);
       }));
     }
     // BN + Linear (+bn2), folded: split-K GEMM over K = 3072
     WS_LAUNCH(gemm_splitk(conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
                           partial, kSplitK, st));
     return 0;
-  }
-
-  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
-    if (frames > maxT || frames < 1) {
-      set_error("num_frames %d outside the finalized capacity [1, %d]", frames, maxT);
-      return WS_ERR_CAPACITY;
-    }
-    for (int b0 = 0; b0 < batch; b0 += maxB) {
-      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
-      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
-                            emb + (size_t)b0 * embed_dim, st);
-      if (r) return r;
-    }
-    return range_guard(emb, batch, st);
   }
 
   double flops(int batch, int T) const override {

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const float* __restrict
                                                          const float* __restrict__ b1,
                                                          const float* __restrict__ w2,
                                                          const float* __restrict__ b2, int bott,
-                                                         float* __restrict__ s) {
+                                                         float* __restrict__ s,
+                                                         const int* __restrict__ lens) {
   __shared__ __attribute__((aligned(16))) float sm[1024 * 4 + 256];
   float* part = sm;             // [groups][C]
   float* hidden = sm + 1024 * 4;  // [bott]
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const float* __restrict
   const int groups = 256 / cols4;           // time groups (>=1)
   const int col = tid % cols4, grp = tid / cols4;
   const float* base = y + (long long)b * T * ldy + col * 4;
+  if (lens) T = lens[b];                    // ragged batch: mean over the utterance's own frames
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
   if (grp < groups) {
     int t = grp;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const float* __restrict
     float v = 0.f;
     for (int c = lane; c < C; c += 64) v += wr[c] * part[c];
     v = wave_sum(v);
-    if (lane == 0) hidden[j] = fmaxf(v + b1[j], 0.f);
+    if (lane == 0) hidden[j] = relu_f(v + b1[j]);
   }
   __syncthreads();
   // s = sigmoid(W2 hidden + b2): thread per output channel (rows of W2 are short: bott floats)
@@ -83,11 +85,11 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const float* __restrict
 
 hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
                              const float* b1, const float* w2, const float* b2, int bottleneck,
-                             float* s, hipStream_t stream) {
+                             float* s, hipStream_t stream, const int* lens) {
   if (C > 1024 || (C & 3) || bottleneck > 256 || (bottleneck & 3) || 256 % (C >> 2) != 0)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(se_pool_fc_kernel, dim3(B), dim3(256), 0, stream, y, ldy, T, C, w1, b1, w2,
-                     b2, bottleneck, s);
+                     b2, bottleneck, s, lens);
   return hipGetLastError();
 }
 
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float t = wave_sum(v[q]);
-      if (lane == 0) hidden[j0 + q] = fmaxf(t + bias1[q], 0.f);
+      if (lane == 0) hidden[j0 + q] = relu_f(t + bias1[q]);
     }
   }
   __syncthreads();
@@ -256,11 +258,13 @@ hipError_t launch_se_scale_residual_f16(const uint16_t* x16, int ldx, int x_off,
 // grid = (B, C/256), block = 256: thread = 1 channel... channel-parallel, two passes over T
 // (mean, then centred sum of squares: same two-pass form torch.var uses, no E[x^2]-m^2 cancellation).
 __global__ __launch_bounds__(256) void astp_stats_kernel(const float* __restrict__ h, int ldh, int T,
-                                                         int C, float* __restrict__ stats) {
+                                                         int C, float* __restrict__ stats,
+                                                         const int* __restrict__ lens) {
   const int b = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const float* base = h + (long long)b * T * ldh + c;
+  if (lens) T = lens[b];
   float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   int t = 0;
   for (; t + 3 < T; t += 4) {
@@ -384,17 +388,18 @@ hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, 
 }
 
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
-                             hipStream_t stream) {
+                             hipStream_t stream, const int* lens) {
   hipLaunchKernelGGL(astp_stats_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, h, ldh, T,
-                     C, stats);
+                     C, stats, lens);
   return hipGetLastError();
 }
 
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
                                     int ldw1, const float* b1, int bottleneck, float* stats,
                                     float* bias_img, hipStream_t stream) {
+  const int* lens = nullptr;
   hipLaunchKernelGGL(astp_stats_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, h, ldh, T,
-                     C, stats);
+                     C, stats, lens);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(astp_context_bias_kernel, dim3(B), dim3(256), 0, stream, stats, 2 * C, w1,
@@ -408,12 +413,14 @@ hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C
 // grid = (B, C/256), block = 256 (thread = channel; lanes contiguous in c -> coalesced rows).
 __global__ __launch_bounds__(256) void astp_pool_kernel(const float* __restrict__ e, int lde,
                                                         const float* __restrict__ h, int ldh,
-                                                        int T, int C, float* __restrict__ pooled) {
+                                                        int T, int C, float* __restrict__ pooled,
+                                                        const int* __restrict__ lens) {
   const int b = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const float* ep = e + (long long)b * T * lde + c;
   const float* hp = h + (long long)b * T * ldh + c;
+  if (lens) T = lens[b];                    // softmax over the utterance's own frames only
   // pass 1: max (keeps exp arguments <= 0 exactly like torch.softmax's max-subtraction)
   float mx = -INFINITY;
   int t = 0;
@@ -484,9 +491,9 @@ hipError_t launch_astp_pool_from_partials(const float* partials, int B, int T, i
 }
 
 hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
-                            float* pooled, hipStream_t stream) {
+                            float* pooled, hipStream_t stream, const int* lens) {
   hipLaunchKernelGGL(astp_pool_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, e, lde, h,
-                     ldh, T, C, pooled);
+                     ldh, T, C, pooled, lens);
   return hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
     const FbankTables tb, const void* __restrict__ wav, int wav_dtype, int N, long long wav_stride,
     float scale, const float* __restrict__ window, int T, long long total_frames,
-    float* __restrict__ feats) {
+    float* __restrict__ feats, const int* __restrict__ frames) {
   __shared__ __attribute__((aligned(16))) float2 bufA[FRAMES_PER_BLOCK][CN];
   __shared__ __attribute__((aligned(16))) float2 bufB[FRAMES_PER_BLOCK][CN + 4];
   // mel filter table staged once per workgroup (4 frames share it): the per-tap weight reads of
@@ -60,6 +60,14 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
   const bool live = frame < total_frames;
   if (!live) frame = total_frames - 1;          // keep control flow uniform for the barriers
   const int b = (int)(frame / T), f = (int)(frame - (long long)b * T);
+  // ragged batch: utterance b has frames[b] <= T frames; the rows beyond are written as zeros (they are
+  // the zero padding the first convolution sees).  Only wave-level synchronisation follows, so the whole
+  // wavefront may leave here.
+  if (frames && f >= frames[b]) {
+    if (live)
+      for (int i = lane; i < tb.num_bins; i += 64) feats[frame * tb.num_bins + i] = 0.f;
+    return;
+  }
   const long long s0 = (long long)b * wav_stride + (long long)f * tb.frame_shift;
   const int L = tb.frame_len;                   // 400
 
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
 
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
-                        hipStream_t stream) {
+                        hipStream_t stream, const int* frames) {
   if (T <= 0 || B <= 0) return hipSuccess;
   if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128)
     return hipErrorInvalidValue;
@@ -163,17 +171,19 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
   const unsigned blocks = (unsigned)((total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
   const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
   hipLaunchKernelGGL(fbank_kernel, dim3(blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
-                     wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats);
+                     wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ CMN
 // feats[b, t, :] -= mean_t feats[b, :, :]   (cli/speaker.py:98-99).  grid = B, block = 256.
-__global__ __launch_bounds__(256) void cmn_kernel(float* __restrict__ feats, int T, int F) {
+__global__ __launch_bounds__(256) void cmn_kernel(float* __restrict__ feats, int T, int F,
+                                                  const int* __restrict__ lens) {
   extern __shared__ float sm[];      // [groups][F]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int groups = 256 / F > 0 ? 256 / F : 1;
   float* base = feats + (long long)b * T * F;
+  if (lens) T = lens[b];             // ragged batch: mean over (and subtracted from) the valid frames only
   const int col = tid % F, grp = tid / F;
   if (grp < groups) {
     float s0 = 0.f, s1 = 0.f;
@@ -196,11 +206,38 @@ __global__ __launch_bounds__(256) void cmn_kernel(float* __restrict__ feats, int
   for (long long i = tid; i < total; i += 256) base[i] -= sm[(int)(i % F)];
 }
 
-hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream) {
+hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens) {
   if (F > 256) return hipErrorInvalidValue;
   const int groups = 256 / F;
   hipLaunchKernelGGL(cmn_kernel, dim3(B), dim3(256), (size_t)groups * F * sizeof(float), stream,
-                     feats, T, F);
+                     feats, T, F, lens);
+  return hipGetLastError();
+}
+
+// dst[b][t][:] = t < lens[b] ? src[b][t][:] : 0   (ragged batch: canonical zero padding of the features)
+__global__ __launch_bounds__(256) void copy_rows_masked_kernel(const float* __restrict__ src,
+                                                               float* __restrict__ dst, int T, int F4,
+                                                               const int* __restrict__ lens,
+                                                               long long total4) {
+  typedef float f32x4e __attribute__((ext_vector_type(4)));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long row = i / F4;
+    const int b = (int)(row / T), t = (int)(row - (long long)b * T);
+    f32x4e v = {0.f, 0.f, 0.f, 0.f};
+    if (t < lens[b]) v = reinterpret_cast<const f32x4e*>(src)[i];
+    reinterpret_cast<f32x4e*>(dst)[i] = v;
+  }
+}
+
+hipError_t launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens,
+                                   hipStream_t stream) {
+  if (F & 3) return hipErrorInvalidValue;
+  const long long total4 = (long long)B * T * (F / 4);
+  if (total4 <= 0) return hipSuccess;
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, T,
+                     F / 4, lens, total4);
   return hipGetLastError();
 }
 

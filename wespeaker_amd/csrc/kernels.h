@@ -9,6 +9,13 @@ namespace wsamd {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
+// ReLU with torch.relu's treatment of non-finite values: NaN stays NaN, +inf stays +inf (bit-identical
+// to fmaxf(v, 0) on finite input).  fmaxf returns the non-NaN operand, i.e. it would turn the NaN that a
+// binary16 overflow upstream produces (inf - inf, inf * 0) back into an innocent 0 and let the damage
+// reach the embedding as a finite wrong number; with this form it arrives as NaN and
+// ws_engine_check_range reports it.
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
 // Implicit-GEMM convolution / linear layer on channels-last activations:
 //   D[m][n] = epilogue( sum_{tap, ci} A[pix(m, tap)][a_off + ci] * W[n][tap*Cin + ci] )
 // m enumerates output pixels (img, oy, ox) row-major; pix() applies stride/dilation/zero padding.
@@ -41,6 +48,8 @@ struct ConvGemmParams {
   const uint16_t* residual16;                 // binary16 form of the residual (same ldr / r_off)
   int act;
   const float* post_scale; const float* post_shift;   // y = act(.)*scale[n] + shift[n] (BN after ReLU)
+  const int* row_len;                         // optional [num_images] (ragged batch): output pixels with
+                                              // ox >= row_len[img] are padding -- stored as zeros
   const float* seg_scale; int seg_len; int segs_per_img;  // optional y *= seg_scale[(img*segs + ox/seg_len)][n]
                                               // (CAM++ context mask, campplus.py:110-115)
   float* colsum;                              // optional [ceil(M/64)][2][N]: column sums of the stored
@@ -75,6 +84,8 @@ struct Res2ChainParams {
   const float* bias[7]; const float* scale[7]; const float* shift[7];
   int B, T, W, dil;
   int prec;                                 // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
+  const int* lens;                          // optional [B]: valid frames per utterance (<= T); rows beyond
+                                            // are padding (ragged batch)
 };
 bool res2_chain_supported(int W, int T, int dil);
 bool res2_half_out_supported(int W, int T, int dil);   // Res2ChainParams::y2h allowed
@@ -88,7 +99,7 @@ hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, co
 // SE_Connect (ecapa_tdnn.py:120-126): s[b][c] = sigmoid(W2 relu(W1 mean_t(y[b,t,:]) + b1) + b2)
 hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
                              const float* b1, const float* w2, const float* b2, int bottleneck,
-                             float* s, hipStream_t stream);
+                             float* s, hipStream_t stream, const int* lens = nullptr);
 // out[m][o_off + c] = x[m][x_off + c] + y[m][c] * s[b][c]      (SE scale + residual)
 // all-binary16 form (f16 back-end): out16 = x16 + y16 * s, 8 halfs per thread
 hipError_t launch_se_scale_residual_f16(const uint16_t* x16, int ldx, int x_off, const uint16_t* y16,
@@ -104,7 +115,7 @@ hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, in
 hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
                                            const float* colsum, float* stats, hipStream_t stream);
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
-                             hipStream_t stream);
+                             hipStream_t stream, const int* lens = nullptr);
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
                                     int ldw1, const float* b1, int bottleneck, float* stats,
                                     float* bias_img, hipStream_t stream);
@@ -115,21 +126,21 @@ hipError_t launch_astp_pool_from_partials(const float* partials, int B, int T, i
 // ASTP pooling (pooling_layers.py:138-144): softmax over T of logits e, weighted mean / std of h
 // -> pooled[b] = [mean(C) | std(C)]
 hipError_t launch_astp_pool(const float* e, int lde, const float* h, int ldh, int B, int T, int C,
-                            float* pooled, hipStream_t stream);
+                            float* pooled, hipStream_t stream, const int* lens = nullptr);
 
 // ResNet / FCM stem: Conv2d(1 -> C, 3x3, pad 1, no bias) + folded BN + ReLU, reading the (B, T, F)
 // feature tensor as the (F x T) image and writing channels-last [B][F][T][C].  w: [C][9], b: [C].
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
                                const float* b, int C, float* out, hipStream_t stream,
-                               uint16_t* out16 = nullptr);
+                               uint16_t* out16 = nullptr, const int* lens = nullptr);
 // TSTP (pooling_layers.py:78-85) over channels-last x[(b*F + f)*T + t][c]: mean and
 // sqrt(unbiased var + 1e-7) over t; optional pre-activation relu(x*pre_scale[c] + pre_shift[c])
 // (CAM++ out_nonlinear).  pooled[b][c*F + f] = mean, pooled[b][C*F + c*F + f] = std.
 hipError_t launch_tstp(const float* x, int ldx, int B, int F, int T, int C, const float* pre_scale,
-                       const float* pre_shift, float* pooled, hipStream_t stream);
+                       const float* pre_shift, float* pooled, hipStream_t stream, const int* lens = nullptr);
 hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, int C,
                            const float* pre_scale, const float* pre_shift, float* pooled,
-                           hipStream_t stream);
+                           hipStream_t stream, const int* lens = nullptr);
 // CAM++ context (campplus.py:108-135): ctx = mean_T(h) + segmean_100(h); m = sigmoid(W2 relu(W1 ctx + b1) + b2)
 // h: [B*T][C] (C = 128); mask out: [B][segs][Cout]
 hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
@@ -137,7 +148,8 @@ hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int
                                           int Cout, float* mask, hipStream_t stream);
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
                               const float* w1, const float* b1, int hidden, const float* w2,
-                              const float* b2, int Cout, float* mask, hipStream_t stream);
+                              const float* b2, int Cout, float* mask, hipStream_t stream,
+                              const int* lens = nullptr);
 
 // ---- frontend
 struct FbankTables {
@@ -153,8 +165,12 @@ struct FbankTables {
 };
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
-                        hipStream_t stream);
-hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream);
+                        hipStream_t stream, const int* frames = nullptr);
+// lens (optional, [B]): valid frames per utterance of a ragged batch -- fbank writes zero rows beyond
+// them, CMN averages over / subtracts from the valid rows only
+hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr);
+hipError_t launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens,
+                                   hipStream_t stream);
 hipError_t launch_resample(const float* x, long long n_in, const float* kern, int orig, int nw, int width,
                            float* y, long long n_out, hipStream_t stream);
 // binary16 im2col of a k-tap "same" Conv1d over time: out[(b,t)][tap*F + f] = feats[b][t + tap - pad][f]

@@ -54,6 +54,8 @@ struct ModelBase : Model {
   int* nonfinite_dev = nullptr;
   ~ModelBase() override {
     if (nonfinite_host) (void)hipHostFree(nonfinite_host);
+    if (lens_pinned) (void)hipHostFree(lens_pinned);
+    if (lens_copied) (void)hipEventDestroy(lens_copied);
   }
   int range_guard(const float* emb, int batch, hipStream_t st) {
     if (gemm_precision == 0 || !nonfinite_dev) return 0;
@@ -65,6 +67,103 @@ struct ModelBase : Model {
     const int n = *reinterpret_cast<volatile int*>(nonfinite_host);
     *reinterpret_cast<volatile int*>(nonfinite_host) = 0;
     return n;
+  }
+  // ---- ragged batches: per-utterance valid lengths at the four time-stride levels of the 2-D models
+  // (level l+1 = (level l - 1) / 2 + 1, the output width of a k3/p1/s2 -- or k1/s2, k5/p2/s2 -- conv)
+  enum { kLenLevels = 4 };
+  const int* cur_lens[kLenLevels] = {nullptr, nullptr, nullptr, nullptr};   // of the chunk in flight
+  DevBuf lens_dev;                 // [kLenLevels][lens_cap] int32
+  int* lens_pinned = nullptr;      // host staging of the same
+  size_t lens_cap = 0;
+  hipEvent_t lens_copied = nullptr;
+  bool ragged() const { return cur_lens[0] != nullptr; }
+
+  virtual int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) = 0;
+  virtual int min_frames() const = 0;
+
+  const int* upload_lens(const int32_t* lens_host, int batch, int frames, hipStream_t st) override {
+    if ((size_t)batch > lens_cap) {
+      if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+      if (lens_pinned) (void)hipHostFree(lens_pinned);
+      lens_pinned = nullptr;
+      const size_t cap = (size_t)batch + batch / 2 + 64;
+      if (lens_dev.alloc(cap * kLenLevels * sizeof(int)) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void**>(&lens_pinned), cap * kLenLevels * sizeof(int), 0) != hipSuccess) {
+        set_error("ragged batch: length table allocation failed");
+        return nullptr;
+      }
+      lens_cap = cap;
+      if (!lens_copied && hipEventCreateWithFlags(&lens_copied, hipEventDisableTiming) != hipSuccess) return nullptr;
+    } else if (lens_copied) {
+      (void)hipEventSynchronize(lens_copied);          // the previous upload has left the staging buffer
+    }
+    for (int b = 0; b < batch; ++b) {
+      int L = lens_host[b];
+      if (L < min_frames() || L > frames) {
+        set_error("ragged batch: utterance %d has %d frames, valid range is [%d, %d]", b, L, min_frames(), frames);
+        return nullptr;
+      }
+      for (int l = 0; l < kLenLevels; ++l) {
+        lens_pinned[(size_t)l * batch + b] = L;
+        L = (L - 1) / 2 + 1;
+      }
+    }
+    if (hipMemcpyAsync(lens_dev.ptr, lens_pinned, (size_t)batch * kLenLevels * sizeof(int),
+                       hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipEventRecord(lens_copied, st) != hipSuccess) {
+      set_error("ragged batch: length table upload failed");
+      return nullptr;
+    }
+    return lens_dev.as<int>();
+  }
+
+  int check_frames(int frames) {
+    if (frames > maxT || frames < min_frames()) {
+      set_error("num_frames %d outside the finalized capacity [%d, %d]", frames, min_frames(), maxT);
+      return WS_ERR_CAPACITY;
+    }
+    return 0;
+  }
+
+  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
+    if (int r = check_frames(frames)) return r;
+    for (int l = 0; l < kLenLevels; ++l) cur_lens[l] = nullptr;
+    for (int b0 = 0; b0 < batch; b0 += maxB) {
+      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
+      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
+                            emb + (size_t)b0 * embed_dim, st);
+      if (r) return r;
+    }
+    return range_guard(emb, batch, st);
+  }
+
+  int forward_chunk_ragged(const float* feats, int nb, int frames, const int* dev, int batch, int b0,
+                           float* emb, hipStream_t st) override {
+    for (int l = 0; l < kLenLevels; ++l) cur_lens[l] = dev + (size_t)l * batch + b0;
+    const int rc = forward_chunk(feats, nb, frames, emb, st);
+    for (int l = 0; l < kLenLevels; ++l) cur_lens[l] = nullptr;
+    return rc;
+  }
+  int finish_forward(const float* emb, int batch, hipStream_t st) override { return range_guard(emb, batch, st); }
+
+  int forward_ragged(const float* feats, int batch, int frames, const int32_t* lens_host, float* emb,
+                     hipStream_t st) override {
+    if (int r = check_frames(frames)) return r;
+    const int* dev = upload_lens(lens_host, batch, frames, st);
+    if (!dev) return WS_ERR_INVALID_ARG;
+    for (int b0 = 0; b0 < batch; b0 += maxB) {
+      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
+      // zero the padding rows: they are what the first convolution's taps must see
+      hipError_t he = launch_copy_rows_masked(feats + (size_t)b0 * frames * feat_dim, feats_ws, nb, frames,
+                                              feat_dim, dev + b0, st);
+      if (he != hipSuccess) {
+        set_error("masked feature copy failed: %s", hipGetErrorString(he));
+        return WS_ERR_HIP;
+      }
+      int r = forward_chunk_ragged(feats_ws, nb, frames, dev, batch, b0, emb + (size_t)b0 * embed_dim, st);
+      if (r) return r;
+    }
+    return range_guard(emb, batch, st);
   }
   float* feats_workspace() override { return feats_ws; }
   int max_batch() const override { return maxB; }

@@ -29,9 +29,12 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % NT, wm = wave / NT;
   const int li = lane & 15, lq = lane >> 4;
-  const int T = p.T, d = p.dil;
+  const int d = p.dil;
+  // ragged batch: rows [lens[b], p.T) of utterance b are padding -- never read, never written, and seen
+  // by the dilated taps as the conv's zero padding (X stays zero there)
+  const int T = p.lens ? p.lens[b] : p.T;
   const int rows_total = MW * MTW * 16 + 2 * d;         // LDS rows incl. halo and row padding
-  const long long m_base = (long long)b * T;
+  const long long m_base = (long long)b * p.T;
 
   // zero the whole X once: halo rows and rows >= T stay zero for all steps
   for (int i = tid * 4; i < rows_total * XS; i += 512 * 4)
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
       for (int r = 0; r < 4; ++r) {
         const int t = t0 + mt * 16 + r;
         if (t < T) {
-          float v = fmaxf(acc[mt][r] + bias, 0.f) * sc + sh;
+          float v = relu_f(acc[mt][r] + bias) * sc + sh;
           y2u[t * ld2] = v;
           if (step < 6) X[(t + d) * XS + co] = v + (PF ? y1n[PF ? mt : 0][r] : y1u[t * ld1]);
         }
@@ -156,7 +159,10 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % NT, wm = wave / NT;
   const int li = lane & 15, lq = lane >> 4;
-  const int T = p.T, d = p.dil;
+  const int d = p.dil;
+  // ragged batch: rows [lens[b], p.T) of utterance b are padding -- never read, never written, and seen
+  // by the dilated taps as the conv's zero padding (X stays zero there)
+  const int T = p.lens ? p.lens[b] : p.T;
   const int rows_total = MW * MTW * 16 + 2 * d;
   _Float16* Xh = Xs;
   _Float16* Xl = Xs + rows_total * XS;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   // coalesced 16-B stores of halfs instead of 4*MTW scalar 4-B stores per lane
   _Float16* Y16 = Xs + 2 * rows_total * XS;
   const bool half_out = p.y2h != nullptr;
-  const long long m_base = (long long)b * T;
+  const long long m_base = (long long)b * p.T;
 
   for (int i = tid * 8; i < 2 * rows_total * XS; i += 512 * 8)
     *reinterpret_cast<f16x8*>(&Xs[i]) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
       if (t < T) {
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[mt][r] + bias[r], 0.f) * sc[r] + sh[r];
+        for (int r = 0; r < 4; ++r) v[r] = relu_f(acc[mt][r] + bias[r]) * sc[r] + sh[r];
         if (half_out) {
           f16x4 hv;
 #pragma unroll

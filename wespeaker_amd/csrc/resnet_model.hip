@@ -135,20 +135,26 @@ struct ResNetModel : ModelBase {
     return 0;
   }
 
-  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) {
+  int min_frames() const override { return 2; }
+
+  int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
     int H = feat_dim, W = T;
+    // ragged chunk: the time axis of utterance b holds cur_lens[level][b] valid columns at stride level
+    // `level`; every convolution stores zeros beyond them (row_len), TSTP runs over the valid columns
+    int lvl = 0;
     // f16 back-end: every activation map lives in HBM as binary16 only (same buffers, half used);
     // all convolutions then run on the LDS-DMA kernel (conv form), residuals are read as halfs
     const bool f16io = gemm_precision == 2;
     float* x = buf[0];
     WS_LAUNCH(other(4.0 * B * H * (double)W * 33, st, [&] {
       return launch_stem_conv3x3(feats, B, T, feat_dim, arena.at(stem_w), arena.at(stem_b), 32, x, st,
-                                 f16io ? reinterpret_cast<uint16_t*>(x) : nullptr);
+                                 f16io ? reinterpret_cast<uint16_t*>(x) : nullptr, cur_lens[0]);
     }));
     // in -> out convolution with the optional residual, in the tensor format of the active back-end
     auto conv = [&](const ConvW& cw, const float* in, int Cin_, float* out, int Cout_, int Hin_, int Win_,
-                    int s_, int pad, int act, const float* res, int ldr) {
+                    int s_, int pad, int act, const float* res, int ldr, int out_lvl) {
       ConvGemmParams p = conv2d(cw, in, Cin_, 0, out, Cout_, 0, B, Hin_, Win_, s_, s_, 1, 1, pad, pad, act);
+      p.row_len = cur_lens[out_lvl];                       // stride level of this launch's OUTPUT width
       if (f16io) {
         p.A16 = reinterpret_cast<const uint16_t*>(in); p.lda16 = Cin_;
         p.D = nullptr; p.D16 = reinterpret_cast<uint16_t*>(out); p.ldd16 = Cout_;
@@ -166,32 +172,34 @@ struct ResNetModel : ModelBase {
       const int s = blk.stride;
       const int Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
       const int Cx = blk.in_planes, P = blk.planes, Co = P * exp;
+      const int lo = lvl + (s == 2 ? 1 : 0);               // stride level of the block's output
       const float* res = x;
       int ldr = Cx;
       if (blk.has_sc) {     // 1x1 stride-s conv + BN on the block input
-        WS_LAUNCH(conv(blk.sc, x, Cx, t2, Co, H, W, s, 0, ACT_NONE, nullptr, 0));
+        WS_LAUNCH(conv(blk.sc, x, Cx, t2, Co, H, W, s, 0, ACT_NONE, nullptr, 0, lo));
         res = t2;
         ldr = Co;
       }
       if (lay.bottleneck) {
-        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0));
-        WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0));
-        WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr));
+        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0, lvl));
+        WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
+        WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr, lo));
         cur = (cur + 1) & 3;            // result in t1
       } else {
-        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, s, 1, ACT_RELU, nullptr, 0));
-        WS_LAUNCH(conv(blk.c2, t1, P, out, Co, Ho, Wo, 1, 1, ACT_RELU, res, ldr));
+        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
+        WS_LAUNCH(conv(blk.c2, t1, P, out, Co, Ho, Wo, 1, 1, ACT_RELU, res, ldr, lo));
         cur = (cur + 3) & 3;            // result in out
       }
       x = buf[cur];
       H = Ho; W = Wo;
+      lvl = lo;
     }
     const int Cl = 256 * exp;           // channels of the last stage
     WS_LAUNCH(other((f16io ? 4.0 : 8.0) * B * H * (double)W * Cl, st, [&] {
       if (f16io)
         return launch_tstp_f16(reinterpret_cast<const uint16_t*>(x), Cl, B, H, W, Cl, nullptr, nullptr,
-                               pooled, st);
-      return launch_tstp(x, Cl, B, H, W, Cl, nullptr, nullptr, pooled, st);
+                               pooled, st, cur_lens[lvl]);
+      return launch_tstp(x, Cl, B, H, W, Cl, nullptr, nullptr, pooled, st, cur_lens[lvl]);
     }));
     if (!two_emb) {
       WS_LAUNCH(gemm_splitk(conv1d(seg1, pooled, 2 * stats_dim, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
@@ -203,20 +211,6 @@ struct ResNetModel : ModelBase {
       WS_LAUNCH(gemm(conv1d(seg2, emb_a, embed_dim, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE), st));
     }
     return 0;
-  }
-
-  int forward(const float* feats, int batch, int frames, float* emb, hipStream_t st) override {
-    if (frames > maxT || frames < 2) {
-      set_error("num_frames %d outside the finalized capacity [2, %d]", frames, maxT);
-      return WS_ERR_CAPACITY;
-    }
-    for (int b0 = 0; b0 < batch; b0 += maxB) {
-      const int nb = batch - b0 < maxB ? batch - b0 : maxB;
-      int r = forward_chunk(feats + (size_t)b0 * frames * feat_dim, nb, frames,
-                            emb + (size_t)b0 * embed_dim, st);
-      if (r) return r;
-    }
-    return range_guard(emb, batch, st);
   }
 
   double flops(int batch, int T) const override {

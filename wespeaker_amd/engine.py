@@ -54,6 +54,28 @@ class Frontend:
     def num_frames(self, num_samples: int) -> int:
         return _lib.lib().ws_num_frames(int(num_samples), self.sample_rate)
 
+    def fbank_ragged(self, wav: torch.Tensor, num_samples, window_type="hamming", cmn=True, scale=1.0):
+        """Padded (B, Nmax) waveforms + per-utterance sample counts -> (B, Tmax, bins) features whose rows
+        beyond an utterance's own frames are zero; CMN over the utterance's own frames (ws_fbank_ragged)."""
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device).contiguous()
+        B, N = wav.shape
+        ns = np.ascontiguousarray(np.asarray(num_samples, dtype=np.int32).reshape(-1))
+        n_max = int(ns.max()) if B else 0
+        T = self.num_frames(n_max)
+        feats = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=self.device)
+        if B and T:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_fbank_ragged(self._h, _lib.ptr(wav), dt, B, _lib.ptr(ns), n_max,
+                                                      wav.stride(0), float(scale), WINDOW_TYPES[window_type],
+                                                      int(bool(cmn)), _lib.ptr(feats),
+                                                      _lib.current_stream_ptr(self.device)), "ws_fbank_ragged")
+        return feats
+
     def fbank(self, wav: torch.Tensor, window_type="hamming", cmn=True, scale=1.0) -> torch.Tensor:
         """wav: (B, N) int16 or float32 (int16-range unless `scale` says otherwise), any device
         -> (B, T, num_mel_bins) float32 on the GPU."""
@@ -124,6 +146,7 @@ class NativeSpeakerModel:
         self.frontend_type = "fbank"
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self._rows_budget = self.max_batch * self.max_frames
+        self._max_batch0 = self.max_batch
         self.ignored_keys = []
         self.precision = "fp32"
         return self
@@ -155,6 +178,7 @@ class NativeSpeakerModel:
                 self.ignored_keys.append(key)
         _lib.check(L.ws_engine_finalize(h, self.max_batch, self.max_frames), "ws_engine_finalize")
         self._rows_budget = self.max_batch * self.max_frames
+        self._max_batch0 = self.max_batch
         self.precision = "fp32"
 
     def __del__(self):
@@ -222,14 +246,21 @@ class NativeSpeakerModel:
                    "ws_engine_reserve")
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
 
-    def _ensure_capacity(self, frames):
+    def _ensure_capacity(self, frames, batch=0):
         """The reference takes utterances of any length (cli/speaker.py:125-167): when one exceeds the
         finalized capacity the workspace is re-laid-out for it, keeping rows (= max_batch x max_frames,
-        i.e. the memory footprint) about constant -- longer utterances run in smaller chunks."""
+        i.e. the memory footprint) about constant -- longer utterances run in smaller chunks.  When much
+        shorter batches come back (a length-bucketed list), the layout is turned back towards many short
+        rows so that they do not run in needlessly small chunks.  Each change synchronises the device."""
+        rows = self._rows_budget
         if frames > self.max_frames:
-            rows = self._rows_budget
             new_frames = -(-int(frames * 1.25) // 100) * 100
-            self.reserve(max(1, min(self.max_batch, rows // new_frames)), new_frames)
+            self.reserve(max(1, min(self._max_batch0, rows // new_frames)), new_frames)
+        elif batch > self.max_batch and self.max_batch < self._max_batch0:
+            new_frames = max(-(-int(frames * 1.25) // 100) * 100, 100)
+            new_batch = max(1, min(self._max_batch0, rows // new_frames))
+            if new_frames < self.max_frames and new_batch >= 2 * self.max_batch:
+                self.reserve(new_batch, new_frames)
 
     def embed(self, feats: torch.Tensor) -> torch.Tensor:
         """(B, T, F) float32 -> (B, E) float32 on the GPU."""
@@ -268,7 +299,7 @@ class NativeSpeakerModel:
             dt = 1
         wav = wav.to(self.device).contiguous()
         B, N = wav.shape
-        self._ensure_capacity(frontend.num_frames(N))
+        self._ensure_capacity(frontend.num_frames(N), B)
         emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
         if B:
             with torch.cuda.device(self.device):
@@ -276,6 +307,55 @@ class NativeSpeakerModel:
                                                  wav.stride(0), float(scale),
                                                  WINDOW_TYPES[window_type], _lib.ptr(emb),
                                                  _lib.current_stream_ptr(self.device)), "ws_extract")
+        return emb
+
+    def embed_ragged(self, feats: torch.Tensor, num_frames) -> torch.Tensor:
+        """(B, Tmax, F) float32 features of utterances of different lengths + their frame counts ->
+        (B, E): row b equals embed(feats[b:b+1, :num_frames[b]]) (ws_forward_ragged); the content of the
+        padding rows is ignored."""
+        if feats.dim() != 3 or feats.shape[2] != self.feat_dim:
+            raise ValueError("expected (B, T, %d) features, got %s" % (self.feat_dim, tuple(feats.shape)))
+        feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T, _ = feats.shape
+        lens = np.ascontiguousarray(np.asarray(num_frames, dtype=np.int32).reshape(-1))
+        if lens.shape[0] != B:
+            raise ValueError("num_frames has %d entries for a batch of %d" % (lens.shape[0], B))
+        self._ensure_capacity(T)
+        emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if B:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_forward_ragged(self._h, _lib.ptr(feats), B, T, _lib.ptr(lens),
+                                                        _lib.ptr(emb), _lib.current_stream_ptr(self.device)),
+                           "ws_forward_ragged")
+        return emb
+
+    def extract_ragged(self, frontend: Frontend, wav: torch.Tensor, num_samples, window_type="hamming",
+                       scale=1.0):
+        """Fused wav -> fbank -> CMN -> forward for utterances of different lengths (ws_extract_ragged):
+        wav (B, Nmax) int16/float32 padded rows (padding content irrelevant), num_samples[b] valid samples.
+        Row b equals extract(wav[b:b+1, :num_samples[b]])."""
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device)
+        if wav.stride(-1) != 1:
+            wav = wav.contiguous()
+        B, N = wav.shape
+        ns = np.ascontiguousarray(np.asarray(num_samples, dtype=np.int32).reshape(-1))
+        if ns.shape[0] != B:
+            raise ValueError("num_samples has %d entries for a batch of %d" % (ns.shape[0], B))
+        n_max = int(ns.max()) if B else 0
+        self._ensure_capacity(frontend.num_frames(n_max), B)
+        emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if B:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_extract_ragged(self._h, frontend._h, _lib.ptr(wav), dt, B, _lib.ptr(ns),
+                                                        n_max, wav.stride(0), float(scale),
+                                                        WINDOW_TYPES[window_type], _lib.ptr(emb),
+                                                        _lib.current_stream_ptr(self.device)),
+                           "ws_extract_ragged")
         return emb
 
     def extract_chunked(self, frontend: Frontend, wav: torch.Tensor, samples_per_chunk: int,

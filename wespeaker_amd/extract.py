@@ -16,8 +16,10 @@ with the same flags, file names and on-disk formats, run as ONE process per GPU:
 
 What is different by design (MI355X-first, not a translation):
   * whole-utterance mode is still "batch_size 1" in its RESULT (every utterance is embedded on its own
-    frames), but utterances of equal length are stacked into one device batch, so the engine sees real
-    batches instead of launch-bound single rows; the output order is the list order;
+    frames), but utterances of similar length (within 12 %) share one device batch: equal lengths go
+    through ws_extract, different ones through ws_extract_ragged, whose rows equal the batch-1 result
+    (padding never enters a convolution tap or a statistic) -- the engine sees real batches instead of
+    launch-bound single rows; the output order is the list order;
   * file decode runs on host threads ahead of the GPU, PCM goes through rotating pinned buffers and a copy
     stream (H2D of batch i+1 overlaps the forward of batch i), embeddings come back through pinned memory;
   * fbank + CMN + forward are one C-ABI call (ws_extract) on int16 PCM resident in HBM;
@@ -124,29 +126,45 @@ class GpuExtractor:
         self._turn = 0
         self.embed_dim = model.embed_dim
 
-    def submit(self, batch_cpu: torch.Tensor):
-        """Enqueue one batch; returns a handle whose .result() is the (B, E) numpy array."""
+    supports_ragged = True
+
+    def submit(self, utts):
+        """Enqueue one batch (a list of 1-D waveforms, or a stacked (B, N) tensor); returns a handle whose
+        .result() is the (B, E) numpy array.  Different lengths -> one padded ragged batch."""
         slot = self._slots[self._turn % self.depth]
         self._turn += 1
-        B, N = batch_cpu.shape
-        if batch_cpu.dtype != torch.int16:                   # 8- / 32-bit files arrive as int16-range floats
-            batch_cpu = batch_cpu.to(torch.float32)
-        nbytes = B * N * batch_cpu.element_size()
+        if isinstance(utts, torch.Tensor):
+            utts = list(utts)
+        lens = [int(u.shape[0]) for u in utts]
+        B, N = len(utts), max(lens)
+        ragged = min(lens) != N
+        dtype = torch.int16 if all(u.dtype == torch.int16 for u in utts) else torch.float32
+        nbytes = B * N * (2 if dtype == torch.int16 else 4)   # 8- / 32-bit files arrive as int16-range floats
         if slot["free"] is not None:
             slot["free"].synchronize()                       # the forward that read this slot has finished
+        main = torch.cuda.current_stream(self.device)
         if slot["pin"] is None or slot["pin"].numel() < nbytes:
             slot["pin"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
-            slot["dev"] = torch.empty(slot["pin"].numel(), dtype=torch.uint8, device=self.device)
-        pin = slot["pin"][:nbytes].view(batch_cpu.dtype).view(B, N)
-        pin.copy_(batch_cpu)
-        dev = slot["dev"][:nbytes].view(batch_cpu.dtype).view(B, N)
+            # The device staging buffer is written by the COPY stream: it must come from that stream's
+            # allocator pool.  A block taken from the main stream's pool may be memory a still-pending
+            # main-stream kernel (e.g. the previous batch's embedding store) is about to write -- legal for
+            # same-stream reuse, a race for the copy stream (seen as a corrupted first utterance).
+            with torch.cuda.stream(self.copy_stream):
+                slot["dev"] = torch.empty(slot["pin"].numel(), dtype=torch.uint8, device=self.device)
+        pin = slot["pin"][:nbytes].view(dtype).view(B, N)
+        for b, u in enumerate(utts):                         # (padding bytes are never read by the kernels)
+            pin[b, :lens[b]].copy_(u)
+        dev = slot["dev"][:nbytes].view(dtype).view(B, N)
         with torch.cuda.stream(self.copy_stream):
             dev.copy_(pin, non_blocking=True)
             uploaded = torch.cuda.Event()
             uploaded.record(self.copy_stream)
-        main = torch.cuda.current_stream(self.device)
         main.wait_event(uploaded)
-        emb = self.model.extract(self.frontend, dev, window_type=self.window_type)
+        dev.record_stream(main)
+        if ragged:
+            emb = self.model.extract_ragged(self.frontend, dev, lens, window_type=self.window_type)
+        else:
+            emb = self.model.extract(self.frontend, dev, window_type=self.window_type)
         slot["free"] = torch.cuda.Event()
         slot["free"].record(main)
         out = torch.empty((B, self.embed_dim), dtype=torch.float32).pin_memory()
@@ -173,12 +191,18 @@ class HostExtractor:
     """Same submit()/finish() protocol around any callable (B, N) tensor -> (B, E) array: the CPU tests use it
     to exercise list handling, bucketing, sharding and file output without a GPU."""
 
-    def __init__(self, fn, embed_dim):
-        self.fn, self.embed_dim = fn, embed_dim
+    def __init__(self, fn, embed_dim, ragged_fn=None):
+        self.fn, self.embed_dim, self.ragged_fn = fn, embed_dim, ragged_fn
+        self.supports_ragged = ragged_fn is not None
 
-    def submit(self, batch_cpu):
-        out = np.asarray(self.fn(batch_cpu), dtype=np.float32)
-        return _Done(out)
+    def submit(self, utts):
+        lens = [int(u.shape[0]) for u in utts]
+        if min(lens) == max(lens):
+            return _Done(np.asarray(self.fn(torch.stack(list(utts))), dtype=np.float32))
+        padded = torch.zeros((len(lens), max(lens)), dtype=utts[0].dtype)
+        for b, u in enumerate(utts):
+            padded[b, :lens[b]] = u
+        return _Done(np.asarray(self.ragged_fn(padded, lens), dtype=np.float32))
 
     def finish(self):
         pass
@@ -208,11 +232,12 @@ def _prefetch(pool, fn, items, depth):
 
 def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=32240, max_batch=256,
                     resample_rate=16000, num_workers=4, seed=0, resample_fn=None,
-                    max_buffered_samples=64 << 20):
+                    max_buffered_samples=64 << 20, length_tolerance=0.12):
     """Embeddings of `entries` ((key, loader) pairs) in list order -> (keys, (n, E) float32).
 
     whole_utt (default: batch_size == 1, the rule of bin/extract.py:95): every utterance on all of its
-    samples; equal-length utterances share a device batch of up to max_batch rows.  Otherwise every
+    samples; utterances whose lengths lie within length_tolerance of each other (extractors with
+    supports_ragged; exact equality otherwise) share a device batch of up to max_batch rows.  Otherwise every
     utterance is cut/tiled to chunk_len samples (random_chunk) and batches hold max(batch_size, ...) rows
     -- the batch size does not change any row's value, so the cohort mode also fills up to max_batch.
     Utterances waiting for a full bucket hold at most max_buffered_samples samples in host memory."""
@@ -235,9 +260,17 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
             pcm = random_chunk(pcm, key, chunk_len, seed)
         return idx, key, pcm
 
-    def flush(length):
-        idxs, tensors = buckets.pop(length)
-        pending.append((idxs, extractor.submit(torch.stack(tensors))))
+    import math
+    ragged_ok = whole_utt and getattr(extractor, "supports_ragged", False) and length_tolerance > 0
+    log_step = math.log1p(length_tolerance) if ragged_ok else 1.0
+
+    def bucket_of(n, dtype):
+        # geometric length classes: everything in a class is within length_tolerance of the class maximum
+        return (int(math.log(max(n, 1)) / log_step) if ragged_ok else n, dtype)
+
+    def flush(key):
+        idxs, tensors = buckets.pop(key)
+        pending.append((idxs, extractor.submit(tensors)))
 
     def drain(keep):
         while len(pending) > keep:
@@ -252,13 +285,14 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
         for idx, key, pcm in _prefetch(pool, load, enumerate(entries), depth=4 * workers):
             keys.append(key)
             n = int(pcm.shape[0])
-            b = buckets.setdefault((n, pcm.dtype), ([], []))
+            key = bucket_of(n, pcm.dtype)
+            b = buckets.setdefault(key, ([], []))
             b[0].append(idx)
             b[1].append(pcm)
             buffered += n
             if len(b[0]) >= max_batch:
-                buffered -= n * len(b[0])
-                flush((n, pcm.dtype))
+                buffered -= sum(int(t.shape[0]) for t in b[1])
+                flush(key)
                 drain(keep=2)
             elif buffered > max_buffered_samples:
                 for length in sorted(buckets, key=lambda t: t[0]):
