@@ -595,12 +595,15 @@ def test_full_size_batch_properties_ecapa():
         model.set_precision(prec)
         full = model.extract(fe, wav)
         shuffled = model.extract(fe, wav[perm])
-        assert torch.equal(shuffled, full[perm]) or _rel_err(shuffled.cpu().numpy(), full[perm].cpu().numpy()).max() < 1e-5
+        # (not bit-equal: the position of an utterance inside the 64-row tiles moves the fp32 summation order
+        # of the SE / context column sums by ~1e-7)
+        assert _rel_err(shuffled.cpu().numpy(), full[perm].cpu().numpy()).max() < 1e-5
         single = torch.cat([model.extract(fe, wav[i:i + 1]) for i in (0, 131, 255)])
         assert _rel_err(single.cpu().numpy(), full[[0, 131, 255]].cpu().numpy()).max() < 1e-5
-        rows = [3, 200]
+        rows = list(range(3, 256, 17))                      # 15 rows spread over every 64-row tile phase
         ref = oecapa.ecapa_forward(sd, np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])).numpy()
         assert _rel_err(full[rows].cpu().numpy(), ref).max() < 5e-4
+        assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL
         assert bool(torch.isfinite(full).all())
     # the headline back-end at the headline size (this is the only size at which the wide layer runs on
     # the phase-staggered 256x256 kernel).  A row's binary16 roundings depend on fp32 summation-order
@@ -629,7 +632,7 @@ def test_full_size_ecapa1024_f16_spot_check():
     wav = device_wavs(256, 32000, model.device, 9)
     model.set_precision("f16")
     full = model.extract(fe, wav)
-    rows = [0, 77, 255]
+    rows = [0, 31, 77, 128, 129, 200, 254, 255]
     ref = oecapa.ecapa_forward(sd, np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])).numpy()
     assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL
     assert _rel_err(full[rows].cpu().numpy(), ref).max() < F16_REL_TOL
@@ -670,7 +673,7 @@ def test_full_size_resnet34_f16_spot_check():
     wav = device_wavs(512, 32000, model.device, 21)
     model.set_precision("f16")
     full = model.extract(fe, wav)
-    rows = [1, 300, 511]
+    rows = [1, 64, 255, 300, 448, 511]
     feats = np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])
     ref = oresnet.resnet_forward(sd, feats, "ResNet34").numpy()
     assert _cos_err(full[rows].cpu().numpy(), ref).max() < COS_TOL

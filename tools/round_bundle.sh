@@ -1,22 +1,53 @@
 #!/bin/bash
 # Round-end verification + measurement bundle for ONE gpurun call (run from the repo root on the GPU box):
-#   gpurun --timeout 2000 -- 'bash tools/round_bundle.sh'
-# Outputs land in gpurun_out/; copy them to profiles/rNN_* afterwards (see tools/README.md).
+#   gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r02'
+# Everything lands in gpurun_out/<tag>_*; tools/collect_profiles.sh <tag> copies the judged artefacts to profiles/.
+TAG=${1:-r02}
 cd "${GRAFT_REPO_ROOT:-.}"
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; tail -1 gpurun_out/bench_full.json | cut -c1-250
-python tools/bench_models.py --steps 5 > gpurun_out/models.jsonl 2>/dev/null
 REPO=$(pwd)
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_final" -o final -- python "$REPO/bench.py" --headline-only --steps 20 > "$REPO/gpurun_out/prof_final.log" 2>&1
-i=0
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$REPO/gpurun_out/pmcf_$i" -- python "$REPO/bench.py" --precision f16 --steps 5 --warmup 2 --headline-only > /dev/null 2>&1
+OUT=$REPO/gpurun_out
+mkdir -p "$OUT"
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short > "$OUT/${TAG}_pytest.log" 2>&1; tail -3 "$OUT/${TAG}_pytest.log"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+fi
+# the driver's line (default: ECAPA-512, fp32 headline + both fast modes + config 1 + PLDA + cpu baseline)
+python bench.py > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/${TAG}_bench_n1.err"; cut -c1-200 "$OUT/${TAG}_bench_n1.json"
+# the other families of BASELINE.json (configs 2-3) through the same bench.py
+for m in ECAPA_TDNN_GLOB_c1024 ResNet34 ResNet221 CAMPPlus; do
+  python bench.py --model $m --steps 10 --windows 3 --cpu-utts 300 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_models.jsonl"
 done
+cd /tmp && export TMPDIR=/tmp
+# kernel tables: one headline-only run per back-end / family, so every table describes ONE workload
+prof() {  # name, bench args...
+  local name=$1; shift
+  rm -rf "$OUT/prof_$name"
+  rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o p -- python "$REPO/bench.py" --headline-only --steps 20 --windows 1 "$@" > "$OUT/prof_$name.log" 2>&1
+  python "$REPO/tools/rocprof_summary.py" "$(ls $OUT/prof_$name/*.db 2>/dev/null | head -1)" > "$OUT/${TAG}_kernel_stats_$name.md" 2>/dev/null
+  head -4 "$OUT/${TAG}_kernel_stats_$name.md" | cut -c1-150
+  rm -rf "$OUT/prof_$name"            # the .db files are tens of MB: gpurun_out/ only travels back under 64 MiB
+}
+prof fp32 --precision fp32
+prof f16 --precision f16
+prof f16x3 --precision f16x3
+prof ResNet34_f16 --model ResNet34 --precision f16 --steps 5
+prof ResNet34_fp32 --model ResNet34 --precision fp32 --steps 5
+prof ResNet221_f16 --model ResNet221 --precision f16 --steps 5
+prof CAMPPlus_f16 --model CAMPPlus --precision f16 --steps 5
+prof CAMPPlus_fp32 --model CAMPPlus --precision fp32 --steps 5
+# PMC passes (counters in their own runs, kernel-trace only): HBM traffic + MFMA-busy of the dominant class
+pmc() {  # prec, needle
+  local prec=$1 needle=$2 i=0
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rm -rf "$OUT/pmc_${prec}_$i"
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${prec}_$i" -- python "$REPO/bench.py" --precision $prec --steps 5 --warmup 2 --windows 1 --headline-only > /dev/null 2>&1
+  done
+  python "$REPO/tools/pmc_traffic.py" $prec "$needle" "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3" > "$OUT/${TAG}_pmc_dominant_kernel_$prec.json"
+  grep -E "traffic_bytes_per_launch|mfma_busy" "$OUT/${TAG}_pmc_dominant_kernel_$prec.json"
+  rm -rf "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3"
+}
+pmc fp32 "conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
+pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64, 64"
 cd "$REPO"
-python tools/rocprof_summary.py "$(ls gpurun_out/prof_final/*.db | head -1)" > gpurun_out/final_kernel_stats.md
-python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel" gpurun_out/pmcf_1 gpurun_out/pmcf_2 gpurun_out/pmcf_3 > gpurun_out/pmc_f16.json
-head -8 gpurun_out/final_kernel_stats.md | cut -c1-160
+ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '
