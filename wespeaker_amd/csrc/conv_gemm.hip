@@ -454,9 +454,14 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
     }
   }
 }
+// One BM x BN output tile.  bid / nblk: this workgroup's index and the number of workgroups of ITS tile
+// class (the plain kernel passes blockIdx.x / gridDim.x; the dual kernel below runs a 128x128 class and a
+// 64x64 class in one grid); m_begin: first output row of the class.
+// (A K-tile-16 / three-workgroups-per-CU fp32 form with a two-half epilogue was measured and dropped: 291 vs
+// 280 us on the N = K = 512 layer, 19 spilled VGPRs at the 168-register budget.)
 template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2))
-void conv_gemm_kernel(const ConvGemmParams p) {
+__device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* lds, const int bid,
+                                               const int nblk, const int m_begin) {
   constexpr int S = LDS_STRIDE;
   constexpr int NT = 64 * WM * WN;                    // threads per workgroup (4 or 8 wavefronts)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -466,7 +471,6 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int W_IT = PREC == 0 ? BN / AROWS : (BN / WROWS > 0 ? BN / WROWS : 1);
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   static_assert(A_IT >= 1 && W_IT >= 1, "tile too small for the thread count");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -476,13 +480,13 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   // the weight panels; placement only affects speed, the map is a bijection for any grid size.
   int work;
   {
-    const int nblk = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     work = xcd * q + (xcd < r ? xcd : r) + local;
   }
   const int tile_m = work / tiles_n;
   const int tile_n = work - tile_m * tiles_n;
-  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
+  const int m0 = m_begin + tile_m * BM, n0 = tile_n * BN;
 
   // ---------------- staging roles: thread -> (16-B chunk kc of the K-tile, rows r0 + 32 i)
   const int kc = tid & 7;
@@ -737,6 +741,98 @@ void conv_gemm_kernel(const ConvGemmParams p) {
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  if constexpr (PREC == 0 && TM == 2 && TN == 2) {
+    // fp32 schedule of the 128x128 tile.  A wave sits in MFMA issue for a whole k-group (16 x 64 cycles)
+    // and the two workgroups of a CU run in lock step (equal tiles, started together), so anything placed
+    // BETWEEN the K-tiles -- LDS stores of the next tile, the barrier, the first fragment reads -- idled the
+    // matrix pipe (cycle stamps on the K = 1536 layer: ~1600 of every 9800 cycles per K-tile unused; each
+    // wave's ~800 cycles of staging were NOT covered by its SIMD partner, whose barrier couples it to three
+    // other SIMDs).  Here every such step is issued BEHIND one MFMA of the running tile (an fp32 MFMA
+    // occupies the pipe for 64 cycles; sched_barrier keeps the filler in its shadow):
+    //   g0: global loads of tile k+1, fragments of g1 | g1: fragments of g2 | g2: LDS stores of tile k+1,
+    //   fragments of g3 | barrier | g3: fragments of group 0 of tile k+1
+    // The barrier may sit before the last group because that group's fragments are already in registers:
+    // behind it nobody reads the current buffer any more and the next one is complete.
+    // Same-box A/B (tools/gemm_probe): K = N = 1536 layer 1952 -> 1857 us, N = K = 512 layer 275 -> 264 us.
+    // What it does not move: one wavefront per SIMD alone already reaches the same 0.82 of the fp32 MFMA
+    // peak inside the loop as two (forced by an LDS pad), two-tiles-ahead register prefetch changes nothing,
+    // swapping the weight fragment's register banks changes nothing.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto frag_piece = [&](int bufi, int g, int slot, int j) {      // j: 0,1 = A blocks, 2,3 = W blocks
+      const float* As = lds + bufi * STAGE_FLOATS + (wm * TM * 32 + li) * S + lh * 4;
+      const float* Ws = lds + bufi * STAGE_FLOATS + BM * S + (wn * TN * 32 + li) * S + lh * 4;
+      if (j < 2) fa[slot][j] = *reinterpret_cast<const f32x4*>(&As[j * 32 * S + g * 8]);
+      else fb[slot][j - 2] = *reinterpret_cast<const f32x4*>(&Ws[(j - 2) * 32 * S + g * 8]);
+    };
+    // 16 MFMAs of the k-group held in fragment slot `slot`; filler(i) is issued behind MFMA i
+    auto mma = [&](int slot, auto&& filler) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in) {
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[slot][in][sq], fa[slot][im][sq], acc[im][in], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            filler(sq * 4 + im * 2 + in);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // staging pieces of the next K-tile: 0 .. W_IT-1 weights, W_IT .. W_IT+A_IT-1 activations
+    constexpr int NP = W_IT + A_IT;
+    static_assert(NP <= 8, "at most eight staging pieces per thread");
+    auto load_piece = [&](int j) {
+      if (j < W_IT) {
+        rw[j] = *reinterpret_cast<const f32x4*>(sw_ptr[j]);
+        sw_ptr[j] += sw_inc[j];
+      } else if (j < NP) {
+        ra[j - W_IT] = *reinterpret_cast<const f32x4*>(sa_ptr[j - W_IT]);
+        sa_ptr[j - W_IT] += sa_inc[j - W_IT];
+      }
+    };
+    auto store_piece = [&](int bufi, int j) {
+      float* As = lds + bufi * STAGE_FLOATS;
+      float* Ws = As + BM * S;
+      if (j < W_IT) *reinterpret_cast<f32x4*>(&Ws[(r0 + AROWS * j) * S + kc * 4]) = rw[j];
+      else if (j < NP) *reinterpret_cast<f32x4*>(&As[(r0 + AROWS * (j - W_IT)) * S + kc * 4]) = ra[j - W_IT];
+    };
+    int buf = 0;
+    if (kt_begin < kt_end) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_piece(0, 0, 0, j);
+    }
+    for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
+      if (!SIMPLE) {                       // general convolution: tap decode once, then all rows
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma(0, [&](int i) {                  // g0: global loads of tile kt+1, then the fragments of g1
+        if (SIMPLE && i < 8) load_piece(i);
+        if (i >= 8 && i < 12) frag_piece(buf, 1, 1, i - 8);
+      });
+      mma(1, [&](int i) {                  // g1: fragments of g2
+        if (i >= 8 && i < 12) frag_piece(buf, 2, 0, i - 8);
+      });
+      mma(0, [&](int i) {                  // g2: LDS stores of tile kt+1, fragments of g3
+        if (i < 8) store_piece(buf ^ 1, i);
+        if (i >= 8 && i < 12) frag_piece(buf, 3, 1, i - 8);
+      });
+      __syncthreads();
+      mma(1, [&](int i) {                  // g3 (fragments already in registers): group 0 of tile kt+1
+        if (i < 4) frag_piece(buf ^ 1, 0, 0, i);
+      });
+      buf ^= 1;
+    }
+    if (kt_begin < kt_end) {
+      mma(0, [&](int i) { if (i >= 8 && i < 12) frag_piece(buf, 1, 1, i - 8); });
+      mma(1, [&](int i) { if (i >= 8 && i < 12) frag_piece(buf, 2, 0, i - 8); });
+      mma(0, [&](int i) { if (i >= 8 && i < 12) frag_piece(buf, 3, 1, i - 8); });
+      mma(1, [](int) {});
+    }
+    __syncthreads();
+  } else {
   // Branch-free steady state (the last K-tile is peeled) so that the scheduler may interleave the
   // conversion / LDS writes of tile k+1 with the MFMAs of tile k.
   int buf = 0;
@@ -749,8 +845,33 @@ void conv_gemm_kernel(const ConvGemmParams p) {
   }
   if (kt_begin < kt_end) compute_tile(buf);
   __syncthreads();
+  }
 
   gemm_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, threadIdx.x);
+}
+
+template <int BM, int BN, int WM, int WN, bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2))
+void conv_gemm_kernel(const ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  conv_gemm_body<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE, PREC>(p, lds, blockIdx.x, gridDim.x, p.m_begin);
+}
+
+// Whole rounds of 128x128 tiles AND the 64x64 tiles of the remaining rows in ONE grid.  A layer whose tile
+// count is not a multiple of the chip's 512 block slots used to run as two launches (128x128 rounds, then a
+// 64x64 tail): here workgroups [0, n_big) take the big tiles and the rest the small ones; the dispatcher
+// hands out workgroups in index order as slots free up.  (Gain: the kernel boundary only, ~4 % on the
+// N = K = 512 layer -- the rounds of equal tiles end together, so the small tiles still start behind them.)
+template <bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
+__global__ __launch_bounds__(256, 2)
+void conv_gemm_dual_kernel(const ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  if (bid < p.n_big)
+    conv_gemm_body<128, 128, 2, 2, HAS_A2, HAS_PRE, SIMPLE, PREC>(p, lds, bid, p.n_big, p.m_begin);
+  else
+    conv_gemm_body<64, 64, 2, 2, HAS_A2, HAS_PRE, SIMPLE, PREC>(p, lds, bid - p.n_big, (int)gridDim.x - p.n_big,
+                                                                p.tail_begin);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1578,6 +1699,28 @@ static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// one grid: 128x128 tiles over rows [m_begin, tail_begin), 64x64 tiles over [tail_begin, M)
+template <bool HAS_A2, bool HAS_PRE, bool SIMPLE, int PREC>
+static hipError_t launch_dual(ConvGemmParams p, int tail_begin, hipStream_t stream) {
+  constexpr size_t big = tile_lds_bytes<128, 128, PREC>(), pool = (size_t)128 * 256 * 2;
+  constexpr size_t max_bytes = big > pool ? big : pool;
+  const size_t lds_bytes = p.pool_partial ? max_bytes : big;
+  static bool attr_set = false;
+  auto kern = conv_gemm_dual_kernel<HAS_A2, HAS_PRE, SIMPLE, PREC>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_n_big = (p.N + 127) / 128, tiles_n_small = (p.N + 63) / 64;
+  p.tail_begin = tail_begin;
+  p.n_big = (tail_begin - p.m_begin) / 128 * tiles_n_big;
+  const int n_small = (p.M - tail_begin + 63) / 64 * tiles_n_small;
+  hipLaunchKernelGGL(kern, dim3(p.n_big + n_small), dim3(256), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
 // mode: 0 general, 1 A2 (second addend), 2 PRE (BN-ReLU on A), 3 SIMPLE (1x1 running pointers)
 template <int BM, int BN, int WM, int WN, int PREC>
 static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t stream) {
@@ -1721,6 +1864,13 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
         peel = true;
       }
     }
+  }
+  static int dual = -1;
+  if (dual < 0) { const char* ev = getenv("WS_DUAL"); dual = ev ? atoi(ev) : 1; }
+  if (peel && dual && !use_dma && !fast16 && (mode == 0 || mode == 3)) {
+    // both tile classes in one grid (conv_gemm_dual_kernel)
+    return mode == 3 ? launch_dual<false, false, true, PREC>(p, main.M, stream)
+                     : launch_dual<false, false, false, PREC>(p, main.M, stream);
   }
   hipError_t e;
   if (use_dma)   // measured alternatives: 3 stages / 4 waves / one workgroup per CU -16 %; 3 stages / 8 waves

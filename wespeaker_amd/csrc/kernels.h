@@ -65,6 +65,9 @@ struct ConvGemmParams {
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
   int epi16;                                  // set by the dispatcher: the 256x256 kernel finishes a D16-only
                                               // layer through its binary16 one-phase epilogue
+  int n_big, tail_begin;                      // set by the dispatcher (conv_gemm_dual_kernel): workgroups
+                                              // [0, n_big) run 128x128 tiles over rows [m_begin, tail_begin),
+                                              // the others 64x64 tiles over rows [tail_begin, M)
 };
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 
