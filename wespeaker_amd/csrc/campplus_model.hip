@@ -164,7 +164,6 @@ struct CamppModel : ModelBase {
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
     // ragged chunk: lens at full resolution (FCM head) and after the stride-2 TDNN layer (trunk); every
     // convolution stores zeros beyond them, the context masks / TSTP run over the valid frames
-    const bool rag = ragged();
     const int* L0 = cur_lens[0];
     const int* L1 = cur_lens[1];
     // ---------------- FCM head (2-D, stride only along frequency)
@@ -237,7 +236,7 @@ struct CamppModel : ModelBase {
         p1.pre_scale = arena.at(L.pre_s); p1.pre_shift = arena.at(L.pre_b);
         // one context segment (T' <= 100) and >= 64 rows per utterance: the time mean of the
         // bottleneck output comes out of this GEMM's epilogue, the mask kernel never reads hbuf
-        const bool ctx_from_colsum = segs == 1 && Tp >= 64 && !rag;
+        const bool ctx_from_colsum = segs == 1 && Tp >= 64;
         if (ctx_from_colsum) p1.colsum = colsum;
         // f16 back-end: the bottleneck output feeds only the k3 conv (and the statistics above): keep it
         // as binary16 (hbuf reused), read by the conv DMA kernel
@@ -249,7 +248,7 @@ struct CamppModel : ModelBase {
         WS_LAUNCH(other(ctx_from_colsum ? 0.0 : 4.0 * B * (double)Tp * 128, st, [&] {
           if (ctx_from_colsum)
             return launch_cam_context_from_colsum(colsum, B, Tp, 128, arena.at(L.cw1), arena.at(L.cb1), 64,
-                                                  arena.at(L.cw2), arena.at(L.cb2), 32, mask, st);
+                                                  arena.at(L.cw2), arena.at(L.cb2), 32, mask, st, L1);
           return launch_cam_context(hbuf, 128, B, Tp, 128, 100, arena.at(L.cw1), arena.at(L.cb1), 64,
                                     arena.at(L.cw2), arena.at(L.cb2), 32, mask, st, L1);
         }));

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
 __global__ __launch_bounds__(128) void cam_context_from_colsum_kernel(
     const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
     const float* __restrict__ b1, int hidden, const float* __restrict__ w2,
-    const float* __restrict__ b2, int Cout, float* __restrict__ mask) {
+    const float* __restrict__ b2, int Cout, float* __restrict__ mask, const int* __restrict__ lens) {
   __shared__ float ctx[128], hid[128];
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(128) void cam_context_from_colsum_kernel(
       const int first_img = (int)(((long long)tm * 64) / T);
       v += colsum[((long long)tm * 2 + (first_img == b ? 0 : 1)) * C + tid];
     }
-    ctx[tid] = 2.f * v / (float)T;               // global mean + (identical) segment mean
+    // (ragged batch: rows beyond lens[b] are zeros; the divisor is the utterance's own length)
+    ctx[tid] = 2.f * v / (float)(lens ? lens[b] : T);   // global mean + (identical) segment mean
   }
   __syncthreads();
   if (tid < hidden) {                            // hid = relu(W1 ctx + b1): thread per row, 16-B loads
@@ -287,10 +288,10 @@ __global__ __launch_bounds__(128) void cam_context_from_colsum_kernel(
 
 hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                           const float* b1, int hidden, const float* w2, const float* b2,
-                                          int Cout, float* mask, hipStream_t stream) {
+                                          int Cout, float* mask, hipStream_t stream, const int* lens) {
   if (C > 128 || (C & 3) || hidden > 128 || (hidden & 3) || Cout > 128 || T < 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(cam_context_from_colsum_kernel, dim3(B), dim3(128), 0, stream, colsum, T, C, w1, b1,
-                     hidden, w2, b2, Cout, mask);
+                     hidden, w2, b2, Cout, mask, lens);
   return hipGetLastError();
 }
 

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(C == 32 ? 256 : 512, 2) void conv3x3_direct_f16_ker
     const int oy = pyi * PH + ppy, ox = pxi * PW + ppx;
     if (oy < p.Hout && ox < p.Wout) {
       const long long m = ((long long)img * p.Hout + oy) * p.Wout + ox;
+      const bool padded = p.row_len && ox >= p.row_len[img];
       if (p.residual16) {
         const f16x8d r0 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + ch0);
         const f16x8d r1 = *reinterpret_cast<const f16x8d*>(p.residual16 + m * p.ldr + ch0 + 8);
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(C == 32 ? 256 : 512, 2) void conv3x3_direct_f16_ker
         float a = v[c], b = v[8 + c];
         if constexpr (C == 32) { a += bias[c]; b += bias[8 + c]; }
         if (p.act == ACT_RELU) { a = relu_f(a); b = relu_f(b); }
+        if (padded) { a = 0.f; b = 0.f; }        // ragged batch: columns beyond the utterance stay zero
         o0[c] = (_Float16)a; o1[c] = (_Float16)b;
       }
       *reinterpret_cast<f16x8d*>(p.D16 + m * p.ldd16 + ch0) = o0;

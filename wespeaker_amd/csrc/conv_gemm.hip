@@ -185,7 +185,17 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
           const int mh = m0 + hf * 64;
-          const int rb = (mh / HW + 1) * HW - mh;
+          const int imgA = mh / HW;
+          const int rb = (imgA + 1) * HW - mh;
+          // ragged batch: only the utterance's own frames enter its softmax (H = 1: HW = frames per slot)
+          int lenA = 0x7fffffff, lenB = 0x7fffffff;
+          if (p.row_len) {
+            const int last = (p.M - 1) / HW;
+            lenA = p.row_len[imgA < last ? imgA : last];
+            lenB = p.row_len[imgA + 1 < last ? imgA + 1 : last];
+          }
+          const int tA0 = mh - imgA * HW;
+          auto live = [&](int rl) { return mh + rl < p.M && (rl < rb ? tA0 + rl < lenA : rl - rb < lenB); };
           f32x4 hv[RI];
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
@@ -207,7 +217,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
             const int rl = rr + RPP * i;
-            if (mh + rl < p.M) {
+            if (live(rl)) {
               const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]);
               const bool second = rl >= rb;
 #pragma unroll
@@ -223,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p,
 #pragma unroll
           for (int i = 0; i < RI; ++i) {
             const int rl = rr + RPP * i;
-            if (mh + rl < p.M) {
+            if (live(rl)) {
               const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(hf * 64 + rl) * ES + c4 * 4]);
               const bool second = rl >= rb;
               const f32x4 arg = v * LOG2E - (second ? ml1 : ml0);
@@ -1385,14 +1395,27 @@ __device__ __forceinline__ void p8_epilogue_f16(const ConvGemmParams& p, f32x16 
 #pragma unroll
   for (int hf = 0; hf < 4; ++hf) {
     const int mh = m0 + hf * 64;
-    const int rb = (mh / HW + 1) * HW - mh;       // rows >= rb of this 64-row group belong to the next image
+    const int imgA = mh / HW;
+    const int rb = (imgA + 1) * HW - mh;          // rows >= rb of this 64-row group belong to the next image
+    // ragged batch (H = 1 layers only): rows beyond the utterance's own length are stored as zeros
+    int lenA = 0x7fffffff, lenB = 0x7fffffff;
+    if (p.row_len) {
+      const int last = (p.M - 1) / HW;
+      lenA = p.row_len[imgA < last ? imgA : last];
+      lenB = p.row_len[imgA + 1 < last ? imgA + 1 : last];
+    }
+    const int tA0 = mh - imgA * HW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rl = rr + 16 * i;
       const int row = hf * 64 + rl;
       const int m = m0 + row;
       if (m < p.M) {
-        const f16x8 hv = *reinterpret_cast<const f16x8*>(&Y[row * YS + c8 * 8]);
+        f16x8 hv = *reinterpret_cast<const f16x8*>(&Y[row * YS + c8 * 8]);
+        if (rl < rb ? tA0 + rl >= lenA : rl - rb >= lenB) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) hv[q] = (_Float16)0.f;
+        }
         *reinterpret_cast<f16x8*>(dst + (long long)m * p.ldd16) = hv;
         if (p.colsum) {
 #pragma unroll
@@ -1773,7 +1796,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     int& bigc = g_ws_big_conv;
     if (bigc < 0) { const char* ev = getenv("WS_BIG_CONV"); bigc = ev ? atoi(ev) : 1; }
     if (bigc && p.N % 256 == 0 && p.Cin % 64 == 0 && p.K % 64 == 0 && !p.bias_img && !p.residual &&
-        !p.seg_scale && !p.colsum && !p.D2 && !p.row_len) {
+        !p.seg_scale && !p.colsum && !p.D2) {
       const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
       const long long rounds = tiles_m * tiles_n / cus;
       if (rounds >= 1) {
@@ -1813,8 +1836,15 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
   if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 3; }
+  if (g_ws_epi16 < 0) { const char* ev = getenv("WS_EPI16"); g_ws_epi16 = ev ? atoi(ev) : 1; }
+  // D16-only layers finish through the binary16 one-phase epilogue (WS_EPI16=0: the fp32 two-phase one)
+  const bool epi16_ok = g_ws_epi16 && big >= 2 && p.D16 && !p.D && !p.D2 && p.act != ACT_TANH && (p.ldd16 & 7) == 0 &&
+                        (p.d_off & 7) == 0 && (!p.colsum || p.Hout * p.Wout >= 64);
+  // (the row mask of ragged batches lives in that binary16 epilogue only -- the fp32 quadrant epilogue has no row
+  // operands -- and is written for H = 1; other masked layers stay on the 128x128 kernels)
+  const bool mask_ok = !p.row_len || (epi16_ok && p.Hout == 1);
   if (use_dma && big && p.N % 256 == 0 && p.N >= (big >= 3 ? 512 : 1024) && !p.pool_partial && !p.bias_img &&
-      !p.residual && !p.residual16 && !p.seg_scale && !p.row_len) {
+      !p.residual && !p.residual16 && !p.seg_scale && mask_ok) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
     const long long rounds = tiles_m * tiles_n / cus;
     if (rounds >= 1) {
@@ -1823,10 +1853,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       if ((tiles_m * tiles_n) % cus == 0 || (tiles_m * tiles_n) % cus * 10 > cus * (big >= 3 ? 4 : 8)) main_tiles_m = tiles_m;
       ConvGemmParams mainb = p;
       if (main_tiles_m < tiles_m) mainb.M = p.m_begin + (int)(main_tiles_m * 256);
-      // D16-only layers finish through the binary16 one-phase epilogue (WS_EPI16=0: the fp32 two-phase one)
-      if (g_ws_epi16 < 0) { const char* ev = getenv("WS_EPI16"); g_ws_epi16 = ev ? atoi(ev) : 1; }
-      mainb.epi16 = g_ws_epi16 && big >= 2 && p.D16 && !p.D && !p.D2 && p.act != ACT_TANH && (p.ldd16 & 7) == 0 &&
-                    (p.d_off & 7) == 0 && (!p.colsum || p.Hout * p.Wout >= 64);
+      mainb.epi16 = epi16_ok;
+
       hipError_t e = big >= 2 ? launch_f16_p8<false>(mainb, stream) : launch_f16_dma<256, 256, 64, 2>(mainb, stream);
       if (e != hipSuccess || main_tiles_m >= tiles_m) return e;
       ConvGemmParams rest = p;
@@ -1899,9 +1927,9 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   if (p.colsum && (p.splitk > 1 || p.Hout * p.Wout < 64)) return hipErrorInvalidValue;
   if (p.pool_partial && (p.splitk > 1 || p.Hout * p.Wout < 64 || (!p.pool_h && !p.pool_h16) || (p.ldh & 3)))
     return hipErrorInvalidValue;
-  // ragged batches: the row mask lives in the general row-operand epilogue; the fused statistics
-  // (column sums, pooling partials) and split-K are not combined with it
-  if (p.row_len && (p.splitk > 1 || p.colsum || p.pool_partial)) return hipErrorInvalidValue;
+  // ragged batches: the row mask (row operand epilogue, pooling epilogue, binary16 256x256 epilogue) is
+  // not combined with split-K; the pooling / binary16 forms are written for H = 1 (time on the W axis)
+  if (p.row_len && (p.splitk > 1 || (p.pool_partial && p.Hout != 1))) return hipErrorInvalidValue;
   if (p.m_begin & 63) return hipErrorInvalidValue;
   if (p.prec == 1) {
     if (!p.Wh || !p.Wl) return hipErrorInvalidValue;
@@ -1911,7 +1939,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     if (!p.Wh) return hipErrorInvalidValue;
     static int direct = -1;
     if (direct < 0) { const char* ev = getenv("WS_DIRECT3X3"); direct = ev ? atoi(ev) : 1; }
-    if (direct && !p.row_len && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
+    if (direct && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
     return launch_prec<2>(p, stream);
   }
   return launch_prec<0>(p, stream);

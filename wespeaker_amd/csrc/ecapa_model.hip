@@ -130,10 +130,9 @@ struct EcapaModel : ModelBase {
 
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
     // Ragged chunk (cur_lens set): utterance b owns rows [0, lens[b]) of its T-row slot.  Every conv/linear
-    // launch stores zeros in the padding rows (ConvGemmParams::row_len), the fused Res2 chain and the
-    // statistics kernels run over lens[b] rows, and the statistics that the uniform path folds into GEMM
-    // epilogues (SE column sums, context statistics, softmax-pooling partials) use their stand-alone forms.
-    const bool rag = ragged();
+    // launch stores zeros in the padding rows (ConvGemmParams::row_len), so the column sums that the GEMM
+    // epilogues leave for the SE / context statistics are already right (only their divisors become lens[b]);
+    // the fused Res2 chain, the centred second moments and the softmax-pooling epilogue run over lens[b] rows.
     const int* L0 = cur_lens[0];
     // layer1: Conv1d(F -> C, k5, p2) -> ReLU -> BN
     // f16 back-end: the layers that feed 1x1 GEMMs also leave a binary16 copy of their output, which
@@ -141,7 +140,7 @@ struct EcapaModel : ModelBase {
     const bool f16io = gemm_precision == 2;
     // ... and with T >= 64 (SE statistics from the epilogue) the block chain out1 -> y3 -> cat lives in
     // binary16 only: the residual stream is rounded once per block like in any fp16 inference engine
-    const bool allf16 = f16io && T >= 64 && !rag;
+    const bool allf16 = f16io && T >= 64;
     {
       ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
       if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
@@ -201,13 +200,13 @@ struct EcapaModel : ModelBase {
       if (y2_half) { p3.A16 = y2_16; p3.lda16 = C; }
       if (allf16) { p3.D = nullptr; p3.D16 = y3_16; p3.ldd16 = C; }
       p3.row_len = L0;
-      if (T >= 64 && !rag) {
+      if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;
         WS_LAUNCH(gemm(p3, st));
         WS_LAUNCH(other(0.0, st, [&] {
           return launch_se_fc_from_colsum(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                          arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st);
+                                          arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st, L0);
         }));
       } else {
         WS_LAUNCH(gemm(p3, st));
@@ -226,7 +225,7 @@ struct EcapaModel : ModelBase {
     }
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
     // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
-    const bool stats_from_colsum = glob && T >= 64 && !rag;
+    const bool stats_from_colsum = glob && T >= 64;
     static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
     const bool h_half = allf16 && !no_fuse;
     {
@@ -245,8 +244,8 @@ struct EcapaModel : ModelBase {
       // [mean; std] statistics, then bias_img = W1[:, C:3C] [mean; std] + b1 as a split-K GEMM
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
         if (stats_from_colsum && h_half)
-          return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st);
-        if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st);
+          return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st, L0);
+        if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st, L0);
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st, L0);
       }));
       ConvGemmParams cb = conv1d(pool1, stats, 3072, 0, bias_img, 128, 0, B, 1, 1, ACT_NONE);
@@ -257,12 +256,13 @@ struct EcapaModel : ModelBase {
     }
     a1.row_len = L0;
     WS_LAUNCH(gemm(a1, st));
-    if (T >= 64 && !no_fuse && !rag) {
+    if (T >= 64 && !no_fuse) {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
       ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
       l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer
       if (h_half) { l2.pool_h = nullptr; l2.pool_h16 = h16; }
       if (f16io) { l2.A16 = att16; l2.lda16 = 128; }
+      l2.row_len = L0;
       WS_LAUNCH(gemm(l2, st));
       WS_LAUNCH(other(0.0, st, [&] {
         return launch_astp_pool_from_partials(e, B, T, 1536, pooled, st);

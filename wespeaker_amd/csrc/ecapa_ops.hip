@@ -99,10 +99,13 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
 __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
     const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-    int bott, float* __restrict__ s) {
+    int bott, float* __restrict__ s, const int* __restrict__ lens) {
   __shared__ __attribute__((aligned(16))) float mean[1024];
   __shared__ __attribute__((aligned(16))) float hidden[256];
   const int b = blockIdx.x, tid = threadIdx.x;
+  // ragged batch: the rows beyond lens[b] were stored as zeros, so the tile sums are right as they are and
+  // only the divisor is the utterance's own length
+  const float inv_len = 1.f / (float)(lens ? lens[b] : T);
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
   const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
   // the tile partials of an utterance (<= 8 for T <= 448; more fall back to the serial loop): all
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
         v += colsum[((long long)tm * 2 + which) * C + c];
       }
     }
-    mean[c] = v / (float)T;
+    mean[c] = v * inv_len;
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
@@ -171,11 +174,11 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
 
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                     const float* b1, const float* w2, const float* b2,
-                                    int bottleneck, float* s, hipStream_t stream) {
+                                    int bottleneck, float* s, hipStream_t stream, const int* lens) {
   if (C > 1024 || (C & 255) || bottleneck > 256 || (bottleneck & 31) || T < 64)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(se_fc_from_colsum_kernel, dim3(B), dim3(512), 0, stream, colsum, T, C, w1, b1,
-                     w2, b2, bottleneck, s);
+                     w2, b2, bottleneck, s, lens);
   return hipGetLastError();
 }
 
@@ -330,7 +333,7 @@ __device__ __forceinline__ f32x4 load4_as_f32<uint16_t>(const uint16_t* p) {
 template <typename TH>
 __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
     const TH* __restrict__ h, int ldh, int T, int C, const float* __restrict__ colsum,
-    float* __restrict__ stats) {
+    float* __restrict__ stats, const int* __restrict__ lens) {
   __shared__ f32x4 red[4][64];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.y * 256 + lane * 4;
@@ -342,8 +345,9 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
     const int which = (first_img == b) ? 0 : 1;
     mean += *reinterpret_cast<const f32x4*>(colsum + ((long long)tm * 2 + which) * C + c);
   }
-  mean *= 1.f / (float)T;
   const TH* base = h + r0 * ldh + c;
+  if (lens) T = lens[b];              // ragged batch: zero rows beyond; statistics over the own frames
+  mean *= 1.f / (float)T;
   f32x4 q[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -372,18 +376,19 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
 }
 
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
-                                       const float* colsum, float* stats, hipStream_t stream) {
+                                       const float* colsum, float* stats, hipStream_t stream, const int* lens) {
   if ((C & 255) || T < 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(astp_std_from_colsum_kernel<float>, dim3(B, C / 256), dim3(256), 0, stream, h, ldh,
-                     T, C, colsum, stats);
+                     T, C, colsum, stats, lens);
   return hipGetLastError();
 }
 
 hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
-                                           const float* colsum, float* stats, hipStream_t stream) {
+                                           const float* colsum, float* stats, hipStream_t stream,
+                                           const int* lens) {
   if ((C & 255) || T < 64 || (ldh & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(astp_std_from_colsum_kernel<uint16_t>, dim3(B, C / 256), dim3(256), 0, stream, h16,
-                     ldh, T, C, colsum, stats);
+                     ldh, T, C, colsum, stats, lens);
   return hipGetLastError();
 }
 

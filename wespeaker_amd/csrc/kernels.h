@@ -98,7 +98,7 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
 // mean[b][c] = (sum of the tile partials covering rows [b*T, (b+1)*T)) / T, then the two FCs.
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                     const float* b1, const float* w2, const float* b2,
-                                    int bottleneck, float* s, hipStream_t stream);
+                                    int bottleneck, float* s, hipStream_t stream, const int* lens = nullptr);
 // SE_Connect (ecapa_tdnn.py:120-126): s[b][c] = sigmoid(W2 relu(W1 mean_t(y[b,t,:]) + b1) + b2)
 hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
                              const float* b1, const float* w2, const float* b2, int bottleneck,
@@ -114,9 +114,11 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
-                                       const float* colsum, float* stats, hipStream_t stream);
+                                       const float* colsum, float* stats, hipStream_t stream,
+                                       const int* lens = nullptr);
 hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
-                                           const float* colsum, float* stats, hipStream_t stream);
+                                           const float* colsum, float* stats, hipStream_t stream,
+                                           const int* lens = nullptr);
 hipError_t launch_astp_stats(const float* h, int ldh, int B, int T, int C, float* stats,
                              hipStream_t stream, const int* lens = nullptr);
 hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C, const float* w1,
@@ -148,7 +150,7 @@ hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, in
 // h: [B*T][C] (C = 128); mask out: [B][segs][Cout]
 hipError_t launch_cam_context_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
                                           const float* b1, int hidden, const float* w2, const float* b2,
-                                          int Cout, float* mask, hipStream_t stream);
+                                          int Cout, float* mask, hipStream_t stream, const int* lens = nullptr);
 hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int seg_len,
                               const float* w1, const float* b1, int hidden, const float* w2,
                               const float* b2, int Cout, float* mask, hipStream_t stream,
