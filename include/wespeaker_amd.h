@@ -62,6 +62,19 @@ WS_API const char* ws_last_error(void);
  * 1 + (N - 400) / 160 at 16 kHz; 0 if N < frame length. */
 WS_API int ws_num_frames(int num_samples, int sample_rate);
 
+/* ------------------------------------------------------------------------ host-side wave loader
+ * Decode threads of the batch driver (no GPU work): what the reference does in DataLoader worker processes
+ * (dataset/processor.py:119-136 parse_raw / read_audio; bin/extract.py:99-103) and in wenet::WavReader
+ * (runtime/core/frontend/wav.h:71-117).  RIFF/WAVE 16-bit integer PCM only; channel 0 is kept.
+ * ws_wav_probe: per file the number of samples per channel (-1: not readable as PCM16) and the sample rate;
+ * returns the number of unreadable files.
+ * ws_wav_load_rows: samples [start[i], start[i] + count[i]) of file i (start NULL = 0) into row i of dst
+ * (HOST, e.g. pinned; n rows of row_stride int16; the tail of a row is left untouched).  WS_OK or a negative
+ * error naming the first file that could not supply its samples.  `threads` std::threads share the files. */
+WS_API int ws_wav_probe(const char* const* paths, int n, int threads, int32_t* num_samples, int32_t* sample_rate);
+WS_API int ws_wav_load_rows(const char* const* paths, int n, int threads, int16_t* dst, int64_t row_stride,
+                     const int32_t* start, const int32_t* count);
+
 /* -------------------------------------------------------------------------------- frontend */
 /* Replaces torchaudio.compliance.kaldi.fbank as called at cli/speaker.py:92-97 and
  * dataset/processor.py:518-525 (+ CMN cli/speaker.py:98-99, dataset_utils.py:19-26); native twin

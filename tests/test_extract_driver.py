@@ -207,3 +207,69 @@ def test_ragged_capable_extractors_get_length_classes(tmp_path):
     ex2 = wx.HostExtractor(_fake_rows, 6)                             # no ragged support: exact lengths only
     keys2, emb2 = wx.extract_entries(wx.iter_entries("scp", lines), ex2, batch_size=1, max_batch=8)
     assert np.array_equal(emb2, ref)
+
+
+def _write_riff(path, pcm, rate=16000, channels=1, bits=16, extra_chunk=False):
+    import struct
+    data = np.ascontiguousarray(pcm).tobytes()
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * channels * bits // 8,
+                                           channels * bits // 8, bits)
+    if extra_chunk:
+        body += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\0"          # odd size + pad byte
+    body += b"data" + struct.pack("<I", len(data)) + data
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_native_wav_loader_rows_and_probe(tmp_path):
+    """ws_wav_probe / ws_wav_load_rows (C++ decode threads, host only): canonical files, a LIST chunk in front of
+    the data, stereo (channel 0 kept), sub-ranges; unreadable / non-PCM16 files are reported, not guessed."""
+    a = synth.synth_wav(1, 5000)
+    b = synth.synth_wav(2, 7000)
+    st = np.stack([synth.synth_wav(3, 3000), synth.synth_wav(4, 3000)], 1)       # interleaved stereo
+    pa, pb, pc, pd, pe = (str(tmp_path / n) for n in ("a.wav", "b.wav", "c.wav", "d.wav", "e.wav"))
+    _write_riff(pa, a)
+    _write_riff(pb, b, extra_chunk=True)
+    _write_riff(pc, st, channels=2)
+    _write_riff(pd, (a[:100] >> 8).astype(np.int8), bits=8)                     # 8-bit: not on this path
+    open(pe, "wb").write(b"not a wave file")
+    ns, sr = wx.probe_wavs([pa, pb, pc, pd, pe, str(tmp_path / "absent.wav")], threads=3)
+    assert list(ns) == [5000, 7000, 3000, -1, -1, -1] and list(sr[:3]) == [16000] * 3
+    buf = np.full((3, 7000), 77, np.int16)
+    wx.load_wav_rows([pa, pb, pc], buf, [5000, 7000, 3000], threads=2)
+    assert np.array_equal(buf[0, :5000], a) and (buf[0, 5000:] == 77).all()
+    assert np.array_equal(buf[1], b) and np.array_equal(buf[2, :3000], st[:, 0])
+    wx.load_wav_rows([pb, pa], buf[:2], [100, 200], starts=[6900, 4800], threads=1)
+    assert np.array_equal(buf[0, :100], b[6900:]) and np.array_equal(buf[1, :200], a[4800:])
+    from wespeaker_amd._lib import NativeError
+    with pytest.raises(NativeError, match="a.wav"):
+        wx.load_wav_rows([pb, pa], buf[:2], [100, 5001], threads=2)             # more than the file holds
+    with pytest.raises(NativeError):
+        wx.load_wav_rows([pd], buf[:1], [10])
+    # the Python fast reader agrees (incl. the chunk walk)
+    from wespeaker_amd.audio import load_pcm16_fast
+    assert np.array_equal(load_pcm16_fast(pb)[0], b) and np.array_equal(load_pcm16_fast(pc)[0], st[:, 0])
+    x8, r8 = load_pcm16_fast(pd)
+    assert r8 == 16000 and x8.dtype == np.float32 and x8.shape == (100,)          # falls back to load_wav
+
+
+def test_file_fast_path_equals_the_general_path(tmp_path):
+    """extract_files (native loader, batches planned on the probed lengths) == extract_entries, row for row, in
+    both modes; lists it cannot take (pipes, shards, other formats / rates, crops of short files) fall back."""
+    lengths, lines_raw, lines_scp = _make_corpus(str(tmp_path), n=21)
+    ragged = lambda padded, lens: np.concatenate([_fake_rows(padded[b:b + 1, :n]) for b, n in enumerate(lens)])  # noqa: E731
+    ex = wx.HostExtractor(_fake_rows, 6, ragged_fn=ragged)
+    for kw in (dict(batch_size=1), dict(batch_size=16, chunk_len=12000, seed=4)):
+        k0, e0 = wx.extract_entries(wx.iter_entries("raw", lines_raw), ex, max_batch=5, **kw)
+        kp = wx.split_path_list("raw", lines_raw)
+        k1, e1 = wx.extract_files(kp[0], kp[1], ex, max_batch=5, threads=3, **kw)
+        assert k0 == k1 and np.array_equal(e0, e1)
+        k2, e2 = wx.extract_list("scp", lines_scp, ex, max_batch=5, num_workers=2, **kw)
+        assert k2 == k0 and np.array_equal(e2, e0)
+    assert wx.split_path_list("raw", [json.dumps({"key": "p", "wav": "cat x.wav |", "spk": "s"})]) is None
+    assert wx.split_path_list("shard", ["a.tar"]) is None
+    kp = wx.split_path_list("scp", lines_scp)
+    assert wx.extract_files(kp[0], kp[1], ex, batch_size=16, chunk_len=30000) is None      # shorter than the crop
+    assert wx.extract_files(kp[0], kp[1], ex, resample_rate=8000) is None                  # other sample rate
+    k3, e3 = wx.extract_list("scp", lines_scp, ex, batch_size=16, chunk_len=30000, seed=1)  # ... general path: tiled
+    assert len(k3) == 21 and e3.shape == (21, 6) and (e3[:, 4] == 30000).all()

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""End-to-end rate of the batch driver (wespeaker_amd.extract: wav files -> decode threads -> pinned H2D on a
+copy stream -> ws_extract / ws_extract_ragged -> D2H -> ark/scp) on synthetic PCM16 files in /dev/shm.
+
+    python tools/bench_driver.py [--n 4096] [--model ECAPA_TDNN_GLOB_c512] [--workers 8]
+
+Two lists: all files exactly 2 s (the uniform path) and lengths uniform in [1.5, 2.5] s (a real test set: every
+length different -> 12 % length classes -> ragged batches).  Reports utterances/s per back-end and the share of
+the device-resident rate (bench.py) that survives the host pipeline.
+"""
+import argparse, json, os, shutil, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from wespeaker_amd import Frontend, NativeSpeakerModel
+from wespeaker_amd import extract as wx
+from fixtures import synth
+from bench import EMBED_DIM
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--model", default="ECAPA_TDNN_GLOB_c512")
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--max_batch", type=int, default=256)
+    ap.add_argument("--python_loader", action="store_true", help="the Python thread-pool decode path instead of "
+                    "the native loader (ws_wav_load_rows)")
+    args = ap.parse_args()
+    root = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rng = np.random.Generator(np.random.PCG64(1))
+        base = synth.synth_wav(0, 40000)
+        lists = {"uniform_2s": [], "varied_1.5-2.5s": []}
+        for i in range(args.n):
+            for tag, n in (("uniform_2s", 32000), ("varied_1.5-2.5s", int(rng.integers(24000, 40001)))):
+                p = os.path.join(root, "%s_%05d.wav" % (tag[:3], i))
+                synth.write_wav(p, np.roll(base, i * 37)[:n])
+                lists[tag].append("utt%05d %s" % (i, p))
+        dev = torch.device("cuda:0")
+        E = EMBED_DIM.get(args.model[:5], 256)
+        fe = Frontend(16000, 80, device=dev)
+        model = NativeSpeakerModel(args.model, synth.synth_state_dict(args.model, 80, E, seed=42), feat_dim=80,
+                                   embed_dim=E, device=dev, max_batch=args.max_batch, max_frames=250)
+        rec = {"model": args.model, "files": args.n, "decode_threads": args.workers, "max_batch": args.max_batch,
+               "loader": "python threads" if args.python_loader else "native (ws_wav_load_rows)",
+               "host_cores": os.cpu_count()}
+        for prec in ("fp32", "f16"):
+            model.set_precision(prec)
+            for tag, lines in lists.items():
+                ex = wx.GpuExtractor(model, fe)
+                run = (lambda ls: wx.extract_entries(wx.iter_entries("scp", ls), ex, batch_size=1,
+                                                     max_batch=args.max_batch, num_workers=args.workers)) \
+                    if args.python_loader else \
+                    (lambda ls: wx.extract_list("scp", ls, ex, batch_size=1, max_batch=args.max_batch,
+                                                num_workers=args.workers))
+                run(lines[:512])                                                   # warm-up (page cache, capacity)
+                t0 = time.perf_counter()
+                keys, emb = run(lines)
+                wx.write_ark_scp(keys, emb, os.path.join(root, "out_%s_%s.ark" % (prec, tag[:3])))
+                dt = time.perf_counter() - t0
+                assert len(keys) == args.n and np.isfinite(emb).all()
+                rec["%s/%s" % (prec, tag)] = args.n / dt
+        print(json.dumps(rec))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

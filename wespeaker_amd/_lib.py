@@ -17,6 +17,8 @@ SIGNATURES = {
     "ws_version": (c_int, []),
     "ws_last_error": (c_char_p, []),
     "ws_num_frames": (c_int, [c_int, c_int]),
+    "ws_wav_probe": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ws_wav_load_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "ws_frontend_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "ws_frontend_destroy": (None, [c_void_p]),
     "ws_fbank": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_int, c_int,

@@ -32,6 +32,34 @@ def load_wav(path: str, normalize: bool = False):
     return out, sr
 
 
+def load_pcm16_fast(source):
+    """Channel 0 of a RIFF/WAVE file (or bytes) as a 1-D numpy array + sample rate, for the batch driver's
+    decode threads: one read(), a chunk walk over the header, np.frombuffer on the data chunk -- 16-bit PCM
+    keeps its int16 samples (what load_wav(normalize=False) returns), other widths fall back to load_wav."""
+    import struct
+    if isinstance(source, (bytes, bytearray, memoryview)):
+        raw = bytes(source)
+    else:
+        with open(source, "rb") as f:
+            raw = f.read()
+    if len(raw) >= 12 and raw[:4] == b"RIFF" and raw[8:12] == b"WAVE":
+        pos, fmt = 12, None
+        while pos + 8 <= len(raw):
+            cid, size = raw[pos:pos + 4], struct.unpack_from("<I", raw, pos + 4)[0]
+            if cid == b"fmt ":
+                fmt = struct.unpack_from("<HHIIHH", raw, pos + 8)
+            elif cid == b"data":
+                if fmt is not None and fmt[0] == 1 and fmt[5] == 16 and fmt[1] >= 1:
+                    n = min(size, len(raw) - pos - 8) // (2 * fmt[1])
+                    data = np.frombuffer(raw, dtype="<i2", count=n * fmt[1], offset=pos + 8)
+                    return (data if fmt[1] == 1 else data[::fmt[1]].copy()), fmt[2]
+                break
+            pos += 8 + size + (size & 1)
+    import io
+    pcm, sr = load_wav(io.BytesIO(raw), normalize=False)
+    return pcm[0].numpy(), sr
+
+
 # ------------------------------------------------------------------------------------ resampling
 def resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
     """Filter bank of torchaudio.transforms.Resample's default method (sinc_interp_hann), the

@@ -40,8 +40,8 @@ import numpy as np
 import torch
 import yaml
 
-from . import parallel
-from .audio import load_wav
+from . import _lib, parallel
+from .audio import load_pcm16_fast
 from .kaldi_io import VectorWriter
 
 AUDIO_SUFFIXES = ("flac", "mp3", "m4a", "ogg", "opus", "wav", "wma")     # dataset/processor.py:33
@@ -62,15 +62,15 @@ def split_rule(n_lines, nj):
 
 
 def _read_audio_entry(wav):
-    """processor.parse_raw.read_audio (:129-136): a path, or a shell command ending in '|'."""
+    """processor.parse_raw.read_audio (:129-136): a path, or a shell command ending in '|'.
+    -> (1-D numpy samples of channel 0: int16 for PCM16 files, int16-range float32 otherwise; sample rate)"""
     if wav.endswith("|"):
-        data = subprocess.run(wav[:-1], shell=True, stdout=subprocess.PIPE, check=True).stdout
-        return load_wav(io.BytesIO(data), normalize=False)
-    return load_wav(wav, normalize=False)
+        return load_pcm16_fast(subprocess.run(wav[:-1], shell=True, stdout=subprocess.PIPE, check=True).stdout)
+    return load_pcm16_fast(wav)
 
 
 def iter_entries(data_type, lines):
-    """-> (key, loader) pairs in list order; loader() -> ((C, N) int16/float tensor, sample_rate).
+    """-> (key, loader) pairs in list order; loader() -> (1-D numpy samples of channel 0, sample_rate).
     raw: json lines {key, wav, spk} (processor.parse_raw); scp: `key path`; shard: tar files of
     key.wav/key.spk members (processor.tar_file_and_group) -- a shard's members are read when reached."""
     if data_type == "raw":
@@ -89,7 +89,7 @@ def iter_entries(data_type, lines):
                     if pos <= 0 or info.name[pos + 1:] not in AUDIO_SUFFIXES:
                         continue
                     data = tar.extractfile(info).read()
-                    yield info.name[:pos], (lambda d=data: load_wav(io.BytesIO(d), normalize=False))
+                    yield info.name[:pos], (lambda d=data: load_pcm16_fast(d))
     else:
         raise NotImplementedError("data_type %r (raw / scp / shard are on the MI355X path; 'feat' lists of "
                                   "precomputed Kaldi features are not)" % data_type)
@@ -103,13 +103,47 @@ def crop_start(key, data_len, chunk_len, seed):
 
 
 def random_chunk(pcm, key, chunk_len, seed):
-    """get_random_chunk: crop if long enough, else tile (`repeat`) and cut to chunk_len."""
+    """get_random_chunk: crop if long enough, else tile (`repeat` / np.tile) and cut to chunk_len.
+    pcm: 1-D numpy array or torch tensor."""
     n = pcm.shape[0]
     if n >= chunk_len:
         s = crop_start(key, n, chunk_len, seed)
         return pcm[s:s + chunk_len]
     reps = chunk_len // n + 1
-    return pcm.repeat(reps)[:chunk_len]
+    tiled = pcm.repeat(reps) if isinstance(pcm, torch.Tensor) else np.tile(pcm, reps)
+    return tiled[:chunk_len]
+
+
+# --------------------------------------------------------------------------- native wave-file loader
+def _c_paths(paths):
+    import ctypes
+    arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    return arr
+
+
+def probe_wavs(paths, threads=16):
+    """ws_wav_probe: (num_samples int32[n] (-1 = not a PCM16 RIFF file), sample_rate int32[n]) read by C++ threads."""
+    n = len(paths)
+    ns, sr = np.empty(n, np.int32), np.empty(n, np.int32)
+    if n:
+        rc = _lib.lib().ws_wav_probe(_c_paths(paths), n, int(threads), _lib.ptr(ns), _lib.ptr(sr))
+        if rc < 0:
+            _lib.check(rc, "ws_wav_probe")
+    return ns, sr
+
+
+def load_wav_rows(paths, dst, counts, starts=None, threads=16):
+    """ws_wav_load_rows: samples [starts[i], starts[i] + counts[i]) of file i into row i of the int16 host array /
+    tensor `dst` (n, stride), decoded by C++ threads (the call releases the GIL)."""
+    n = len(paths)
+    if not n:
+        return
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    st = None if starts is None else np.ascontiguousarray(starts, dtype=np.int32)
+    stride = int(dst.stride(0)) if isinstance(dst, torch.Tensor) else int(dst.strides[0] // 2)
+    _lib.check(_lib.lib().ws_wav_load_rows(_c_paths(paths), n, int(threads), _lib.ptr(dst), stride,
+                                           _lib.ptr(st) if st is not None else None, _lib.ptr(counts)),
+               "ws_wav_load_rows")
 
 
 # ------------------------------------------------------------------------------ the overlapped engine
@@ -122,23 +156,35 @@ class GpuExtractor:
         self.device = model.device
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.depth = depth
-        self._slots = [dict(pin=None, dev=None, ready=None, free=None) for _ in range(depth)]
+        self._slots = [dict(pin=None, dev=None, out=None, handle=None, free=None) for _ in range(depth)]
         self._turn = 0
         self.embed_dim = model.embed_dim
 
     supports_ragged = True
 
-    def submit(self, utts):
+    def submit_files(self, paths, counts, starts=None, threads=16):
+        """Enqueue one batch of PCM16 files: C++ threads (ws_wav_load_rows) decode samples
+        [starts[i], starts[i] + counts[i]) of file i straight into the pinned staging buffer."""
+        return self.submit(None, files=(paths, np.asarray(counts, dtype=np.int32), starts, threads))
+
+    def submit(self, utts, files=None):
         """Enqueue one batch (a list of 1-D waveforms, or a stacked (B, N) tensor); returns a handle whose
         .result() is the (B, E) numpy array.  Different lengths -> one padded ragged batch."""
         slot = self._slots[self._turn % self.depth]
         self._turn += 1
-        if isinstance(utts, torch.Tensor):
-            utts = list(utts)
-        lens = [int(u.shape[0]) for u in utts]
-        B, N = len(utts), max(lens)
+        if files is not None:
+            lens = [int(c) for c in files[1]]
+            utts = None
+            npdt = np.int16
+        else:
+            if isinstance(utts, torch.Tensor):
+                utts = list(utts.numpy())
+            utts = [u.numpy() if isinstance(u, torch.Tensor) else u for u in utts]
+            lens = [int(u.shape[0]) for u in utts]
+            npdt = np.int16 if all(u.dtype == np.int16 for u in utts) else np.float32
+        B, N = len(lens), max(lens)
         ragged = min(lens) != N
-        dtype = torch.int16 if all(u.dtype == torch.int16 for u in utts) else torch.float32
+        dtype = torch.int16 if npdt is np.int16 else torch.float32
         nbytes = B * N * (2 if dtype == torch.int16 else 4)   # 8- / 32-bit files arrive as int16-range floats
         if slot["free"] is not None:
             slot["free"].synchronize()                       # the forward that read this slot has finished
@@ -152,8 +198,12 @@ class GpuExtractor:
             with torch.cuda.stream(self.copy_stream):
                 slot["dev"] = torch.empty(slot["pin"].numel(), dtype=torch.uint8, device=self.device)
         pin = slot["pin"][:nbytes].view(dtype).view(B, N)
-        for b, u in enumerate(utts):                         # (padding bytes are never read by the kernels)
-            pin[b, :lens[b]].copy_(u)
+        if files is not None:
+            load_wav_rows(files[0], pin, files[1], files[2], files[3])
+        else:
+            pin_np = pin.numpy()                             # numpy row copies: ~10 us each (torch's: ~60)
+            for b, u in enumerate(utts):                     # (padding bytes are never read by the kernels)
+                pin_np[b, :lens[b]] = u
         dev = slot["dev"][:nbytes].view(dtype).view(B, N)
         with torch.cuda.stream(self.copy_stream):
             dev.copy_(pin, non_blocking=True)
@@ -167,11 +217,18 @@ class GpuExtractor:
             emb = self.model.extract(self.frontend, dev, window_type=self.window_type)
         slot["free"] = torch.cuda.Event()
         slot["free"].record(main)
-        out = torch.empty((B, self.embed_dim), dtype=torch.float32).pin_memory()
+        # pinned result buffer of the slot (pin_memory() costs ~10 ms per call: never per batch).  The previous
+        # batch of this slot may not have been collected yet: materialise it before its buffer is reused.
+        if slot["handle"] is not None:
+            slot["handle"].materialize()
+        if slot["out"] is None or slot["out"].shape[0] < B:
+            slot["out"] = torch.empty((max(B, 256), self.embed_dim), dtype=torch.float32).pin_memory()
+        out = slot["out"][:B]
         out.copy_(emb, non_blocking=True)
         done = torch.cuda.Event()
         done.record(main)
-        return _Pending(out, done)
+        slot["handle"] = _Pending(out, done)
+        return slot["handle"]
 
     def finish(self):
         torch.cuda.current_stream(self.device).synchronize()
@@ -180,11 +237,17 @@ class GpuExtractor:
 
 class _Pending:
     def __init__(self, out, event):
-        self._out, self._event = out, event
+        self._out, self._event, self._value = out, event, None
+
+    def materialize(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = self._out.numpy().copy()       # (the pinned buffer belongs to the slot)
+            self._out = None
+        return self._value
 
     def result(self):
-        self._event.synchronize()
-        return self._out.numpy()
+        return self.materialize()
 
 
 class HostExtractor:
@@ -195,7 +258,14 @@ class HostExtractor:
         self.fn, self.embed_dim, self.ragged_fn = fn, embed_dim, ragged_fn
         self.supports_ragged = ragged_fn is not None
 
+    def submit_files(self, paths, counts, starts=None, threads=4):
+        counts = np.asarray(counts, dtype=np.int32)
+        buf = np.zeros((len(paths), int(counts.max())), dtype=np.int16)
+        load_wav_rows(paths, buf, counts, starts, threads)
+        return self.submit([buf[b, :int(c)] for b, c in enumerate(counts)])
+
     def submit(self, utts):
+        utts = [torch.from_numpy(np.array(u)) if isinstance(u, np.ndarray) else u for u in utts]
         lens = [int(u.shape[0]) for u in utts]
         if min(lens) == max(lens):
             return _Done(np.asarray(self.fn(torch.stack(list(utts))), dtype=np.float32))
@@ -217,17 +287,22 @@ class _Done:
 
 
 # ------------------------------------------------------------------------------------- one job
-def _prefetch(pool, fn, items, depth):
-    """fn(item) results in item order with at most `depth` items decoded ahead of the consumer
-    (Executor.map would submit the whole list -- and hold every decoded waveform -- at once)."""
+def _prefetch(pool, fn, items, depth, chunk=32):
+    """fn(item) results in item order, computed on the pool in tasks of `chunk` items with at most `depth`
+    tasks ahead of the consumer (Executor.map would submit the whole list -- and hold every decoded waveform
+    -- at once; one future per file costs more Python time than decoding a PCM16 file does)."""
     from collections import deque
+    import itertools
     q = deque()
-    for it in items:
-        q.append(pool.submit(fn, it))
-        if len(q) >= depth:
-            yield q.popleft().result()
-    while q:
-        yield q.popleft().result()
+    it = iter(items)
+    while True:
+        group = list(itertools.islice(it, chunk))
+        if group:
+            q.append(pool.submit(lambda g=group: [fn(x) for x in g]))
+        if not group or len(q) >= depth:
+            if not q:
+                return
+            yield from q.popleft().result()
 
 
 def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=32240, max_batch=256,
@@ -243,7 +318,7 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
     Utterances waiting for a full bucket hold at most max_buffered_samples samples in host memory."""
     if whole_utt is None:
         whole_utt = batch_size == 1
-    keys, rows = [], {}
+    keys, done = [], []                # done: (indices, (b, E) array) per finished batch
     pending = []                       # (indices, handle)
     buckets = {}                       # (length, dtype) -> (indices, tensors)
     buffered = 0
@@ -251,11 +326,12 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
     def load(item):
         idx, (key, loader) = item
         pcm, sr = loader()
-        pcm = pcm[0]
+        if isinstance(pcm, torch.Tensor):                  # (C, N) tensors from custom loaders: channel 0
+            pcm = (pcm[0] if pcm.dim() == 2 else pcm).numpy()
         if sr != resample_rate:
             if resample_fn is None:
                 raise RuntimeError("%s is sampled at %d Hz, expected %d (no resampler given)" % (key, sr, resample_rate))
-            pcm = resample_fn(pcm, sr, resample_rate)
+            pcm = resample_fn(torch.from_numpy(np.ascontiguousarray(pcm)), sr, resample_rate).numpy()
         if not whole_utt:
             pcm = random_chunk(pcm, key, chunk_len, seed)
         return idx, key, pcm
@@ -275,17 +351,15 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
     def drain(keep):
         while len(pending) > keep:
             idxs, handle = pending.pop(0)
-            emb = handle.result()
-            for k, i in enumerate(idxs):
-                rows[i] = emb[k].copy()
+            done.append((idxs, np.asarray(handle.result(), dtype=np.float32)))
 
     workers = max(1, num_workers)
     with ThreadPoolExecutor(max_workers=workers) as pool:
         # file decode runs ahead of the GPU on the pool; results arrive in list order
-        for idx, key, pcm in _prefetch(pool, load, enumerate(entries), depth=4 * workers):
+        for idx, key, pcm in _prefetch(pool, load, enumerate(entries), depth=2 * workers + 2):
             keys.append(key)
             n = int(pcm.shape[0])
-            key = bucket_of(n, pcm.dtype)
+            key = bucket_of(n, pcm.dtype.str)
             b = buckets.setdefault(key, ([], []))
             b[0].append(idx)
             b[1].append(pcm)
@@ -299,14 +373,98 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
                     flush(length)
                     drain(keep=2)
                 buffered = 0
-        for length in sorted(buckets, key=lambda t: t[0]):
+        for length in sorted(buckets, key=lambda t: t[0], reverse=True):
             flush(length)
             drain(keep=2)
         drain(keep=0)
     extractor.finish()
-    n = len(keys)
-    emb = np.stack([rows[i] for i in range(n)]) if n else np.zeros((0, extractor.embed_dim), np.float32)
+    emb = np.zeros((len(keys), extractor.embed_dim), np.float32)
+    for idxs, block in done:
+        emb[np.asarray(idxs, dtype=np.int64)] = block
     return keys, emb
+
+
+def extract_files(keys, paths, extractor, batch_size=1, whole_utt=None, chunk_len=32240, max_batch=256,
+                  resample_rate=16000, threads=16, seed=0, length_tolerance=0.12):
+    """The same result as extract_entries for a list of wave FILES, with no per-file Python work: C++ threads
+    probe every header (ws_wav_probe), the batches are planned on the length array (numpy), and every batch is
+    decoded by C++ threads straight into the pinned staging buffer (ws_wav_load_rows) while the previous batch
+    computes.  Returns None when the list needs the general path (files that are not 16-bit PCM, another sample
+    rate, or -- in the random-crop mode -- files shorter than the crop, which are tiled there)."""
+    if whole_utt is None:
+        whole_utt = batch_size == 1
+    n = len(paths)
+    if n == 0:
+        return [], np.zeros((0, extractor.embed_dim), np.float32)
+    ns, sr = probe_wavs(paths, threads)
+    if (ns <= 0).any() or (sr != resample_rate).any():
+        return None
+    starts = None
+    if whole_utt:
+        counts = ns
+    else:
+        if (ns < chunk_len).any():
+            return None
+        counts = np.full(n, chunk_len, np.int32)
+        starts = np.array([crop_start(k, int(m), chunk_len, seed) for k, m in zip(keys, ns)], dtype=np.int32)
+    ragged_ok = whole_utt and getattr(extractor, "supports_ragged", False) and length_tolerance > 0
+    cls = (np.floor(np.log(np.maximum(counts, 1)) / np.log1p(length_tolerance)).astype(np.int64)
+           if ragged_ok else counts.astype(np.int64))
+    emb = np.zeros((n, extractor.embed_dim), np.float32)
+    pending = []
+
+    def drain(keep):
+        while len(pending) > keep:
+            idx, handle = pending.pop(0)
+            emb[idx] = handle.result()
+
+    order = np.argsort(cls, kind="stable")              # classes together, list order inside a class
+    bounds = np.flatnonzero(np.diff(cls[order])) + 1
+    # longest class first: the pinned / device staging buffers and the engine workspace are sized once, by the
+    # first batches, instead of being re-allocated (pin_memory: ~10 ms) every time a longer class arrives
+    for group in reversed(np.split(order, bounds)):
+        for b0 in range(0, len(group), max_batch):
+            idx = group[b0:b0 + max_batch]
+            handle = extractor.submit_files([paths[i] for i in idx], counts[idx],
+                                            None if starts is None else starts[idx], threads)
+            pending.append((idx, handle))
+            drain(keep=2)
+    drain(keep=0)
+    extractor.finish()
+    return list(keys), emb
+
+
+def split_path_list(data_type, lines):
+    """(keys, paths) of a raw / scp list whose entries are plain files, else None (pipes, shards)."""
+    keys, paths = [], []
+    try:
+        for line in lines:
+            if data_type == "raw":
+                obj = json.loads(line)
+                key, path = obj["key"], obj["wav"]
+            elif data_type == "scp":
+                key, path = line.strip().split(None, 1)
+            else:
+                return None
+            if path.endswith("|"):
+                return None
+            keys.append(key)
+            paths.append(path)
+    except (ValueError, KeyError):
+        return None
+    return keys, paths
+
+
+def extract_list(data_type, lines, extractor, **kw):
+    """extract_files when the list allows it, extract_entries otherwise (same result either way)."""
+    kp = split_path_list(data_type, lines)
+    if kp is not None and hasattr(extractor, "submit_files"):
+        fast = {k: v for k, v in kw.items() if k in ("batch_size", "whole_utt", "chunk_len", "max_batch",
+                                                       "resample_rate", "seed", "length_tolerance")}
+        out = extract_files(kp[0], kp[1], extractor, threads=max(4, 2 * int(kw.get("num_workers", 8))), **fast)
+        if out is not None:
+            return out
+    return extract_entries(iter_entries(data_type, lines), extractor, **kw)
 
 
 def write_ark_scp(keys, emb, embed_ark):
@@ -388,8 +546,8 @@ def extract(config="conf/config.yaml", **kwargs):
                                         max_batch=int(configs.get("max_batch", 256)),
                                         precision=configs.get("precision", "fp32"))
     lines = read_lists(configs["data_list"])
-    keys, emb = extract_entries(
-        iter_entries(configs["data_type"], lines), extractor, batch_size=batch_size,
+    keys, emb = extract_list(
+        configs["data_type"], lines, extractor, batch_size=batch_size,
         chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
         max_batch=int(configs.get("max_batch", 256)), resample_rate=fc["resample_rate"],
         num_workers=int(configs.get("num_workers", 4)), seed=int(configs.get("seed", 0)),
@@ -421,9 +579,9 @@ def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, b
             continue                                # `split` writes no file for an empty tail job
         if extractor is None:
             extractor = make_extractor()
-        keys, emb = extract_entries(iter_entries(data_type, lines[lo:hi]), extractor, batch_size=batch_size,
-                                    chunk_len=chunk_len, max_batch=max_batch, resample_rate=resample_rate,
-                                    num_workers=num_workers, seed=seed, resample_fn=resample_fn)
+        keys, emb = extract_list(data_type, lines[lo:hi], extractor, batch_size=batch_size,
+                                 chunk_len=chunk_len, max_batch=max_batch, resample_rate=resample_rate,
+                                 num_workers=num_workers, seed=seed, resample_fn=resample_fn)
         write_ark_scp(keys, emb, os.path.join(embed_dir, "xvector_%03d.ark" % j))
         my_keys.append((j, keys))
         my_emb.append((j, emb))
