@@ -1,7 +1,9 @@
 // Micro-probe: what keeps v_mfma_f32_32x32x2_f32 below its 64-cycle issue rate inside a GEMM loop?
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_f32_probe.hip -o tools/bin/mfma_f32_probe
 // variants: 0 registers only | 1 + LDS fragment reads (16 ds_read_b128 per 64 MFMAs) | 2 + a workgroup
-// barrier per 64 MFMAs | 3 + 8 ds_write_b128 per 64 MFMAs | 4 + 8 global_load_dwordx4 per 64 MFMAs
+// barrier per 64 MFMAs | 3 + 8 ds_write_b128 per 64 MFMAs | 4 + 8 global_load_dwordx4 per 64 MFMAs (1 KB
+// contiguous per wave instruction) | 5 the same loads with the GEMM's row-strided pattern (8 rows x 128 B per
+// wave instruction, 6 KB row stride, a new 128-row panel every 48 iterations)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +44,12 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, flo
             acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[in][s], fa[im][s], acc[im][in], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int i = s * 4 + im * 2 + in;
-            if (V >= 4 && grp == 0 && i < 8) ld[i] = *reinterpret_cast<const f32x4*>(gp + (size_t)it * 1024 * 256 + i * 64);
+            if (V == 4 && grp == 0 && i < 8) ld[i] = *reinterpret_cast<const f32x4*>(gp + (size_t)it * 1024 * 256 + i * 64);
+            if (V == 5 && grp == 0 && i < 8) {
+              const size_t panel = ((size_t)blockIdx.x * 37 + (size_t)(it / 48)) % 2000;
+              ld[i] = *reinterpret_cast<const f32x4*>(g + (panel * 128 + (size_t)(tid >> 3) + 32 * (i & 3)) * 1536 +
+                                                     (size_t)(it % 48) * 32 + (tid & 7) * 4 + (i >> 2) * 0);
+            }
             if (V >= 3 && grp == 2 && i < 8)
               *reinterpret_cast<f32x4*>(&lds[9216 + ((tid >> 3) + 32 * i) * 36 + (tid & 7) * 4]) = ld[i];
             __builtin_amdgcn_sched_barrier(0);
@@ -78,6 +85,7 @@ int main() {
   hipMemset(g, 0, (size_t)2100 * 1024 * 256 * 4 + (1 << 20));
   for (int bpc = 1; bpc <= 2; ++bpc) {
     run<0>(g, out, bpc); run<1>(g, out, bpc); run<2>(g, out, bpc); run<3>(g, out, bpc); run<4>(g, out, bpc);
+    run<5>(g, out, bpc);
   }
   return 0;
 }
