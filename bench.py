@@ -72,11 +72,12 @@ DTYPE_TEXT = {
 def kernel_text(model_name, prec):
     ecapa = model_name.startswith("ECAPA")
     if prec == "fp32":
-        return ("conv_gemm_kernel<128,128,2,2,...,PREC=0> (v_mfma_f32_32x32x2_f32, exact fp32 products) "
-                "+ its 64x64 tail launches: every conv/linear with N > 64")
+        return ("conv_gemm_dual_kernel<..,PREC=0> (whole rounds of 128x128 tiles + the 64x64 tiles of the remaining "
+                "rows in one grid; v_mfma_f32_32x32x2_f32, exact fp32 products) and conv_gemm_kernel<128,128,2,2,"
+                "..,PREC=0> where the tile count needs no remainder class: every conv/linear with N > 64")
     if prec == "f16x3":
-        return ("conv_gemm_kernel<128,128,2,2,...,PREC=1> (3 x v_mfma_f32_32x32x16_f16 on hi/lo binary16 "
-                "splits) + tail launches: every conv/linear with N > 64")
+        return ("conv_gemm_dual_kernel<..,PREC=1> / conv_gemm_kernel<128,128,2,2,..,PREC=1> (3 x "
+                "v_mfma_f32_32x32x16_f16 on hi/lo binary16 splits): every conv/linear with N > 64")
     if ecapa:
         return ("gemm_f16_p8_kernel (256x256 tile, two wave groups one barrier interval apart, "
                 "v_mfma_f32_32x32x16_f16, both binary16 operands staged by global_load_lds_dwordx4: the "

@@ -47,7 +47,7 @@ pmc() {  # prec, needle
   grep -E "traffic_bytes_per_launch|mfma_busy" "$OUT/${TAG}_pmc_dominant_kernel_$prec.json"
   rm -rf "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3"
 }
-pmc fp32 "conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
+pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
 pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64, 64"
 cd "$REPO"
 ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '
