@@ -191,6 +191,15 @@ WS_API int ws_engine_set_precision(ws_engine* eng, int mode);
  * returns WS_ERR_RANGE (message in ws_last_error) if any were produced since the last call, else WS_OK,
  * and clears the counter.  (The reference's fp32 path has no such limit: switch to WS_PREC_FP32.) */
 WS_API int ws_engine_check_range(ws_engine* eng, ws_stream stream);
+/* Diagnostic (no reference counterpart): which kernel every distinct conv / linear problem was given.  The
+ * dispatcher chooses among a dozen tile shapes and staging forms by shape and operand type; a layer that falls
+ * off the fast forms costs speed, never correctness, so nothing else would show it.  mode 0 off, 1 on, 2 on and
+ * forget what was noted (also: environment WS_DISPATCH_LOG=1 at load time).  The report is text, one line per
+ * distinct (problem, kernel) with its launch count; the call returns the bytes the whole report needs
+ * (including the terminator) and writes at most cap of them -- call with (NULL, 0) for the size.
+ * tests/golden/dispatch_*.txt pin the tables of the BASELINE models. */
+WS_API int ws_debug_dispatch_log(int mode);
+WS_API long long ws_debug_dispatch_report(char* buf, long long cap);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 

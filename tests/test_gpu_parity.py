@@ -1224,3 +1224,30 @@ def test_driver_batches_similar_lengths_through_the_ragged_path(tmp_path):
     ref = np.stack([oecapa.ecapa_forward(sd, ofbank.speaker_features(synth.synth_wav(900 + i, L))[None]).numpy()[0]
                     for i, L in enumerate(lengths)])
     assert _cos_err(emb, ref).max() < COS_TOL and _rel_err(emb, ref).max() < 5e-4
+
+
+# ------------------------------------------------------------------------------------------ dispatch tables
+def _dispatch_cases():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dispatch_tables
+    return dispatch_tables
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("prec", ["fp32", "f16"])
+def test_dispatch_tables_are_pinned(case, prec):
+    """Which kernel every conv / linear problem of the five BASELINE workloads is given
+    (ws_debug_dispatch_report) equals tests/golden/dispatch_<model>_<prec>.txt.  A layer that falls off the fast
+    kernels costs speed, not correctness: this is the test that makes it a reviewed change
+    (`python tools/dispatch_tables.py --write` regenerates the tables)."""
+    dt = _dispatch_cases()
+    model, E, batch, chunk = dt.CASES[case]
+    got = dt.table(model, E, batch, chunk, prec)
+    want = [l.rstrip("\n") for l in open(dt.golden_path(model, prec)) if l.strip()]
+    assert got == want, "dispatch of %s/%s changed:\n%s" % (
+        model, prec, "\n".join(sorted(set(got) ^ set(want))))
+    # and the log is really off again: nothing is noted by a later forward
+    from wespeaker_amd.engine import dispatch_report
+    assert dispatch_report() == []

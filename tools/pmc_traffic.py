@@ -30,9 +30,18 @@ def main():
     vals = collections.defaultdict(list)
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     names = set()
+    # whole forward: every wsamd:: dispatch, divided by the number of forwards (= fbank_kernel dispatches)
+    whole = collections.defaultdict(float)
+    forwards = collections.defaultdict(int)
+    launches = collections.defaultdict(int)
     for d in sys.argv[3:]:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
+                if "wsamd::" in r["Kernel_Name"]:
+                    whole[r["Counter_Name"]] += float(r["Counter_Value"])
+                    launches[r["Counter_Name"]] += 1
+                    if "fbank_kernel" in r["Kernel_Name"]:
+                        forwards[r["Counter_Name"]] += 1
                 if any(n in r["Kernel_Name"] for n in needles):
                     names.add(r["Kernel_Name"])
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -51,6 +60,12 @@ def main():
         out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
         out["note"] = ("gfx950: FETCH_SIZE reports half the bytes of wide coalesced streaming reads "
                        "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE uncalibrated, taken as is")
+    if whole.get("FETCH_SIZE") and whole.get("WRITE_SIZE") and forwards.get("FETCH_SIZE"):
+        nf = forwards["FETCH_SIZE"]
+        fb, wb = 2 * 1024 * whole["FETCH_SIZE"] / nf, 1024 * whole["WRITE_SIZE"] / forwards["WRITE_SIZE"]
+        out["whole_forward"] = {"forwards_profiled": nf, "kernel_launches_per_forward": launches["FETCH_SIZE"] / nf,
+                                "fetch_bytes_corrected_x2": fb, "write_bytes": wb, "traffic_bytes": fb + wb,
+                                "note": "all wsamd:: kernels of one fbank -> embedding pass at the bench batch"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
         # busy cycles are summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
         out["mfma_busy_fraction_of_cycles"] = (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (avg["GRBM_GUI_ACTIVE"] / 8.0)

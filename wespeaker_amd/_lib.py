@@ -46,6 +46,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "ws_engine_set_precision": (c_int, [c_void_p, c_int]),
     "ws_engine_check_range": (c_int, [c_void_p, c_void_p]),
+    "ws_debug_dispatch_log": (c_int, [c_int]),
+    "ws_debug_dispatch_report": (c_int64, [c_char_p, c_int64]),
     "ws_engine_profile_enable": (c_int, [c_void_p, c_int]),
     "ws_engine_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ws_engine_flops": (c_double, [c_void_p, c_int, c_int]),

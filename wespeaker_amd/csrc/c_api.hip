@@ -541,6 +541,18 @@ int ws_engine_check_range(ws_engine* eng, ws_stream stream) {
   return WS_OK;
 }
 
+int ws_debug_dispatch_log(int mode) {
+  if (mode < 0 || mode > 2) { set_error("ws_debug_dispatch_log: mode %d (0 off, 1 on, 2 on + clear)", mode); return WS_ERR_INVALID_ARG; }
+  dispatch_log_enable(mode != 0);
+  if (mode == 2) dispatch_log_clear();
+  return WS_OK;
+}
+
+long long ws_debug_dispatch_report(char* buf, long long cap) {
+  if (cap < 0 || (cap > 0 && !buf)) { set_error("ws_debug_dispatch_report: invalid argument"); return WS_ERR_INVALID_ARG; }
+  return (long long)dispatch_log_dump(buf, (size_t)cap);
+}
+
 int ws_engine_profile_enable(ws_engine* eng, int on) {
   if (!eng) { set_error("ws_engine_profile_enable: invalid argument"); return WS_ERR_INVALID_ARG; }
   eng->model->prof.enabled = on != 0;

@@ -18,6 +18,7 @@
 // wavefronts = 4 pixel groups x 2 output-channel halves, so that each wavefront's 36 weight fragments
 // (144 VGPRs) still live in registers; the two halves read the same activation fragments.
 #include "kernels.h"
+#include <cstdio>
 
 namespace wsamd {
 
@@ -223,6 +224,11 @@ static hipError_t launch_direct(const ConvGemmParams& p, hipStream_t stream) {
   const size_t by_regs = C == 32 ? 2 : 1;
   long long blocks = (long long)cus * (by_lds < by_regs ? by_lds : by_regs);
   if (blocks > total) blocks = total;
+  if (dispatch_log_enabled()) {
+    char k[64];
+    snprintf(k, sizeof(k), "conv3x3_direct_f16_kernel<%d,%d,%d>", C, SH, SW);
+    dispatch_log_note(p, k);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C == 32 ? 256 : 512), lds, stream, p, pyb, pxb,
                      (int)total);
   return hipGetLastError();

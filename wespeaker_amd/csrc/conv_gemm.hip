@@ -39,7 +39,69 @@
 //    partials.
 #include "kernels.h"
 
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
 namespace wsamd {
+
+// ------------------------------------------------------------------------------------- dispatch log
+namespace {
+std::atomic<int> g_dlog_on{-1};
+std::mutex g_dlog_mu;
+std::map<std::string, long> g_dlog;
+}  // namespace
+bool dispatch_log_enabled() {
+  int v = g_dlog_on.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* ev = getenv("WS_DISPATCH_LOG");
+    v = ev && atoi(ev) != 0;
+    g_dlog_on.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+void dispatch_log_enable(bool on) { g_dlog_on.store(on ? 1 : 0, std::memory_order_relaxed); }
+void dispatch_log_clear() {
+  std::lock_guard<std::mutex> lk(g_dlog_mu);
+  g_dlog.clear();
+}
+void dispatch_log_note(const ConvGemmParams& p, const char* kernel) {
+  char key[320];
+  // the problem as the dispatcher sees it: rows of this launch, N, K, taps / strides, back-end, operand forms,
+  // fused extras
+  snprintf(key, sizeof(key),
+           "rows=%d N=%d K=%d k=%dx%d s=%dx%d d=%dx%d prec=%d A=%s out=%s%s%s%s%s%s%s%s%s -> %s",
+           p.M - p.m_begin, p.N, p.K, p.kh, p.kw, p.stride_h, p.stride_w, p.dil_h, p.dil_w, p.prec,
+           p.A16 ? "f16" : "f32", p.D ? "f32" : "", p.D16 ? "f16" : "", p.A2 ? " +A2" : "",
+           p.pre_scale ? " +pre" : "", p.residual || p.residual16 ? " +res" : "", p.colsum ? " +colsum" : "",
+           p.pool_partial ? " +pool" : "", p.splitk > 1 ? " +splitk" : "", p.row_len ? " +mask" : "", kernel);
+  std::lock_guard<std::mutex> lk(g_dlog_mu);
+  ++g_dlog[key];
+}
+size_t dispatch_log_dump(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_dlog_mu);
+  size_t need = 0;
+  for (const auto& kv : g_dlog) {
+    char line[400];
+    const int n = snprintf(line, sizeof(line), "%s  x%ld\n", kv.first.c_str(), kv.second);
+    if (buf && need + (size_t)n < cap) memcpy(buf + need, line, (size_t)n);
+    need += (size_t)n;
+  }
+  if (buf && cap) buf[need < cap ? need : cap - 1] = 0;
+  return need + 1;
+}
+#define WS_DLOG(p, ...)                                         \
+  do {                                                          \
+    if (dispatch_log_enabled()) {                               \
+      char _k[96];                                              \
+      snprintf(_k, sizeof(_k), __VA_ARGS__);                    \
+      dispatch_log_note(p, _k);                                 \
+    }                                                           \
+  } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1300,6 +1362,7 @@ static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
+  WS_DLOG(p, "gemm_f16_dma_kernel<%d,%d,%d,%d%s>", BM, BN, BKT, NSTAGE, CONV ? ",conv" : "");
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * NW), lds_bytes, stream, p);
   return hipGetLastError();
 }
@@ -1677,6 +1740,7 @@ static hipError_t launch_f16_p8(const ConvGemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M - p.m_begin + 255) / 256, tiles_n = (p.N + 255) / 256;
   if (tiles_m <= 0) return hipSuccess;
+  WS_DLOG(p, "gemm_f16_p8_kernel<256,256%s>%s", CONV ? ",conv" : "", p.epi16 ? " epi16" : "");
   hipLaunchKernelGGL(gemm_f16_p8_kernel<CONV>, dim3(tiles_m * tiles_n), dim3(512), lds_bytes, stream, p);
   return hipGetLastError();
 }
@@ -1694,6 +1758,7 @@ static hipError_t launch_f16_fast(const ConvGemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
+  WS_DLOG(p, "gemm_f16_kernel<%d,%d,%s>", BM, BN, AF32 ? "A=f32" : "A=f16");
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds_bytes, stream, p);
   return hipGetLastError();
 }
@@ -1718,6 +1783,7 @@ static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
   dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1, 1);
+  WS_DLOG(p, "conv_gemm_kernel<%d,%d,%s>", BM, BN, SIMPLE ? "1x1" : (HAS_A2 ? "A2" : (HAS_PRE ? "pre" : "conv")));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds_bytes, stream, p);
   return hipGetLastError();
 }
@@ -1740,6 +1806,7 @@ static hipError_t launch_dual(ConvGemmParams p, int tail_begin, hipStream_t stre
   p.tail_begin = tail_begin;
   p.n_big = (tail_begin - p.m_begin) / 128 * tiles_n_big;
   const int n_small = (p.M - tail_begin + 63) / 64 * tiles_n_small;
+  WS_DLOG(p, "conv_gemm_dual_kernel<128,128 + 64,64,%s> big=%d small=%d", SIMPLE ? "1x1" : "conv", p.n_big, n_small);
   hipLaunchKernelGGL(kern, dim3(p.n_big + n_small), dim3(256), lds_bytes, stream, p);
   return hipGetLastError();
 }

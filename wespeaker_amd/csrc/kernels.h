@@ -71,6 +71,15 @@ struct ConvGemmParams {
 };
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 
+// Dispatch log (diagnostic, off by default; env WS_DISPATCH_LOG=1 or dispatch_log_enable): every kernel launch
+// of the conv-GEMM family notes (problem, kernel) once, so that "which kernel did this layer get" -- and a layer
+// that silently fell off the fast kernels -- can be read back (ws_debug_dispatch_report, tests/golden/dispatch_*).
+void dispatch_log_enable(bool on);
+bool dispatch_log_enabled();
+void dispatch_log_note(const ConvGemmParams& p, const char* kernel);
+size_t dispatch_log_dump(char* buf, size_t cap);      // text lines; returns the bytes the full report needs
+void dispatch_log_clear();
+
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
 

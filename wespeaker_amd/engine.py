@@ -125,6 +125,24 @@ def save_native_model(path, model_name, state_dict, feat_dim=80, embed_dim=None)
     return path
 
 
+def dispatch_log(on=True, clear=False):
+    """Diagnostic: start / stop noting which kernel every distinct conv / linear problem is given
+    (ws_debug_dispatch_log; process-wide).  `clear` forgets what was noted so far."""
+    _lib.check(_lib.lib().ws_debug_dispatch_log(2 if (on and clear) else (1 if on else 0)), "ws_debug_dispatch_log")
+    if clear and not on:
+        _lib.check(_lib.lib().ws_debug_dispatch_log(2), "ws_debug_dispatch_log")
+        _lib.check(_lib.lib().ws_debug_dispatch_log(0), "ws_debug_dispatch_log")
+
+
+def dispatch_report():
+    """The noted (problem -> kernel) table as sorted text lines (ws_debug_dispatch_report)."""
+    import ctypes
+    need = int(_lib.lib().ws_debug_dispatch_report(None, 0))
+    buf = ctypes.create_string_buffer(max(need, 1))
+    _lib.lib().ws_debug_dispatch_report(buf, need)
+    return [l for l in buf.value.decode().split("\n") if l]
+
+
 class NativeSpeakerModel:
     """The engine behind `Speaker.model`."""
 
