@@ -280,8 +280,16 @@ def main():
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fpmc:
                     pmc = json.load(fpmc)
-                roof["traffic"] = pmc.get("traffic_bytes_per_launch")
+                # per launch of THIS line's class: the counted kernels' bytes per forward / the launches per step
+                # counted here (the counter table also holds the two split-K dispatches of the embedding layers,
+                # which share the kernel name: bytes negligible, but they would dilute a per-dispatch average)
+                per_fwd = pmc.get("dominant_bytes_per_forward")
+                lps = g["launches"] / float(steps)             # launches of the class per step (= per forward)
+                roof["traffic"] = per_fwd / lps if per_fwd and lps else pmc.get("traffic_bytes_per_launch")
                 roof["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC)"
+                if "whole_forward" in pmc:
+                    roof["whole_forward_hbm_bytes"] = pmc["whole_forward"]["traffic_bytes"]
+                    roof["whole_forward_kernel_launches"] = pmc["whole_forward"]["kernel_launches_per_forward"]
                 roof["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
                 if "mfma_busy_fraction_of_cycles" in pmc:
                     roof["pmc_mfma_busy_fraction_of_cycles"] = pmc["mfma_busy_fraction_of_cycles"]

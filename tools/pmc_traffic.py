@@ -60,6 +60,11 @@ def main():
         out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
         out["note"] = ("gfx950: FETCH_SIZE reports half the bytes of wide coalesced streaming reads "
                        "(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE uncalibrated, taken as is")
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and forwards.get("FETCH_SIZE") and forwards.get("WRITE_SIZE"):
+        # the dominant kernels' bytes per forward: bench.py divides by ITS launches per step (the kernel names
+        # also match the two split-K dispatches of the embedding layers: bytes negligible, count not)
+        out["dominant_bytes_per_forward"] = (2 * 1024 * sum(vals["FETCH_SIZE"]) / forwards["FETCH_SIZE"] +
+                                             1024 * sum(vals["WRITE_SIZE"]) / forwards["WRITE_SIZE"])
     if whole.get("FETCH_SIZE") and whole.get("WRITE_SIZE") and forwards.get("FETCH_SIZE"):
         nf = forwards["FETCH_SIZE"]
         fb, wb = 2 * 1024 * whole["FETCH_SIZE"] / nf, 1024 * whole["WRITE_SIZE"] / forwards["WRITE_SIZE"]
