@@ -56,9 +56,10 @@ BACKENDS = ("fp32", "f16x3", "f16")
 DOMINANT = "gemm_main"              # profile class 0: every conv/linear GEMM launch with N > 64
 
 # per-GPU batch / engine chunk defaults: ECAPA = BASELINE configs[1]'s 256 x 2 s; the 2-D families get
-# what fills the chip at their row counts (ResNet221's 48-layer stage 3 keeps 64-utterance chunks)
+# what fills the chip at their row counts (ResNet221: 256-utterance chunks -- 64 left its ~300 launches per
+# forward latency-bound: 2034 -> 2264 utt/s fp32, 5131 -> 5933 f16; 512 adds 2-4 % for twice the workspace)
 DEFAULT_BATCH = {"ECAPA": (256, 256), "ResNet34": (512, 512), "ResNet18": (512, 512),
-                 "ResNe": (128, 64), "CAMPP": (512, 512)}
+                 "ResNe": (256, 256), "CAMPP": (512, 512)}
 EMBED_DIM = {"ECAPA": 192, "ResNe": 256, "CAMPP": 512}
 
 DTYPE_TEXT = {

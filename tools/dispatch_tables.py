@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 # (model, embed_dim, batch, engine chunk): bench.py's per-GPU workloads at 2 s (T = 198)
 CASES = [("ECAPA_TDNN_GLOB_c512", 192, 256, 256), ("ECAPA_TDNN_GLOB_c1024", 192, 256, 256),
-         ("ResNet34", 256, 512, 512), ("ResNet221", 256, 128, 64), ("CAMPPlus", 512, 512, 512)]
+         ("ResNet34", 256, 512, 512), ("ResNet221", 256, 256, 256), ("CAMPPlus", 512, 512, 512)]
 PRECISIONS = ("fp32", "f16")
 
 
