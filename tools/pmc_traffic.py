@@ -6,7 +6,7 @@ Run on the GPU box (counters in SEPARATE passes, kernel-trace only, as gpurun re
     cd /tmp && export TMPDIR=/tmp
     for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ; do
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$i -- \
-          python bench.py --precision f16 --steps 5 --warmup 2 --headline-only ; done
+          python bench.py --precision f16 --steps 3 --warmup 1 --windows 1 --headline-only [--model M] ; done
     python tools/pmc_traffic.py f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel" $OUT/pmc_* \
         > profiles/r01_pmc_dominant_kernel_f16.json
 
@@ -48,7 +48,7 @@ def main():
                     per_kernel[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     avg = {k: sum(v) / len(v) for k, v in vals.items()}
     out = {"command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --precision %s "
-                      "--steps 5 --warmup 2 --headline-only" % prec,
+                      "--steps 3 --warmup 1 --windows 1 --headline-only [--model M]" % prec,
            "kernel": sorted(names), "launches_profiled": max(len(v) for v in vals.values()),
            "counters_avg_per_launch": avg,
            "per_kernel": {k: {"dispatches": max(len(x) for x in c.values()),

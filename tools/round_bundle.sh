@@ -36,18 +36,23 @@ prof ResNet221_f16 --model ResNet221 --precision f16 --steps 5
 prof CAMPPlus_f16 --model CAMPPlus --precision f16 --steps 5
 prof CAMPPlus_fp32 --model CAMPPlus --precision fp32 --steps 5
 # PMC passes (counters in their own runs, kernel-trace only): HBM traffic + MFMA-busy of the dominant class
-pmc() {  # prec, needle
-  local prec=$1 needle=$2 i=0
+pmc() {  # prec, needle, [model]
+  local prec=$1 needle=$2 model=${3:-ECAPA_TDNN_GLOB_c512} i=0 tag=""
+  [ "$model" != "ECAPA_TDNN_GLOB_c512" ] && tag="_$model"
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     rm -rf "$OUT/pmc_${prec}_$i"
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${prec}_$i" -- python "$REPO/bench.py" --precision $prec --steps 5 --warmup 2 --windows 1 --headline-only > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${prec}_$i" -- python "$REPO/bench.py" --model $model --precision $prec --steps 3 --warmup 1 --windows 1 --headline-only > /dev/null 2>&1
   done
-  python "$REPO/tools/pmc_traffic.py" $prec "$needle" "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3" > "$OUT/${TAG}_pmc_dominant_kernel_$prec.json"
-  grep -E "traffic_bytes_per_launch|mfma_busy" "$OUT/${TAG}_pmc_dominant_kernel_$prec.json"
+  python "$REPO/tools/pmc_traffic.py" $prec "$needle" "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3" > "$OUT/${TAG}_pmc_dominant_kernel_$prec$tag.json"
+  grep -E "traffic_bytes_per_launch|mfma_busy|\"traffic_bytes\"" "$OUT/${TAG}_pmc_dominant_kernel_$prec$tag.json"
   rm -rf "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3"
 }
 pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
 pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64, 64"
+# the 2-D families: whole-forward HBM bytes tell whether their MFMA fraction is the binding limit at all
+pmc f16 "gemm_f16_dma_kernel|gemm_f16_p8_kernel|conv3x3_direct_f16_kernel" ResNet221
+pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel" ResNet34
+pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel" CAMPPlus
 cd "$REPO"
 ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '
