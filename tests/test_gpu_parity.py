@@ -1137,7 +1137,13 @@ RAGGED_CASES = [("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 399, 5, 201]),
                 ("ECAPA_TDNN_c1024", 192, [198, 64, 230, 131]),
                 ("ResNet34", 256, [198, 131, 9, 200, 64]),
                 ("ResNet221", 256, [150, 57, 98]),
-                ("CAMPPlus", 512, [603, 328, 201, 99, 57, 7])]
+                ("CAMPPlus", 512, [603, 328, 201, 99, 57, 7]),
+                # longer than the fused Res2 chain's 416-frame window (the 21-launch form) / many CAM segments:
+                # what a real VoxCeleb list (4 - 20 s utterances) looks like
+                ("ECAPA_TDNN_GLOB_c512", 192, [1203, 417, 798, 416, 500]),
+                ("ECAPA_TDNN_c1024", 192, [600, 450]),
+                ("ResNet34", 256, [1001, 640, 431]),
+                ("CAMPPlus", 512, [1500, 1001, 777])]
 
 
 @pytest.mark.parametrize("name,E,lens", RAGGED_CASES)
@@ -1251,3 +1257,20 @@ def test_dispatch_tables_are_pinned(case, prec):
     # and the log is really off again: nothing is noted by a later forward
     from wespeaker_amd.engine import dispatch_report
     assert dispatch_report() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "f16"])
+def test_one_minute_utterance(prec):
+    """A single 60 s utterance (T = 5998: 47 row tiles of one image, every per-utterance kernel on its long-loop
+    form, engine workspace grown from a 2 s finalisation) against the oracle."""
+    sd = synth.synth_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    model = _native("ECAPA_TDNN_GLOB_c512", sd, 192, max_batch=2, max_frames=198)
+    model.set_precision(prec)
+    f = np.random.RandomState(60).randn(1, 5998, 80).astype(np.float32)
+    out = model(torch.from_numpy(f))
+    got = (out[-1] if isinstance(out, tuple) else out).cpu().numpy()
+    ref = oecapa.ecapa_forward(sd, f).numpy()
+    assert _cos_err(got, ref).max() < COS_TOL
+    assert _rel_err(got, ref).max() < (REL_TOL if prec == "fp32" else F16_REL_TOL)
+    model.check_range()
