@@ -253,6 +253,42 @@ def test_native_wav_loader_rows_and_probe(tmp_path):
     assert r8 == 16000 and x8.dtype == np.float32 and x8.shape == (100,)          # falls back to load_wav
 
 
+def test_native_wav_loader_survives_damaged_files(tmp_path):
+    """Truncations at every header byte, random byte flips in the header and absurd chunk sizes: the C++ chunk walk
+    either reports the file as unusable (-1) or returns a sample count the file really holds -- it never reads past
+    what it was given and never crashes the process."""
+    good = str(tmp_path / "good.wav")
+    _write_riff(good, synth.synth_wav(9, 2000), extra_chunk=True)
+    raw = open(good, "rb").read()
+    hdr = len(raw) - 4000                       # bytes in front of the samples
+    paths, limits = [], []
+    for cut in list(range(0, hdr + 3)) + [hdr + 101, len(raw) - 1]:           # cut anywhere in / just behind the header
+        q = str(tmp_path / ("cut%d.wav" % cut))
+        open(q, "wb").write(raw[:cut])
+        paths.append(q); limits.append(max(0, cut - hdr) // 2)
+    rng = np.random.RandomState(3)
+    for k in range(200):                                                      # flipped header bytes
+        b = bytearray(raw)
+        for _ in range(rng.randint(1, 4)):
+            b[rng.randint(0, hdr)] = rng.randint(0, 256)
+        q = str(tmp_path / ("flip%d.wav" % k))
+        open(q, "wb").write(bytes(b))
+        paths.append(q); limits.append(len(raw) // 2)
+    for size in (0xffffffff, 0x7fffffff, 0x80000001, 3999, 4001):            # lying data-chunk sizes
+        b = bytearray(raw)
+        b[hdr - 4:hdr] = int(size).to_bytes(4, "little")
+        q = str(tmp_path / ("size%x.wav" % size))
+        open(q, "wb").write(bytes(b))
+        paths.append(q); limits.append(2000)
+    ns, _ = wx.probe_wavs(paths, threads=4)
+    for n, lim, q in zip(ns, limits, paths):
+        assert n == -1 or 0 <= n <= lim, (q, n, lim)
+    usable = [(q, int(n)) for q, n in zip(paths, ns) if n > 0]
+    assert usable                                                               # e.g. the lying sizes clamp to the file
+    buf = np.zeros((len(usable), 2000), np.int16)
+    wx.load_wav_rows([q for q, _ in usable], buf, [n for _, n in usable], threads=4)
+
+
 def test_file_fast_path_equals_the_general_path(tmp_path):
     """extract_files (native loader, batches planned on the probed lengths) == extract_entries, row for row, in
     both modes; lists it cannot take (pipes, shards, other formats / rates, crops of short files) fall back."""

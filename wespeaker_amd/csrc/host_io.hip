@@ -41,14 +41,16 @@ bool parse_header(int fd, long file_size, WavInfo* w) {
   for (;;) {
     unsigned char cbuf[24];
     const unsigned char* c;
+    long have = 24;                                 // bytes of this chunk (id, size, first 16 of the body) in hand
     if (pos + 24 <= got) c = h + pos;
     else {
-      if (pread(fd, cbuf, 24, pos) < 8) return false;
+      have = pread(fd, cbuf, 24, pos);
+      if (have < 8) return false;
       c = cbuf;
     }
     const unsigned size = c[4] | (c[5] << 8) | (c[6] << 16) | ((unsigned)c[7] << 24);
     if (std::memcmp(c, "fmt ", 4) == 0) {
-      if (size < 16) return false;
+      if (size < 16 || have < 24) return false;     // (a format chunk cut off by the end of the file)
       const unsigned char* b = c + 8;
       const int fmt = b[0] | (b[1] << 8), bits = b[14] | (b[15] << 8);
       w->channels = b[2] | (b[3] << 8);
