@@ -192,9 +192,22 @@ def main():
     wav = device_wavs(batch, num_samples, device, seed_base=rank)
     n_total = batch * world
 
+    # N > 1: the all_gather of step k is issued asynchronously (RCCL's own stream) and joined two steps later, so it
+    # overlaps the next forward and the ranks are not re-synchronised at every step; everything is joined
+    # before the closing fence of a timed window (`drain`), i.e. all K gathers lie inside the timed region
+    in_flight = []
+
     def step():
         emb = model.extract(fe, wav)                              # (B, E) on this GPU
-        return parallel.gather_rows(emb, n_total) if world > 1 else emb
+        if world == 1:
+            return emb
+        in_flight.append(parallel.gather_rows_async(emb, n_total))
+        return in_flight.pop(0).wait() if len(in_flight) > 2 else None
+
+    def drain(last):
+        while in_flight:
+            last = in_flight.pop(0).wait()
+        return last
 
     nccl = world > 1 and dist.get_backend() == "nccl"
 
@@ -221,6 +234,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
+        out = drain(out)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = model.profile_read()[DOMINANT]
@@ -231,6 +245,7 @@ def main():
         model.set_precision(prec)
         for _ in range(warmup):
             step()
+        drain(None)
         dts, profs, out = [], [], None
         for _ in range(windows):
             dt, prof, out = timed_window(steps)
@@ -242,6 +257,7 @@ def main():
         bsteps = min(steps, 5)
         for _ in range(bsteps):
             step()
+        drain(None)
         fence()
         breakdown = model.profile_read()
         model.profile(False)

@@ -76,7 +76,14 @@ def _gloo_worker(rank, world, port, n_total, q):
 
     out = parallel.extract_sharded(fake_extract, wavs, batch_size=3)
     expect = fake_extract(wavs)
-    q.put((rank, bool(torch.equal(out, expect)), tuple(out.shape)))
+    ok = bool(torch.equal(out, expect))
+    # the pipelined form bench.py --gpus N uses: several gathers in flight, joined in order
+    lo, hi = parallel.shard_range(n_total, rank, world)
+    pend = [parallel.gather_rows_async(fake_extract(wavs[lo:hi] + k), n_total) for k in range(4)]
+    for k, h in enumerate(pend):
+        ok = ok and bool(torch.equal(h.wait(), fake_extract(wavs + k)))
+        ok = ok and bool(torch.equal(h.wait(), fake_extract(wavs + k)))      # wait() twice is harmless
+    q.put((rank, ok, tuple(out.shape)))
     dist.barrier()
     dist.destroy_process_group()
 

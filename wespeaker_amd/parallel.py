@@ -71,6 +71,43 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     return out[:n_total]
 
 
+class PendingGather:
+    """Handle of gather_rows_async: wait() makes the CURRENT stream wait for the collective (no host block with
+    RCCL) and returns the full (n_total, E) tensor."""
+
+    def __init__(self, out, n_total, work=None):
+        self._out, self._n, self._work = out, n_total, work
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._out[:self._n]
+
+
+def gather_rows_async(local: torch.Tensor, n_total: int, group=None) -> PendingGather:
+    """gather_rows that does not put the collective on the critical path: with RCCL the all_gather is issued with
+    async_op=True on the process group's own stream (it waits for `local` by event), the caller's stream goes on
+    with the next batch and joins at PendingGather.wait().  A job that gathers every batch -- bench.py --gpus N,
+    a streaming server -- then overlaps the (latency-bound, few hundred KB) gather of batch k with the forward of
+    batch k + 1, and a slow rank delays its peers by at most the batches they keep in flight instead of at every
+    step.  (gloo with CUDA tensors -- the one-GPU debug path -- completes the gather before returning.)"""
+    if (not dist.is_initialized() or dist.get_world_size(group) == 1
+            or (dist.get_backend(group) == "gloo" and local.is_cuda)):
+        return PendingGather(gather_rows(local, n_total, group), n_total)
+    world = dist.get_world_size(group)
+    per = shard_size(n_total, world)
+    width = tuple(local.shape[1:])
+    if local.shape[0] == per:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((per,) + width, dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty((world * per,) + width, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, padded, group=group, async_op=True)
+    return PendingGather(out, n_total, work)
+
+
 def extract_sharded(extract_fn, wavs: torch.Tensor, batch_size: int = 256, group=None):
     """wavs: (N, samples) on every rank (or at least this rank's shard valid).  extract_fn maps a
     (b, samples) block to (b, E) embeddings on this rank's GPU.  Returns (N, E) on every rank."""
