@@ -51,10 +51,16 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   }
   __syncthreads();
 
-  const int co = wn * 16 + li;                          // this lane's output channel
+  // The weights are the MFMA's A operand and the activations its B operand (the same fragments: swapping the
+  // operands transposes the product), i.e. a wavefront computes a 16 (channels) x 16 (time steps) block of Y^T
+  // and a lane owns FOUR CONSECUTIVE CHANNELS (rows 4*lq .. 4*lq+3 of the C tile) of ONE time step (column li):
+  // next-split loads, output stores and the LDS write-back of the running activation are 16-byte vectors
+  // instead of four scalar accesses per accumulator (28 scalar 4-B global stores per lane and step before).
+  const int co = wn * 16 + li;                          // weight row of this lane's A fragment
+  const int c0 = wn * 16 + lq * 4;                      // first of the lane's 4 output channels
   constexpr bool PF = MTW <= 7;     // enough registers to prefetch the next split during the MFMAs
-  const int t0 = wm * MTW * 16 + lq * 4;
-  // weights of a step for column co: k = 16 g + 4 q + s   (packed [co][tap*W + ci], ld 3W)
+  const int tb = wm * MTW * 16 + li;                    // lane's time step inside row tile 0
+  // weights of a step for row co: k = 16 g + 4 q + s   (packed [co][tap*W + ci], ld 3W)
   f32x4 bw[KG];
   auto load_weights = [&](int step) {
     const float* wrow = p.w[step] + (long long)co * p.ldw + lq * 4;
@@ -63,19 +69,25 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   };
   load_weights(0);
   for (int step = 0; step < 7; ++step) {
-    const float bias = p.bias[step][co], sc = p.scale[step][co], sh = p.shift[step][co];
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[step] + c0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale[step] + c0);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift[step] + c0);
+    // The row strides are laundered through an empty asm so the per-tile addresses are recomputed inside
+    // the step instead of being hoisted out of the step loop (where they would live across the MFMA
+    // section and spill).
+    int ld1 = p.ldy1, ld2 = p.ldy2, xw = (tb + d) * XS + c0;
+    asm volatile("" : "+v"(ld1), "+v"(ld2), "+v"(xw));
     // next split of y1 (added to this step's output to form the next input): issued now, consumed
     // in the epilogue, so its latency hides under the MFMAs
-    float y1n[PF ? MTW : 1][4];
+    f32x4 y1n[PF ? MTW : 1];
     if (PF && step < 6) {
-      const float* y1u = p.y1 + m_base * p.ldy1 + (step + 1) * W + co;
+      const float* y1u = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int t = t0 + mt * 16 + r;
-          y1n[PF ? mt : 0][r] = t < T ? y1u[(long long)t * p.ldy1] : 0.f;
-        }
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int t = tb + mt * 16;
+        y1n[PF ? mt : 0] = t < T ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
+                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 
     f32x4 acc[MTW];
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
 
     // rows of this wave's tiles: t = (wm*MTW + mt)*16 + li ; X row = t + d + (tap-1)*d = t + tap*d.
     // Two row tiles at a time (independent accumulators hide the 40-cycle dependent-MFMA latency),
-    // A fragments software-pipelined one k-group ahead; sched_barrier keeps hipcc from hoisting
+    // activation fragments software-pipelined one k-group ahead; sched_barrier keeps hipcc from hoisting
     // every ds_read of the unrolled loop to the top (which spills).
     const float* xbase = &X[(wm * MTW * 16 + li) * XS + lq * 4];
     auto xaddr = [&](int mt, int g) {
@@ -105,9 +117,9 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bw[g][s], acc[mp], 0, 0, 0);
+          acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], a0[s], acc[mp], 0, 0, 0);
           if (two)
-            acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bw[g][s], acc[mp + 1], 0, 0, 0);
+            acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], a1[s], acc[mp + 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0; a1 = n1;
@@ -116,24 +128,21 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     // the weight registers are free now: fetch the next step's weights under the epilogue
     if (step < 6) load_weights(step + 1);
     __syncthreads();                                    // everyone finished reading X
-    // C/D layout 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    // The row strides are laundered through an empty asm so the 4*MTW row addresses are
-    // recomputed here instead of being hoisted out of the step loop (where they would live
-    // across the MFMA section and spill).
-    int ld1 = p.ldy1, ld2 = p.ldy2;
-    asm volatile("" : "+v"(ld1), "+v"(ld2));
-    const float* y1u = p.y1 + m_base * ld1 + (step + 1) * W + co;
-    float* y2u = p.y2 + m_base * ld2 + step * W + co;
+    // C/D layout 16x16: col = lane & 15 (time step), row = (lane >> 4) * 4 + reg (channel)
+    const float* y1e = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
+    float* y2u = p.y2 + (m_base + tb) * ld2 + step * W + c0;
+    float* xo = X + xw;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
+      const int t = tb + mt * 16;
+      if (t < T) {
+        f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = t0 + mt * 16 + r;
-        if (t < T) {
-          float v = relu_f(acc[mt][r] + bias) * sc + sh;
-          y2u[t * ld2] = v;
-          if (step < 6) X[(t + d) * XS + co] = v + (PF ? y1n[PF ? mt : 0][r] : y1u[t * ld1]);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = relu_f(acc[mt][r] + bias[r]) * sc[r] + sh[r];
+        *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
+        if (step < 6)
+          *reinterpret_cast<f32x4*>(xo + mt * 16 * XS) =
+              v + (PF ? y1n[PF ? mt : 0] : *reinterpret_cast<const f32x4*>(y1e + (long long)(mt * 16) * ld1));
       }
     }
     __syncthreads();
