@@ -629,6 +629,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
   }
 
   f32x4 ra[A_IT];
+  f32x4 ra2[HAS_A2 ? A_IT : 1];                       // second addend of the staged pieces (finish_piece)
+  f32x4 pre_s4 = {1.f, 1.f, 1.f, 1.f}, pre_t4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned pre_ok = 0;                                // bit i: piece i lies inside the image / K range
   f32x4 rw[PREC == 0 ? W_IT : 1];
   u32x4 rwh[PREC >= 1 ? W_IT : 1], rwl[PREC == 1 ? W_IT : 1];
   auto load_tile = [&](int kt) {
@@ -673,18 +676,28 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
       ra[i] = *reinterpret_cast<const f32x4*>(src);
       if (HAS_A2) {
         const float* src2 = ok ? p.A2 + pix * p.lda2 + p.a2_off + ci : p.zeros;
-        ra[i] += *reinterpret_cast<const f32x4*>(src2);
+        ra2[i] = *reinterpret_cast<const f32x4*>(src2);
       }
-      if (HAS_PRE) {
-        // ci < Cin is guaranteed when kok; clamp keeps the (discarded) tail loads in range
-        const int cc = kok ? ci : 0;
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.pre_scale + cc);
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.pre_shift + cc);
-        f32x4 v = ra[i] * s4 + t4;
+      if (HAS_PRE) pre_ok = ok ? (pre_ok | (1u << i)) : (pre_ok & ~(1u << i));
+    }
+    if (HAS_PRE) {
+      // ci < Cin is guaranteed when kok; clamp keeps the (discarded) tail loads in range
+      const int cc = kok ? ci : 0;
+      pre_s4 = *reinterpret_cast<const f32x4*>(p.pre_scale + cc);
+      pre_t4 = *reinterpret_cast<const f32x4*>(p.pre_shift + cc);
+    }
+  };
+  // Second addend / BN-ReLU pre-activation of staged piece i: applied when the piece is WRITTEN to LDS, not
+  // when it is requested -- done in load_tile, the first dependent VALU op waited for the global loads in front of
+  // the running tile's MFMAs (one exposed L2 / HBM round trip per K-tile in every A2 / PRE layer).
+  auto finish_piece = [&](int i) {
+    if (HAS_A2) ra[i] += ra2[i];
+    if (HAS_PRE) {
+      f32x4 v = ra[i] * pre_s4 + pre_t4;
+      const bool ok = (pre_ok >> i) & 1u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ok ? relu_f(v[q]) : 0.f;
-        ra[i] = v;
-      }
+      for (int q = 0; q < 4; ++q) v[q] = ok ? relu_f(v[q]) : 0.f;
+      ra[i] = v;
     }
   };
 
@@ -693,6 +706,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
   constexpr int STAGE_FLOATS =
       PREC == 0 ? (BM + BN) * S : (PREC == 1 ? (BM + BN) * HS : (BM + BN) * HS / 2);   // floats per buffer
   auto store_tile = [&](int buf) {
+    if (HAS_A2 || HAS_PRE) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) finish_piece(i);
+    }
     if (PREC == 0) {
       float* As = lds + buf * STAGE_FLOATS;
       float* Ws = As + BM * S;
@@ -868,7 +885,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
       float* As = lds + bufi * STAGE_FLOATS;
       float* Ws = As + BM * S;
       if (j < W_IT) *reinterpret_cast<f32x4*>(&Ws[(r0 + AROWS * j) * S + kc * 4]) = rw[j];
-      else if (j < NP) *reinterpret_cast<f32x4*>(&As[(r0 + AROWS * (j - W_IT)) * S + kc * 4]) = ra[j - W_IT];
+      else if (j < NP) {
+        if (HAS_A2 || HAS_PRE) finish_piece(j - W_IT);
+        *reinterpret_cast<f32x4*>(&As[(r0 + AROWS * (j - W_IT)) * S + kc * 4]) = ra[j - W_IT];
+      }
     };
     int buf = 0;
     if (kt_begin < kt_end) {
