@@ -606,6 +606,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
       sa_inc[i] = ok ? BK : 0;
     }
   }
+  // SIMPLE + PRE (pre-activated 1x1 layers, CAM++'s dense / transit layers): the BN vectors of this thread's
+  // four K columns run along with the rows
+  const float* sps_ptr = nullptr;
+  const float* spt_ptr = nullptr;
+  if (SIMPLE && HAS_PRE) {
+    sps_ptr = p.pre_scale + (long long)kt_begin * BK + kc * 4;
+    spt_ptr = p.pre_shift + (long long)kt_begin * BK + kc * 4;
+  }
   // running weight pointers (all modes): fp32 rows, or hi/lo half planes
   const float* sw_ptr[W_IT];
   const uint16_t* swh_ptr[W_IT];
@@ -632,6 +640,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
   f32x4 ra2[HAS_A2 ? A_IT : 1];                       // second addend of the staged pieces (finish_piece)
   f32x4 pre_s4 = {1.f, 1.f, 1.f, 1.f}, pre_t4 = {0.f, 0.f, 0.f, 0.f};
   unsigned pre_ok = 0;                                // bit i: piece i lies inside the image / K range
+  if (SIMPLE && HAS_PRE) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) pre_ok |= (m0 + r0 + AROWS * i < p.M) ? (1u << i) : 0u;
+  }
   f32x4 rw[PREC == 0 ? W_IT : 1];
   u32x4 rwh[PREC >= 1 ? W_IT : 1], rwl[PREC == 1 ? W_IT : 1];
   auto load_tile = [&](int kt) {
@@ -656,6 +668,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
       for (int i = 0; i < A_IT; ++i) {
         ra[i] = *reinterpret_cast<const f32x4*>(sa_ptr[i]);
         sa_ptr[i] += sa_inc[i];
+      }
+      if (HAS_PRE) {
+        pre_s4 = *reinterpret_cast<const f32x4*>(sps_ptr);
+        pre_t4 = *reinterpret_cast<const f32x4*>(spt_ptr);
+        sps_ptr += BK; spt_ptr += BK;
       }
       return;
     }
@@ -879,6 +896,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, float* l
       } else if (j < NP) {
         ra[j - W_IT] = *reinterpret_cast<const f32x4*>(sa_ptr[j - W_IT]);
         sa_ptr[j - W_IT] += sa_inc[j - W_IT];
+        if (HAS_PRE && j == W_IT) {
+          pre_s4 = *reinterpret_cast<const f32x4*>(sps_ptr);
+          pre_t4 = *reinterpret_cast<const f32x4*>(spt_ptr);
+          sps_ptr += BK; spt_ptr += BK;
+        }
       }
     };
     auto store_piece = [&](int bufi, int j) {
@@ -1803,7 +1825,8 @@ static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
   dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1, 1);
-  WS_DLOG(p, "conv_gemm_kernel<%d,%d,%s>", BM, BN, SIMPLE ? "1x1" : (HAS_A2 ? "A2" : (HAS_PRE ? "pre" : "conv")));
+  WS_DLOG(p, "conv_gemm_kernel<%d,%d,%s>", BM, BN,
+          SIMPLE ? (HAS_PRE ? "pre 1x1" : "1x1") : (HAS_A2 ? "A2" : (HAS_PRE ? "pre" : "conv")));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds_bytes, stream, p);
   return hipGetLastError();
 }
@@ -1838,6 +1861,9 @@ static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t str
     case 1: return launch_one<BM, BN, WM, WN, true, false, false, PREC>(p, stream);
     case 2: return launch_one<BM, BN, WM, WN, false, true, false, PREC>(p, stream);
     case 3: return launch_one<BM, BN, WM, WN, false, false, true, PREC>(p, stream);
+    case 4:   // pre-activated 1x1 layer: running pointers (instantiated for the two square tiles only)
+      if constexpr (BM == BN) return launch_one<BM, BN, WM, WN, false, true, true, PREC>(p, stream);
+      else return launch_one<BM, BN, WM, WN, false, true, false, PREC>(p, stream);
     default: return launch_one<BM, BN, WM, WN, false, false, false, PREC>(p, stream);
   }
 }
@@ -1852,7 +1878,9 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool simple = !p.pre_scale && !p.A2 && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                       p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K % BK == 0 &&
                       p.K == p.Cin;
-  const int mode = p.A2 ? 1 : (p.pre_scale ? 2 : (simple ? 3 : 0));
+  const bool simple_geom = p.kh == 1 && p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 &&
+                           p.pad_w == 0 && p.K % BK == 0 && p.K == p.Cin;
+  const int mode = p.A2 ? 1 : (p.pre_scale ? (simple_geom ? 4 : 2) : (simple ? 3 : 0));
   static int slots = 0;
   if (!slots) {
     int dev = 0, cus = 256;
