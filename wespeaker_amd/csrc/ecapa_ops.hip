@@ -134,22 +134,25 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  // FC1: hidden = relu(W1 mean + b1); 4 rows per wavefront pass (4 x C/256 loads in flight)
-  for (int j0 = wave * 4; j0 < bott; j0 += 32) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + j0);   // (not behind the lane-0 branch below)
+  // FC1: hidden = relu(W1 mean + b1); 8 rows per wavefront pass (8 x C/256 independent 16-B loads in flight:
+  // the kernel is a chain of L2 round trips, so fewer, wider passes -- 2 instead of 4 for bott = 128)
+  for (int j0 = wave * 8; j0 < bott; j0 += 64) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (bott % 32 == 0 on the host: a wave's 8 rows are all inside or all outside)
+    const f32x4 bias1a = *reinterpret_cast<const f32x4*>(b1 + j0);   // (not behind the lane-0 branch below)
+    const f32x4 bias1b = *reinterpret_cast<const f32x4*>(b1 + j0 + 4);
     for (int c = lane * 4; c < C; c += 256) {
       const f32x4 m = *reinterpret_cast<const f32x4*>(&mean[c]);
+      f32x4 w[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + (long long)(j0 + q) * C + c);
-        v[q] += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
-      }
+      for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(w1 + (long long)(j0 + q) * C + c);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += w[q][0] * m[0] + w[q][1] * m[1] + w[q][2] * m[2] + w[q][3] * m[3];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const float t = wave_sum(v[q]);
-      if (lane == 0) hidden[j0 + q] = relu_f(t + bias1[q]);
+      if (lane == 0) hidden[j0 + q] = relu_f(t + (q < 4 ? bias1a[q & 3] : bias1b[q & 3]));
     }
   }
   __syncthreads();
