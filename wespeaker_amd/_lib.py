@@ -5,7 +5,7 @@ The library is the product: if it is missing or fails to load, everything here r
 is no CPU / eager fallback."""
 import ctypes
 import os
-from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p)
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwespeaker_amd.so")

@@ -28,7 +28,6 @@ What is different by design (MI355X-first, not a translation):
 The random crops of the cohort mode use a seeded per-utterance generator (the reference draws from the
 unseeded global `random` in DataLoader workers, i.e. is not reproducible; the crop length rule is the same).
 """
-import io
 import json
 import os
 import subprocess
