@@ -201,12 +201,10 @@ static hipError_t launch_direct(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int NP = (IH * IW + PXP - 1) / PXP;
   constexpr size_t lds = 2 * (size_t)NP * 1024;
   auto kern = conv3x3_direct_f16_kernel<C, SH, SW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int images = p.M / (p.Hout * p.Wout);
   const int pyb = (p.Hout + PH - 1) / PH, pxb = (p.Wout + PW - 1) / PW;

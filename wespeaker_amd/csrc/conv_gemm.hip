@@ -1394,13 +1394,11 @@ void gemm_f16_dma_kernel(const ConvGemmParams p) {
 template <int BM, int BN, int BKT, int NSTAGE, int NW = (BM == 256 ? 8 : 4), int WM_ = 2, bool CONV = false>
 static hipError_t launch_f16_dma(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_dma_lds_bytes<BM, BN, BKT, NSTAGE, NW>();
-  static bool attr_set = false;
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
   auto kern = gemm_f16_dma_kernel<BM, BN, BKT, NSTAGE, NW, WM_, CONV>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
@@ -1773,12 +1771,10 @@ void gemm_f16_p8_kernel(const ConvGemmParams p) {
 template <bool CONV = false>
 static hipError_t launch_f16_p8(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_p8_lds_bytes();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_p8_kernel<CONV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f16_p8_kernel<CONV>), lds_bytes, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tiles_m = (p.M - p.m_begin + 255) / 256, tiles_n = (p.N + 255) / 256;
   if (tiles_m <= 0) return hipSuccess;
@@ -1790,13 +1786,11 @@ static hipError_t launch_f16_p8(const ConvGemmParams& p, hipStream_t stream) {
 template <int BM, int BN, bool AF32>
 static hipError_t launch_f16_fast(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t lds_bytes = f16_lds_bytes<BM, BN>();
-  static bool attr_set = false;
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
   auto kern = gemm_f16_kernel<BM, BN, 2, 2, AF32>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
@@ -1814,13 +1808,11 @@ static hipError_t launch_one(const ConvGemmParams& p, hipStream_t stream) {
   constexpr size_t pool_bytes = (size_t)BM * (64 * WM * WN) * 2;
   constexpr size_t max_bytes = base_bytes > pool_bytes ? base_bytes : pool_bytes;
   const size_t lds_bytes = p.pool_partial ? max_bytes : base_bytes;
-  static bool attr_set = false;
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
   auto kern = conv_gemm_kernel<BM, BN, WM, WN, HAS_A2, HAS_PRE, SIMPLE, PREC>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), max_bytes, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   if (tiles_m <= 0) return hipSuccess;
@@ -1837,13 +1829,11 @@ static hipError_t launch_dual(ConvGemmParams p, int tail_begin, hipStream_t stre
   constexpr size_t big = tile_lds_bytes<128, 128, PREC>(), pool = (size_t)128 * 256 * 2;
   constexpr size_t max_bytes = big > pool ? big : pool;
   const size_t lds_bytes = p.pool_partial ? max_bytes : big;
-  static bool attr_set = false;
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
   auto kern = conv_gemm_dual_kernel<HAS_A2, HAS_PRE, SIMPLE, PREC>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), max_bytes, lds_granted);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tiles_n_big = (p.N + 127) / 128, tiles_n_small = (p.N + 63) / 64;
   p.tail_begin = tail_begin;

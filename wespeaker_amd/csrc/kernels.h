@@ -7,6 +7,23 @@
 
 namespace wsamd {
 
+// Opt-in to more than 64 KB of dynamic LDS: hipFuncSetAttribute acts on the CURRENT device's copy of the kernel, so
+// "done" is remembered per (kernel, device) -- a per-kernel `static bool` let the second GPU of a process launch
+// without the attribute (one process per GPU is how this library is deployed, but the C-ABI takes a device index).
+// `granted[d]` = bytes already granted on device d; the launchers keep one such array per kernel instantiation.
+constexpr int WS_MAX_DEVICES = 64;
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, size_t (&granted)[WS_MAX_DEVICES]) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  size_t& g = granted[dev & (WS_MAX_DEVICES - 1)];
+  if (bytes <= g) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) g = bytes;
+  return e;
+}
+
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
 // ReLU with torch.relu's treatment of non-finite values: NaN stays NaN, +inf stays +inf (bit-identical

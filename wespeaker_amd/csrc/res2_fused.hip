@@ -336,12 +336,10 @@ static hipError_t launch_res2_f16_variant(const Res2ChainParams& p, hipStream_t 
   const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
                      (p.y2h ? (size_t)p.T * W * sizeof(_Float16) : 0);
   auto kern = res2_chain_f16x3_kernel<W, MTW>;
-  static size_t attr_bytes = 0;
-  if (lds > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
     if (e != hipSuccess) return e;
-    attr_bytes = lds;
   }
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
   return hipGetLastError();
@@ -352,12 +350,10 @@ static hipError_t launch_res2_variant(const Res2ChainParams& p, hipStream_t stre
   constexpr int MW = 8 / (W / 16);
   const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 8) * sizeof(float);
   auto kern = res2_chain_kernel<W, MTW>;
-  static size_t attr_bytes = 0;
-  if (lds > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
     if (e != hipSuccess) return e;
-    attr_bytes = lds;
   }
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
   return hipGetLastError();
