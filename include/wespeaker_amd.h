@@ -15,7 +15,10 @@
  *   - pointers marked DEVICE are HIP device pointers on the handle's device; HOST are host pointers.
  *   - all GPU work is enqueued on the caller's stream (a hipStream_t passed as void*; NULL = the
  *     default stream); no call synchronises the device unless documented.
- *   - one handle per (process, GPU); handles are not thread-safe.
+ *   - one handle per (process, GPU); handles are not thread-safe.  Every call that takes a handle makes the
+ *     handle's device the calling thread's current HIP device (hipSetDevice) and leaves it so; the handle-less
+ *     helpers (ws_cos_*, ws_cohort_stats, ws_asnorm_pairs, ws_plda_stats, ws_rows_affine, ws_resample) launch
+ *     on the calling thread's current device: make the device of their DEVICE pointers current first.
  */
 #ifndef WESPEAKER_AMD_H_
 #define WESPEAKER_AMD_H_

@@ -162,6 +162,7 @@ int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num
   const int T = ws_num_frames(num_samples, fe->sample_rate);
   if (T == 0 || batch == 0) return WS_OK;          // shorter than one frame: empty output
   hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(hipSetDevice(fe->device));
   WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, num_samples, wav_stride, scale,
                             window_type, T, feats, st));
   if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st));
@@ -354,6 +355,7 @@ int ws_forward(ws_engine* eng, const float* feats, int batch, int num_frames, fl
   }
   if (!eng->finalized) { set_error("ws_forward: engine not finalized"); return WS_ERR_STATE; }
   if (batch == 0) return WS_OK;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
   return eng->model->forward(feats, batch, num_frames, emb, (hipStream_t)stream);
 }
 
@@ -378,6 +380,7 @@ int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, 
   const int chunk = eng->model->max_batch();
   const size_t esz = wav_dtype == WS_WAV_INT16 ? 2 : 4;
   float* fw = eng->model->feats_workspace();
+  WS_HIP_CHECK(hipSetDevice(eng->device));
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int nb = batch - b0 < chunk ? batch - b0 : chunk;
     const char* w = reinterpret_cast<const char*>(wav) + (size_t)b0 * wav_stride * esz;
@@ -606,6 +609,7 @@ void ws_plda_destroy(ws_plda* plda) { delete plda; }
 static int plda_prepare(ws_plda* p, const void* emb, int is_f64, const int32_t* groups, int n_out,
                         const double* mean_vec, int pre_norm, double* out, hipStream_t st) {
   const double* mv = nullptr;
+  WS_HIP_CHECK(hipSetDevice(p->device));
   if (mean_vec) {
     WS_HIP_CHECK(hipMemcpyAsync(p->mean_vec.ptr, mean_vec, p->dim * sizeof(double),
                                 hipMemcpyHostToDevice, st));
@@ -665,6 +669,7 @@ struct PldaOps { const double* A; const double* Bm; const double* colc; int K; }
 static int plda_terms(ws_plda* p, const double* enroll, const int32_t* n_sessions, int n_uniform,
                       int n_enroll, const double* test, int n_test, hipStream_t st, PldaOps* ops) {
   const size_t D2 = 2 * (size_t)p->dim;
+  WS_HIP_CHECK(hipSetDevice(p->device));
   if ((size_t)n_enroll > p->cap_e) {
     WS_HIP_CHECK(hipStreamSynchronize(st));
     WS_HIP_CHECK(p->EA.alloc((size_t)n_enroll * D2 * sizeof(double)));
