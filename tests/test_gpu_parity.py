@@ -1274,3 +1274,17 @@ def test_one_minute_utterance(prec):
     assert _cos_err(got, ref).max() < COS_TOL
     assert _rel_err(got, ref).max() < (REL_TOL if prec == "fp32" else F16_REL_TOL)
     model.check_range()
+
+
+@pytest.mark.gpu
+def test_engine_chunk_beyond_32bit_offsets_is_refused():
+    """The binary16 convolution kernels address a tensor with 32-bit element offsets: an engine chunk whose
+    stage-1 activation map would pass 2^31 elements is refused at finalisation (WS_ERR_CAPACITY), not computed
+    wrongly; the same model with a sane chunk works."""
+    from wespeaker_amd._lib import NativeError
+    from wespeaker_amd.engine import NativeSpeakerModel
+    sd = synth.synth_state_dict("ResNet221", 80, 256, seed=42)
+    with pytest.raises(NativeError, match="2\\^31"):
+        NativeSpeakerModel("ResNet221", sd, feat_dim=80, embed_dim=256, max_batch=1100, max_frames=198)
+    m = NativeSpeakerModel("ResNet221", sd, feat_dim=80, embed_dim=256, max_batch=2, max_frames=198)
+    assert m.embed(torch.zeros(1, 198, 80, device="cuda")).shape == (1, 256)

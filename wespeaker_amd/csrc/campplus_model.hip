@@ -139,6 +139,12 @@ struct CamppModel : ModelBase {
     int err = 0;
     maxB = max_batch; maxT = max_frames;
     const size_t img = (size_t)maxB * feat_dim * maxT * 32;        // FCM full-resolution activation
+    // (32-bit element offsets in the binary16 convolution kernels: one engine chunk stays below 2^31 elements)
+    if (img >= (size_t)1 << 31) {
+      set_error("CAMPPlus: max_batch %d x max_frames %d puts %zu elements in one activation map (limit 2^31); "
+                "use a smaller engine chunk", max_batch, max_frames, img);
+      return WS_ERR_CAPACITY;
+    }
     const int Tp = (maxT - 1) / 2 + 1;
     const size_t Mp = (size_t)maxB * Tp;
     max_segs = (Tp + 99) / 100;

@@ -1889,8 +1889,13 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
                        (long long)p.N * p.ldw < (1LL << 31);
   const int rows = p.M - p.m_begin;             // rows this launch covers (m_begin > 0: a peeled tail)
   // f16 back-end, general convolution on binary16 activations: the DMA kernel in CONV form
+  // (32-bit element offsets again: the whole input tensor and the weight matrix must lie below 2^31 elements; the
+  // 2-D models refuse an engine chunk beyond that at reserve() -- ResNet221's 128-channel stage 1 reaches it at
+  // ~1060 two-second utterances -- so this is a second line of defence for direct callers)
+  const long long in_elems = (long long)(p.M / (p.Hout * p.Wout > 0 ? p.Hout * p.Wout : 1)) * p.Hin * p.Win * p.lda16;
   const bool conv16 = PREC == 2 && dma && p.A16 && !p.A2 && !p.pre_scale && !fast16 && p.splitk <= 1 &&
-                      (p.Cin & 7) == 0 && (p.lda16 & 7) == 0 && (p.a_off & 7) == 0 && !p.pool_partial;
+                      (p.Cin & 7) == 0 && (p.lda16 & 7) == 0 && (p.a_off & 7) == 0 && !p.pool_partial &&
+                      in_elems < (1LL << 31) && (long long)p.N * p.ldw < (1LL << 31);
   if (conv16) {
     // N <= 32 (ResNet stage 1, CAM++ head: K = 9 * 32): K-tile 32 divides K exactly, 10-KB stages
     // -> 4 stages and 4 workgroups per CU hide the DMA round trip

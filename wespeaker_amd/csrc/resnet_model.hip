@@ -121,6 +121,14 @@ struct ResNetModel : ModelBase {
     maxB = max_batch; maxT = max_frames;
     // largest activation: stage-1 output (F x T x 32*exp); scratch planes are never larger
     const size_t act = (size_t)maxB * feat_dim * maxT * (size_t)(32 * exp);
+    // (the binary16 convolution kernels address a tensor with 32-bit element offsets: one engine chunk keeps
+    // every activation map below 2^31 elements -- ~4200 x 2 s utterances for BasicBlock nets, ~1060 for
+    // Bottleneck nets; larger batches are processed in chunks anyway)
+    if (act >= (size_t)1 << 31) {
+      set_error("%s: max_batch %d x max_frames %d puts %zu elements in one activation map (limit 2^31); "
+                "use a smaller engine chunk", name.c_str(), max_batch, max_frames, act);
+      return WS_ERR_CAPACITY;
+    }
     size_t total = 0;
     auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
     size_t ob[4];
