@@ -11,6 +11,11 @@
 //    weight fragment uses the same k permutation, so the sum is over all k exactly once.
 //  * epilogue per step: + bias, ReLU, BN affine -> store sp_i to y2[:, i*w ...] and write
 //    sp_i + split_{i+1} back into X for the next step.
+//  * utterances longer than a workgroup's rows (224 at w = 64, 208 at w = 128) are cut into TIME TILES, one
+//    workgroup each: a tile owns `tile_rows` output rows and also carries a halo of 7 * d rows on each side,
+//    because step s needs rows t +- d of step s - 1: whatever is computed within s * d rows of the window edge
+//    is wrong, never stored, and after the seventh step still 0 rows short of the owned range.  (Before round 2
+//    such utterances -- anything beyond 4.2 s -- took 21 separate GEMM launches per block.)
 #include "kernels.h"
 
 namespace wsamd {
@@ -25,7 +30,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   constexpr int KG = 3 * W / 16;        // k groups of 16 per step
   extern __shared__ __attribute__((aligned(16))) float X[];
 
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / p.tiles, tile = blockIdx.x - b * p.tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % NT, wm = wave / NT;
   const int li = lane & 15, lq = lane >> 4;
@@ -33,20 +38,27 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   // ragged batch: rows [lens[b], p.T) of utterance b are padding -- never read, never written, and seen
   // by the dilated taps as the conv's zero padding (X stays zero there)
   const int T = p.lens ? p.lens[b] : p.T;
-  const int rows_total = MW * MTW * 16 + 2 * d;         // LDS rows incl. halo and row padding
+  constexpr int CAP = MW * MTW * 16;                    // rows a workgroup computes
+  const int rows_total = CAP + 2 * d;                   // LDS rows incl. the conv's zero padding
   const long long m_base = (long long)b * p.T;
+  // time tile: LDS row u <-> frame tbase + u; frames [own_lo, own_hi) are stored, the rest is halo
+  const int own_lo = tile * p.tile_rows;
+  const int own_hi = own_lo + p.tile_rows < T ? own_lo + p.tile_rows : T;
+  if (own_lo >= T) return;                              // (ragged batch: a tile beyond this utterance's end)
+  const int tbase = p.tiles > 1 ? own_lo - 7 * d : 0;
 
-  // zero the whole X once: halo rows and rows >= T stay zero for all steps
+  // zero the whole X once: padding rows and rows outside [0, T) stay zero for all steps
   for (int i = tid * 4; i < rows_total * XS; i += 512 * 4)
     *reinterpret_cast<f32x4*>(&X[i]) = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  // stage split 0: X[t + d][c] = y1[m][c]
+  // stage split 0: X[u + d][c] = y1[frame tbase + u][c]
   {
     constexpr int C4 = W / 4;
-    for (int i = tid; i < T * C4; i += 512) {
-      const int t = i / C4, c = (i - t * C4) * 4;
-      *reinterpret_cast<f32x4*>(&X[(t + d) * XS + c]) =
-          *reinterpret_cast<const f32x4*>(p.y1 + (m_base + t) * p.ldy1 + c);
+    for (int i = tid; i < CAP * C4; i += 512) {
+      const int u = i / C4, c = (i - u * C4) * 4, t = tbase + u;
+      if (t >= 0 && t < T)
+        *reinterpret_cast<f32x4*>(&X[(u + d) * XS + c]) =
+            *reinterpret_cast<const f32x4*>(p.y1 + (m_base + t) * p.ldy1 + c);
     }
   }
   __syncthreads();
@@ -81,12 +93,12 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     // in the epilogue, so its latency hides under the MFMAs
     f32x4 y1n[PF ? MTW : 1];
     if (PF && step < 6) {
-      const float* y1u = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
+      const float* y1u = p.y1 + (m_base + tbase + tb) * ld1 + (step + 1) * W + c0;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        const int t = tb + mt * 16;
-        y1n[PF ? mt : 0] = t < T ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
-                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int t = tbase + tb + mt * 16;
+        y1n[PF ? mt : 0] = (t >= 0 && t < T) ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
 
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // rows of this wave's tiles: t = (wm*MTW + mt)*16 + li ; X row = t + d + (tap-1)*d = t + tap*d.
+    // rows of this wave's tiles: u = (wm*MTW + mt)*16 + li ; X row = u + d + (tap-1)*d = u + tap*d.
     // Two row tiles at a time (independent accumulators hide the 40-cycle dependent-MFMA latency),
     // activation fragments software-pipelined one k-group ahead; sched_barrier keeps hipcc from hoisting
     // every ds_read of the unrolled loop to the top (which spills).
@@ -129,17 +141,17 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     if (step < 6) load_weights(step + 1);
     __syncthreads();                                    // everyone finished reading X
     // C/D layout 16x16: col = lane & 15 (time step), row = (lane >> 4) * 4 + reg (channel)
-    const float* y1e = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
-    float* y2u = p.y2 + (m_base + tb) * ld2 + step * W + c0;
+    const float* y1e = p.y1 + (m_base + tbase + tb) * ld1 + (step + 1) * W + c0;
+    float* y2u = p.y2 + (m_base + tbase + tb) * ld2 + step * W + c0;
     float* xo = X + xw;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const int t = tb + mt * 16;
-      if (t < T) {
+      const int t = tbase + tb + mt * 16;
+      if (t >= 0 && t < T) {
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = relu_f(acc[mt][r] + bias[r]) * sc[r] + sh[r];
-        *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
+        if (t >= own_lo && t < own_hi) *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
         if (step < 6)
           *reinterpret_cast<f32x4*>(xo + mt * 16 * XS) =
               v + (PF ? y1n[PF ? mt : 0] : *reinterpret_cast<const f32x4*>(y1e + (long long)(mt * 16) * ld1));
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   constexpr int KS = 3 * W / 32;        // 32-wide k-steps per conv step
   extern __shared__ __attribute__((aligned(16))) _Float16 Xs[];
 
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / p.tiles, tile = blockIdx.x - b * p.tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % NT, wm = wave / NT;
   const int li = lane & 15, lq = lane >> 4;
@@ -172,22 +184,29 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   // ragged batch: rows [lens[b], p.T) of utterance b are padding -- never read, never written, and seen
   // by the dilated taps as the conv's zero padding (X stays zero there)
   const int T = p.lens ? p.lens[b] : p.T;
-  const int rows_total = MW * MTW * 16 + 2 * d;
+  constexpr int CAP = MW * MTW * 16;
+  const int rows_total = CAP + 2 * d;
   _Float16* Xh = Xs;
   _Float16* Xl = Xs + rows_total * XS;
-  // binary16 output staging [T][W] (only when p.y2h is set): the step results leave the chip as
+  // binary16 output staging [owned rows][W] (only when p.y2h is set): the step results leave the chip as
   // coalesced 16-B stores of halfs instead of 4*MTW scalar 4-B stores per lane
   _Float16* Y16 = Xs + 2 * rows_total * XS;
   const bool half_out = p.y2h != nullptr;
   const long long m_base = (long long)b * p.T;
+  // time tile (see the fp32 kernel): LDS row u <-> frame tbase + u, frames [own_lo, own_hi) are stored
+  const int own_lo = tile * p.tile_rows;
+  const int own_hi = own_lo + p.tile_rows < T ? own_lo + p.tile_rows : T;
+  if (own_lo >= T) return;
+  const int tbase = p.tiles > 1 ? own_lo - 7 * d : 0;
 
   for (int i = tid * 8; i < 2 * rows_total * XS; i += 512 * 8)
     *reinterpret_cast<f16x8*>(&Xs[i]) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
   {
     constexpr int C4 = W / 4;
-    for (int i = tid; i < T * C4; i += 512) {
-      const int t = i / C4, c = (i - t * C4) * 4;
+    for (int i = tid; i < CAP * C4; i += 512) {
+      const int u = i / C4, c = (i - u * C4) * 4, t = tbase + u;
+      if (t < 0 || t >= T) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.y1 + (m_base + t) * p.ldy1 + c);
       f16x4 hi, lo;
 #pragma unroll
@@ -195,8 +214,8 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
         hi[q] = (_Float16)v[q];
         lo[q] = (_Float16)(v[q] - (float)hi[q]);
       }
-      *reinterpret_cast<f16x4*>(&Xh[(t + d) * XS + c]) = hi;
-      *reinterpret_cast<f16x4*>(&Xl[(t + d) * XS + c]) = lo;
+      *reinterpret_cast<f16x4*>(&Xh[(u + d) * XS + c]) = hi;
+      *reinterpret_cast<f16x4*>(&Xl[(u + d) * XS + c]) = lo;
     }
   }
   __syncthreads();
@@ -232,12 +251,12 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
     asm volatile("" : "+v"(ld1), "+v"(ld2), "+v"(xw));
     f32x4 y1n[PF ? MTW : 1];
     if (PF && step < 6) {
-      const float* y1u = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
+      const float* y1u = p.y1 + (m_base + tbase + tb) * ld1 + (step + 1) * W + c0;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        const int t = tb + mt * 16;
-        y1n[PF ? mt : 0] = t < T ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
-                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int t = tbase + tb + mt * 16;
+        y1n[PF ? mt : 0] = (t >= 0 && t < T) ? *reinterpret_cast<const f32x4*>(y1u + (long long)(mt * 16) * ld1)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
     f32x4 acc[MTW];
@@ -283,24 +302,26 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
     }
     if (step < 6) load_weights(step + 1);
     __syncthreads();
-    const float* y1e = p.y1 + (m_base + tb) * ld1 + (step + 1) * W + c0;
-    float* y2u = p.y2 + (m_base + tb) * ld2 + step * W + c0;
+    const float* y1e = p.y1 + (m_base + tbase + tb) * ld1 + (step + 1) * W + c0;
+    float* y2u = p.y2 + (m_base + tbase + tb) * ld2 + step * W + c0;
     _Float16* xh = Xh + xw;
     _Float16* xl = Xl + xw;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const int t = tb + mt * 16;
-      if (t < T) {
+      const int t = tbase + tb + mt * 16;
+      if (t >= 0 && t < T) {
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = relu_f(acc[mt][r] + bias[r]) * sc[r] + sh[r];
-        if (half_out) {
-          f16x4 hv;
+        if (t >= own_lo && t < own_hi) {
+          if (half_out) {
+            f16x4 hv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
-          *reinterpret_cast<f16x4*>(&Y16[t * W + c0]) = hv;
-        } else {
-          *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
+            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+            *reinterpret_cast<f16x4*>(&Y16[(t - own_lo) * W + c0]) = hv;
+          } else {
+            *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
+          }
         }
         if (step < 6) {
           const f32x4 x = v + (PF ? y1n[PF ? mt : 0]
@@ -320,8 +341,8 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
     if (half_out) {
       // (the next write to Y16 happens after the next step's mid barrier, i.e. after this copy)
       constexpr int C8 = W / 8;
-      uint16_t* dst = p.y2h + m_base * p.ldy2h + step * W;
-      for (int i = tid; i < T * C8; i += 512) {
+      uint16_t* dst = p.y2h + (m_base + own_lo) * p.ldy2h + step * W;
+      for (int i = tid; i < (own_hi - own_lo) * C8; i += 512) {
         const int t = i / C8, c = (i - t * C8) * 8;
         *reinterpret_cast<f16x8*>(dst + (long long)t * p.ldy2h + c) =
             *reinterpret_cast<const f16x8*>(&Y16[t * W + c]);
@@ -330,70 +351,73 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   }
 }
 
+// rows a workgroup of the <W, MTW> variant computes, and the rows a time tile owns at dilation d
+static constexpr int chain_cap(int W, int MTW) { return (8 / (W / 16)) * MTW * 16; }
+static int chain_mtw(int W) { return W == 64 ? 7 : 13; }
+// tiles per utterance / owned rows per tile for frames T (whole utterance in one workgroup when it fits)
+static void chain_tiling(int W, int T, int dil, int* tiles, int* tile_rows) {
+  const int cap = chain_cap(W, chain_mtw(W));
+  if (T <= cap) { *tiles = 1; *tile_rows = cap; return; }
+  const int own = cap - 2 * 7 * dil;
+  *tiles = (T + own - 1) / own;
+  *tile_rows = own;
+}
+
 template <int W, int MTW>
-static hipError_t launch_res2_f16_variant(const Res2ChainParams& p, hipStream_t stream) {
-  constexpr int MW = 8 / (W / 16);
-  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
-                     (p.y2h ? (size_t)p.T * W * sizeof(_Float16) : 0);
+static hipError_t launch_res2_f16_variant(Res2ChainParams p, hipStream_t stream) {
+  chain_tiling(W, p.T, p.dil, &p.tiles, &p.tile_rows);
+  const int own = p.tiles > 1 ? p.tile_rows : p.T;
+  const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
+                     (p.y2h ? (size_t)own * W * sizeof(_Float16) : 0);
   auto kern = res2_chain_f16x3_kernel<W, MTW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles), dim3(512), lds, stream, p);
   return hipGetLastError();
 }
 
 template <int W, int MTW>
-static hipError_t launch_res2_variant(const Res2ChainParams& p, hipStream_t stream) {
-  constexpr int MW = 8 / (W / 16);
-  const size_t lds = (size_t)(MW * MTW * 16 + 2 * p.dil) * (W + 8) * sizeof(float);
+static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
+  chain_tiling(W, p.T, p.dil, &p.tiles, &p.tile_rows);
+  const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 8) * sizeof(float);
   auto kern = res2_chain_kernel<W, MTW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(p.B), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tiles), dim3(512), lds, stream, p);
   return hipGetLastError();
 }
 
-// binary16 output staging ([T][W] halfs on top of the hi/lo activation planes) must fit the 160 KB LDS
+// binary16 output staging ([owned rows][W] halfs on top of the hi/lo activation planes) must fit the 160 KB LDS
 bool res2_half_out_supported(int W, int T, int dil) {
   if (!res2_chain_supported(W, T, dil)) return false;
-  const int mtw = W == 64 ? (T <= 2 * 7 * 16 ? 7 : 13) : 13;
-  const int mw = 8 / (W / 16);
-  const size_t lds = (size_t)(mw * mtw * 16 + 2 * dil) * (W + 16) * 2 * 2 + (size_t)T * W * 2;
+  int tiles, own;
+  chain_tiling(W, T, dil, &tiles, &own);
+  if (tiles == 1) own = T;
+  const size_t lds = (size_t)(chain_cap(W, chain_mtw(W)) + 2 * dil) * (W + 16) * 2 * 2 + (size_t)own * W * 2;
   return lds <= 160 * 1024;
 }
 
+// any length: utterances beyond one workgroup's rows run as time tiles with a 7 * dil halo
 bool res2_chain_supported(int W, int T, int dil) {
-  if (W == 64) return T <= 2 * 13 * 16 && (size_t)(2 * 13 * 16 + 2 * dil) * 72 * 4 <= 160 * 1024;
-  if (W == 128) return T <= 13 * 16;
-  return false;
+  if (W != 64 && W != 128) return false;
+  return T >= 1 && dil >= 1 && chain_cap(W, chain_mtw(W)) - 2 * 7 * dil >= 32;
 }
 
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
   if (p.y2h && (p.prec < 1 || (p.ldy2h & 7))) return hipErrorInvalidValue;
+  if (!res2_chain_supported(p.W, p.T, p.dil)) return hipErrorInvalidValue;
   if (p.prec >= 1) {   // (the f16 mode reuses the split kernel: more precise, same launch count)
-    if (p.W == 64) {
-      if (p.T <= 2 * 7 * 16) return launch_res2_f16_variant<64, 7>(p, stream);
-      if (p.T <= 2 * 13 * 16) return launch_res2_f16_variant<64, 13>(p, stream);
-    } else if (p.W == 128) {
-      if (p.T <= 13 * 16) return launch_res2_f16_variant<128, 13>(p, stream);
-    }
-    return hipErrorInvalidValue;
+    return p.W == 64 ? launch_res2_f16_variant<64, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
   }
-  if (p.W == 64) {
-    if (p.T <= 2 * 7 * 16) return launch_res2_variant<64, 7>(p, stream);
-    if (p.T <= 2 * 13 * 16) return launch_res2_variant<64, 13>(p, stream);
-  } else if (p.W == 128) {
-    if (p.T <= 13 * 16) return launch_res2_variant<128, 13>(p, stream);
-  }
-  return hipErrorInvalidValue;
+  return p.W == 64 ? launch_res2_variant<64, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
 }
 
 }  // namespace wsamd
