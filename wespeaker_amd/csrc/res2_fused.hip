@@ -17,6 +17,7 @@
 //    is wrong, never stored, and after the seventh step still 0 rows short of the owned range.  (Before round 2
 //    such utterances -- anything beyond 4.2 s -- took 21 separate GEMM launches per block.)
 #include "kernels.h"
+#include <cstdlib>
 
 namespace wsamd {
 
@@ -351,21 +352,41 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
   }
 }
 
-// rows a workgroup of the <W, MTW> variant computes, and the rows a time tile owns at dilation d
+// rows a workgroup of the <W, MTW> variant computes
 static constexpr int chain_cap(int W, int MTW) { return (8 / (W / 16)) * MTW * 16; }
-static int chain_mtw(int W) { return W == 64 ? 7 : 13; }
+// the two window sizes per width: the big one for full batches, the small one (128 / 112 rows) when the batch
+// would leave most CUs idle -- a chain is 7 serial steps of ~10 us whatever the batch, so a lone utterance is
+// spread over three or four workgroups instead of one
+static int chain_mtw(int W, bool small) { return W == 64 ? (small ? 4 : 7) : (small ? 7 : 13); }
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  return cus;
+}
 // tiles per utterance / owned rows per tile for frames T (whole utterance in one workgroup when it fits)
-static void chain_tiling(int W, int T, int dil, int* tiles, int* tile_rows) {
-  const int cap = chain_cap(W, chain_mtw(W));
+static void chain_tiling_for(int cap, int T, int dil, int* tiles, int* tile_rows) {
   if (T <= cap) { *tiles = 1; *tile_rows = cap; return; }
   const int own = cap - 2 * 7 * dil;
   *tiles = (T + own - 1) / own;
   *tile_rows = own;
 }
+// small windows when the big ones would occupy at most a quarter of the chip (env WS_CHAIN_SMALL=0/1 forces)
+static bool chain_use_small(int W, int B, int T, int dil) {
+  static int forced = -2;
+  if (forced == -2) { const char* ev = getenv("WS_CHAIN_SMALL"); forced = ev ? atoi(ev) : -1; }
+  if (forced >= 0) return forced != 0;
+  int tiles, own;
+  chain_tiling_for(chain_cap(W, chain_mtw(W, false)), T, dil, &tiles, &own);
+  return (long long)B * tiles * 4 <= device_cus();
+}
 
 template <int W, int MTW>
 static hipError_t launch_res2_f16_variant(Res2ChainParams p, hipStream_t stream) {
-  chain_tiling(W, p.T, p.dil, &p.tiles, &p.tile_rows);
+  chain_tiling_for(chain_cap(W, MTW), p.T, p.dil, &p.tiles, &p.tile_rows);
   const int own = p.tiles > 1 ? p.tile_rows : p.T;
   const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
                      (p.y2h ? (size_t)own * W * sizeof(_Float16) : 0);
@@ -381,7 +402,7 @@ static hipError_t launch_res2_f16_variant(Res2ChainParams p, hipStream_t stream)
 
 template <int W, int MTW>
 static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
-  chain_tiling(W, p.T, p.dil, &p.tiles, &p.tile_rows);
+  chain_tiling_for(chain_cap(W, MTW), p.T, p.dil, &p.tiles, &p.tile_rows);
   const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 8) * sizeof(float);
   auto kern = res2_chain_kernel<W, MTW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
@@ -394,19 +415,21 @@ static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
 }
 
 // binary16 output staging ([owned rows][W] halfs on top of the hi/lo activation planes) must fit the 160 KB LDS
+// (checked for the big windows: the small ones need less)
 bool res2_half_out_supported(int W, int T, int dil) {
   if (!res2_chain_supported(W, T, dil)) return false;
   int tiles, own;
-  chain_tiling(W, T, dil, &tiles, &own);
+  const int cap = chain_cap(W, chain_mtw(W, false));
+  chain_tiling_for(cap, T, dil, &tiles, &own);
   if (tiles == 1) own = T;
-  const size_t lds = (size_t)(chain_cap(W, chain_mtw(W)) + 2 * dil) * (W + 16) * 2 * 2 + (size_t)own * W * 2;
+  const size_t lds = (size_t)(cap + 2 * dil) * (W + 16) * 2 * 2 + (size_t)own * W * 2;
   return lds <= 160 * 1024;
 }
 
 // any length: utterances beyond one workgroup's rows run as time tiles with a 7 * dil halo
 bool res2_chain_supported(int W, int T, int dil) {
   if (W != 64 && W != 128) return false;
-  return T >= 1 && dil >= 1 && chain_cap(W, chain_mtw(W)) - 2 * 7 * dil >= 32;
+  return T >= 1 && dil >= 1 && chain_cap(W, chain_mtw(W, true)) - 2 * 7 * dil >= 32;
 }
 
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
@@ -414,10 +437,13 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
   if (p.y2h && (p.prec < 1 || (p.ldy2h & 7))) return hipErrorInvalidValue;
   if (!res2_chain_supported(p.W, p.T, p.dil)) return hipErrorInvalidValue;
+  const bool small = chain_use_small(p.W, p.B, p.T, p.dil);
   if (p.prec >= 1) {   // (the f16 mode reuses the split kernel: more precise, same launch count)
-    return p.W == 64 ? launch_res2_f16_variant<64, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
+    if (p.W == 64) return small ? launch_res2_f16_variant<64, 4>(p, stream) : launch_res2_f16_variant<64, 7>(p, stream);
+    return small ? launch_res2_f16_variant<128, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
   }
-  return p.W == 64 ? launch_res2_variant<64, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
+  if (p.W == 64) return small ? launch_res2_variant<64, 4>(p, stream) : launch_res2_variant<64, 7>(p, stream);
+  return small ? launch_res2_variant<128, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
 }
 
 }  // namespace wsamd
