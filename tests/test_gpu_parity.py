@@ -1288,3 +1288,44 @@ def test_engine_chunk_beyond_32bit_offsets_is_refused():
         NativeSpeakerModel("ResNet221", sd, feat_dim=80, embed_dim=256, max_batch=1100, max_frames=198)
     m = NativeSpeakerModel("ResNet221", sd, feat_dim=80, embed_dim=256, max_batch=2, max_frames=198)
     assert m.embed(torch.zeros(1, 198, 80, device="cuda")).shape == (1, 256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "f16"])
+def test_res2_time_tiles_are_bit_identical_to_whole_utterance_windows(tmp_path, prec):
+    """The fused Res2 chain cuts an utterance into time tiles with a 7 * dilation halo when it is longer than a
+    workgroup's rows or when the batch is small (res2_fused.hip).  A tile computes its owned rows from exactly the
+    same operands in the same order as the whole-utterance window does, so the embeddings must be IDENTICAL bit for
+    bit whichever form runs: small windows (WS_CHAIN_SMALL=1: three tiles per 198-frame utterance, five at 301)
+    against big ones (=0), in two processes because the switch is read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "from wespeaker_amd import NativeSpeakerModel\n"
+        "from fixtures import synth\n"
+        "out = {}\n"
+        "for name, E in (('ECAPA_TDNN_GLOB_c512', 192), ('ECAPA_TDNN_c1024', 192)):\n"
+        "    sd = synth.synth_state_dict(name, 80, E, seed=42)\n"
+        "    m = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=E, max_batch=4, max_frames=301)\n"
+        "    m.set_precision(sys.argv[2])\n"
+        "    for T in (198, 301, 57):\n"
+        "        f = torch.from_numpy(np.random.RandomState(T).randn(3, T, 80).astype(np.float32)).cuda()\n"
+        "        out['%s_%d' % (name, T)] = m.embed(f).cpu().numpy()\n"
+        "    lens = [301, 120, 250]\n"
+        "    f = torch.from_numpy(np.random.RandomState(9).randn(3, 301, 80).astype(np.float32)).cuda()\n"
+        "    out[name + '_ragged'] = m.embed_ragged(f, lens).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = []
+    for small in ("0", "1"):
+        path = str(tmp_path / ("small%s.npz" % small))
+        env = dict(os.environ, PYTHONPATH=root, WS_CHAIN_SMALL=small)
+        r = subprocess.run([sys.executable, "-c", code, path, prec], env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        res.append(np.load(path))
+    assert sorted(res[0].files) == sorted(res[1].files) and len(res[0].files) == 8
+    for k in res[0].files:
+        assert np.isfinite(res[0][k]).all()
+        assert np.array_equal(res[0][k], res[1][k]), (k, np.abs(res[0][k] - res[1][k]).max())
