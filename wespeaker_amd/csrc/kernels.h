@@ -115,6 +115,9 @@ struct Res2ChainParams {
   int prec;                                 // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
   const int* lens;                          // optional [B]: valid frames per utterance (<= T); rows beyond
                                             // are padding (ragged batch)
+  int y2h_direct;                           // set by launch_res2_chain: the binary16 rows go to y2h as 8-byte
+                                            // stores from the accumulators (no LDS staging: it does not fit
+                                            // beside the w = 128 activation planes)
   int tiles, tile_rows;                     // set by launch_res2_chain: time tiles per utterance (1 = the whole
                                             // utterance in one workgroup) and the rows each tile OWNS; a tile
                                             // also recomputes a halo of 7 * dil rows on each side

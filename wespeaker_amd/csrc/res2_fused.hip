@@ -319,7 +319,10 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
             f16x4 hv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
-            *reinterpret_cast<f16x4*>(&Y16[(t - own_lo) * W + c0]) = hv;
+            if (p.y2h_direct)
+              *reinterpret_cast<f16x4*>(p.y2h + (m_base + t) * p.ldy2h + step * W + c0) = hv;
+            else
+              *reinterpret_cast<f16x4*>(&Y16[(t - own_lo) * W + c0]) = hv;
           } else {
             *reinterpret_cast<f32x4*>(y2u + (long long)(mt * 16) * ld2) = v;
           }
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(512) void res2_chain_f16x3_kernel(const Res2ChainPa
       }
     }
     __syncthreads();
-    if (half_out) {
+    if (half_out && !p.y2h_direct) {
       // (the next write to Y16 happens after the next step's mid barrier, i.e. after this copy)
       constexpr int C8 = W / 8;
       uint16_t* dst = p.y2h + (m_base + own_lo) * p.ldy2h + step * W;
@@ -388,8 +391,12 @@ template <int W, int MTW>
 static hipError_t launch_res2_f16_variant(Res2ChainParams p, hipStream_t stream) {
   chain_tiling_for(chain_cap(W, MTW), p.T, p.dil, &p.tiles, &p.tile_rows);
   const int own = p.tiles > 1 ? p.tile_rows : p.T;
-  const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16) +
-                     (p.y2h ? (size_t)own * W * sizeof(_Float16) : 0);
+  const size_t planes = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 16) * 2 * sizeof(_Float16);
+  const size_t stage = p.y2h ? (size_t)own * W * sizeof(_Float16) : 0;
+  // binary16 rows: staged in LDS and copied out as 16-byte vectors when that fits beside the activation planes
+  // (w = 64), else stored straight from the accumulators, 8 bytes per lane (w = 128: 124 KB of planes)
+  p.y2h_direct = p.y2h && planes + stage > 160 * 1024;
+  const size_t lds = planes + (p.y2h_direct ? 0 : stage);
   auto kern = res2_chain_f16x3_kernel<W, MTW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   {
@@ -414,17 +421,9 @@ static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// binary16 output staging ([owned rows][W] halfs on top of the hi/lo activation planes) must fit the 160 KB LDS
-// (checked for the big windows: the small ones need less)
-bool res2_half_out_supported(int W, int T, int dil) {
-  if (!res2_chain_supported(W, T, dil)) return false;
-  int tiles, own;
-  const int cap = chain_cap(W, chain_mtw(W, false));
-  chain_tiling_for(cap, T, dil, &tiles, &own);
-  if (tiles == 1) own = T;
-  const size_t lds = (size_t)(cap + 2 * dil) * (W + 16) * 2 * 2 + (size_t)own * W * 2;
-  return lds <= 160 * 1024;
-}
+// binary16 output (Res2ChainParams::y2h): always available on the split-f16 kernel -- staged through LDS when it
+// fits, stored directly otherwise (launch_res2_f16_variant)
+bool res2_half_out_supported(int W, int T, int dil) { return res2_chain_supported(W, T, dil); }
 
 // any length: utterances beyond one workgroup's rows run as time tiles with a 7 * dil halo
 bool res2_chain_supported(int W, int T, int dil) {
