@@ -382,6 +382,8 @@ static bool chain_use_small(int W, int B, int T, int dil) {
   static int forced = -2;
   if (forced == -2) { const char* ev = getenv("WS_CHAIN_SMALL"); forced = ev ? atoi(ev) : -1; }
   if (forced >= 0) return forced != 0;
+  if (T <= chain_cap(W, chain_mtw(W, true))) return true;   // a short utterance fits the small window whole:
+                                                            // 128 (112) computed rows instead of 224 (208)
   int tiles, own;
   chain_tiling_for(chain_cap(W, chain_mtw(W, false)), T, dil, &tiles, &own);
   return (long long)B * tiles * 4 <= device_cus();
