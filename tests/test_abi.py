@@ -101,3 +101,20 @@ def test_only_the_c_abi_is_exported():
     syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
     assert syms and all(s.startswith("ws_") for s in syms), [s for s in syms if not s.startswith("ws_")][:5]
     assert set(syms) == set(_header_functions())
+
+
+def test_dispatch_log_entry_points_are_host_only():
+    """ws_debug_dispatch_log / ws_debug_dispatch_report need no device: the switch validates its mode, an empty
+    log reports one terminator byte, and the Python wrapper returns an empty table."""
+    import ctypes
+    L = _lib.lib()
+    assert L.ws_debug_dispatch_log(7) == -1 and b"mode" in L.ws_last_error()
+    assert L.ws_debug_dispatch_log(2) == 0                       # on + forget
+    assert L.ws_debug_dispatch_report(None, 0) == 1              # just the terminator
+    buf = ctypes.create_string_buffer(8)
+    assert L.ws_debug_dispatch_report(buf, 8) == 1 and buf.value == b""
+    assert L.ws_debug_dispatch_report(None, -1) == -1
+    from wespeaker_amd.engine import dispatch_log, dispatch_report
+    assert dispatch_report() == []
+    dispatch_log(False, clear=True)
+    assert dispatch_report() == []
