@@ -158,6 +158,55 @@ def test_plda_model_roundtrip_keeps_the_callers_file_name(tmp_path):
         TwoCovPLDA.load_model(str(tmp_path / "junk"))
 
 
+def test_plda_hdf5_files_have_the_reference_layout_and_survive_a_rewrite(tmp_path):
+    """save_model writes the reference's HDF5 layout (two_cov_plda.py:311-339) through libhdf5: checked with the
+    HDF5 project's own tools, not with our reader -- h5dump must show six datasets, the arrays float64, chunked,
+    gzip + fletcher32, unlimited maxshape, the flags int64 scalars -- and load_model must read the file after
+    h5repack has rewritten it contiguous and unfiltered (another writer's layout).  h5py is not in this image, so
+    an h5py-written file cannot be pinned here; both sides sit on the same C library h5py wraps."""
+    import shutil
+    import subprocess
+    from wespeaker_amd import hdf5_io
+    from wespeaker_amd.plda import TwoCovPLDA
+    if not hdf5_io.available():
+        pytest.skip("no HDF5 C library in this environment")
+    p = synth.synth_plda(10, seed=5, normalize_length=True)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], True, False)
+    path = str(tmp_path / "plda")
+    plda.save_model(path)                                        # default format = hdf5 here
+    assert open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    back = TwoCovPLDA.load_model(path)
+    for k in ("mu", "transform", "psi", "offset"):
+        assert np.array_equal(getattr(back, k), getattr(plda, k)) and getattr(back, k).dtype == np.float64
+    assert back.normalize_length is True and back.subtract_train_set_mean is False
+    plda.save_model(str(tmp_path / "plda_npz"), fmt="npz")       # the other container on request
+    assert open(str(tmp_path / "plda_npz"), "rb").read(2) == b"PK"
+    with pytest.raises(KeyError):
+        hdf5_io.read_datasets(path, ("mu", "no_such_dataset"))
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    h5repack = shutil.which("h5repack") or "/opt/conda/bin/h5repack"
+    if not (os.path.exists(h5dump) and os.path.exists(h5repack)):
+        pytest.skip("HDF5 command-line tools not installed")
+    hdr = subprocess.run([h5dump, "-p", "-H", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert hdr.count("DATASET ") == 6
+    for name, shape in (("mu", "( 10 ) / ( H5S_UNLIMITED )"), ("transform", "( 10, 10 ) / ( H5S_UNLIMITED, H5S_UNLIMITED )")):
+        block = hdr[hdr.index('DATASET "%s"' % name):]
+        block = block[:block.index("ALLOCATION_TIME")]
+        assert "H5T_IEEE_F64LE" in block and shape in block and "CHUNKED" in block
+        assert "CHECKSUM FLETCHER32" in block and "COMPRESSION DEFLATE { LEVEL 4 }" in block
+    flag = hdr[hdr.index('DATASET "normalize_length"'):]
+    assert "H5T_STD_I64LE" in flag[:300] and "SCALAR" in flag[:300]
+    val = subprocess.run([h5dump, "-d", "/psi", "-w", "0", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    got = np.array([float(x) for x in val[val.index("(0):") + 4:val.index("}", val.index("(0):"))].split(",")])
+    assert np.allclose(got, plda.psi, rtol=1e-5)                 # (h5dump prints 6 significant digits)
+    plain = str(tmp_path / "plda_contiguous.h5")
+    subprocess.run([h5repack, "-l", "CONTI", "-f", "NONE", path, plain], check=True, stdout=subprocess.PIPE)
+    again = TwoCovPLDA.load_model(plain)
+    for k in ("mu", "transform", "psi", "offset"):
+        assert np.array_equal(getattr(again, k), getattr(plda, k))
+    assert again.normalize_length is True and again.subtract_train_set_mean is False
+
+
 def test_twocovplda_constructor_keeps_the_reference_positional_order():
     """two_cov_plda.py:68-73: (scp_file, utt2spk_file, embed_dim, subtract_train_set_mean,
     normalize_length); trained parameters are keyword-only here."""

@@ -141,36 +141,37 @@ class TwoCovPLDA:
                                               bool(f["subtract_train_set_mean"]), device=device)
         if magic != b"\x89HDF\r\n\x1a\n":
             raise ValueError("%s is neither a .npz nor an HDF5 PLDA model" % path)
-        model_name = path
+        # the reference's own format (two_cov_plda.py:348-355 reads it with h5py): here through the HDF5 C library
+        # (wespeaker_amd/hdf5_io.py, ctypes), which this image has while h5py is absent
+        from . import hdf5_io
         try:
-            import h5py
-        except ImportError as e:
-            raise ImportError("reading the reference's HDF5 PLDA models needs h5py (not installed); "
-                              "use .npz or from_kaldi=True") from e
-        with h5py.File(model_name, "r") as f:
-            return TwoCovPLDA.from_params(f.get("mu")[()], f.get("transform")[()], f.get("psi")[()],
-                                          f.get("offset")[()], bool(f.get("normalize_length")[()]),
-                                          bool(f.get("subtract_train_set_mean")[()]), device=device)
+            f = hdf5_io.read_datasets(path, ("mu", "transform", "psi", "offset", "normalize_length",
+                                             "subtract_train_set_mean"))
+        except hdf5_io.Hdf5Error as e:
+            raise ImportError("reading the reference's HDF5 PLDA model %s needs libhdf5 (WS_HDF5_LIB) : %s; "
+                              "use .npz or from_kaldi=True" % (path, e)) from e
+        return TwoCovPLDA.from_params(f["mu"], f["transform"], f["psi"], f["offset"], bool(f["normalize_length"]),
+                                      bool(f["subtract_train_set_mean"]), device=device)
 
-    def save_model(self, output_file_name):
-        """Writes exactly `output_file_name` (np.savez on a path would append '.npz'): HDF5 like the
-        reference (two_cov_plda.py:311-339) when h5py is importable, numpy's .npz container otherwise;
-        load_model tells them apart by the file magic."""
-        try:
-            import h5py
-        except ImportError:
-            h5py = None
-        if h5py is not None:
-            with h5py.File(output_file_name, "w") as f:
-                for k in ("mu", "transform", "psi", "offset"):
-                    f.create_dataset(k, data=getattr(self, k))
-                f.create_dataset("normalize_length", data=int(self.normalize_length))
-                f.create_dataset("subtract_train_set_mean", data=int(self.subtract_train_set_mean))
-            return
-        with open(output_file_name, "wb") as fh:
-            np.savez(fh, mu=self.mu, transform=self.transform, psi=self.psi,
-                     offset=self.offset, normalize_length=int(self.normalize_length),
+    def save_model(self, output_file_name, fmt=None):
+        """Writes exactly `output_file_name` (np.savez on a path would append '.npz').  fmt "hdf5" = the
+        reference's format (two_cov_plda.py:311-339: six datasets, arrays chunked + gzip + fletcher32 with
+        unlimited maxshape, the two flags as integer scalars), written through libhdf5 (hdf5_io.py); "npz" =
+        numpy's container.  Default: hdf5 where the HDF5 library is found, npz otherwise; load_model tells them
+        apart by the file magic."""
+        from . import hdf5_io
+        if fmt is None:
+            fmt = "hdf5" if hdf5_io.available() else "npz"
+        items = dict(mu=self.mu, transform=self.transform, psi=self.psi, offset=self.offset,
+                     normalize_length=int(self.normalize_length),
                      subtract_train_set_mean=int(self.subtract_train_set_mean))
+        if fmt == "hdf5":
+            hdf5_io.write_datasets(output_file_name, items)
+        elif fmt == "npz":
+            with open(output_file_name, "wb") as fh:
+                np.savez(fh, **items)
+        else:
+            raise ValueError("save_model: fmt must be 'hdf5' or 'npz'")
 
     # ------------------------------------------------------------------------- device primitives
     def _dev(self, x, dtype):

@@ -190,8 +190,8 @@ def adapt_parameters(mu, transform, psi, adp_rows, normalize_length, ac_scale=0.
 # ------------------------------------------------------- bin/train_plda.py, bin/adapt_plda.py
 def train_plda(scp_path, utt2spk, indim, exp_dir, iter=5, type="2cov"):   # noqa: A002 (reference flag names)
     """bin/train_plda.py: --type 2cov --scp_path --utt2spk --indim --exp_dir --iter.
-    Saves `exp_dir/plda` like the reference (HDF5 when h5py is importable, else numpy's .npz container
-    under the same name; TwoCovPLDA.load_model sniffs the format)."""
+    Saves `exp_dir/plda` like the reference: HDF5 (written through libhdf5, wespeaker_amd/hdf5_io.py; numpy's
+    .npz container under the same name where no HDF5 library exists -- TwoCovPLDA.load_model sniffs the format)."""
     import os
     from .plda import TwoCovPLDA
     if type != "2cov":
