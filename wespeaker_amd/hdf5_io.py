@@ -95,11 +95,16 @@ def _lib():
                 fn.restype, fn.argtypes = res, args
             if lib.H5open() < 0:
                 raise Hdf5Error("H5open failed")
+            ver = (ctypes.c_uint * 3)()
+            lib.H5get_libversion.restype = ctypes.c_int
+            lib.H5get_libversion(ctypes.byref(ver, 0), ctypes.byref(ver, 4), ctypes.byref(ver, 8))
+            if (ver[0], ver[1]) < (1, 10):                # hid_t is a 32-bit int before 1.10: not this binding
+                raise ValueError("HDF5 %d.%d.%d is older than 1.10" % (ver[0], ver[1], ver[2]))
             lib.H5Eset_auto2(0, None, None)           # errors are reported by return values, not printed
             lib._f64 = _hid.in_dll(lib, "H5T_NATIVE_DOUBLE_g").value
             lib._i64 = _hid.in_dll(lib, "H5T_NATIVE_INT64_g").value
             lib._dcpl = _hid.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value
-        except (AttributeError, ValueError) as e:
+        except (AttributeError, ValueError, Hdf5Error) as e:
             last = e
             continue
         _LIB = lib
