@@ -189,7 +189,7 @@ def test_plda_hdf5_files_have_the_reference_layout_and_survive_a_rewrite(tmp_pat
         pytest.skip("HDF5 command-line tools not installed")
     hdr = subprocess.run([h5dump, "-p", "-H", path], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert hdr.count("DATASET ") == 6
-    for name, shape in (("mu", "( 10 ) / ( H5S_UNLIMITED )"), ("transform", "( 10, 10 ) / ( H5S_UNLIMITED, H5S_UNLIMITED )")):
+    for name, shape in (("mu", "( 10 ) / ( 10 )"), ("transform", "( 10, 10 ) / ( H5S_UNLIMITED, H5S_UNLIMITED )")):
         block = hdr[hdr.index('DATASET "%s"' % name):]
         block = block[:block.index("ALLOCATION_TIME")]
         assert "H5T_IEEE_F64LE" in block and shape in block and "CHUNKED" in block
@@ -205,6 +205,55 @@ def test_plda_hdf5_files_have_the_reference_layout_and_survive_a_rewrite(tmp_pat
     for k in ("mu", "transform", "psi", "offset"):
         assert np.array_equal(getattr(again, k), getattr(plda, k))
     assert again.normalize_length is True and again.subtract_train_set_mean is False
+
+
+def _layout_lines(path):
+    """h5dump's header of a file, minus what legitimately differs between writers (byte offsets, sizes, fill / allocation
+    timing): data types, data spaces, chunking and the filter pipeline remain."""
+    import shutil
+    import subprocess
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if not os.path.exists(h5dump):
+        pytest.skip("h5dump not installed")
+    out = subprocess.run([h5dump, "-p", "-H", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    keep = []
+    for line in out.splitlines()[1:]:
+        t = line.strip()
+        if t.startswith(("SIZE", "OFFSET", "FILL_TIME", "H5D_ALLOC_TIME", "VALUE")):
+            continue
+        keep.append(t)
+    return keep
+
+
+def test_plda_hdf5_against_a_file_written_by_h5py(golden_dir, tmp_path):
+    """tests/golden/plda_h5py.h5 was written by the real h5py (3.3.0, the Anaconda interpreter of this image) with
+    the reference's six create_dataset calls (oracle/make_golden_h5py.py): load_model reads it to the last bit, and
+    the file save_model writes has the SAME data types, data spaces, chunking and filter pipeline, dataset by
+    dataset.  Where that interpreter exists, h5py also reads back what we wrote."""
+    import json
+    import subprocess
+    from wespeaker_amd import hdf5_io
+    from wespeaker_amd.plda import TwoCovPLDA
+    if not hdf5_io.available():
+        pytest.skip("no HDF5 C library in this environment")
+    gold = os.path.join(golden_dir, "plda_h5py.h5")
+    exp = np.load(os.path.join(golden_dir, "plda_h5py_expected.npz"))
+    plda = TwoCovPLDA.load_model(gold)
+    for k in ("mu", "transform", "psi", "offset"):
+        assert np.array_equal(getattr(plda, k), exp[k]) and getattr(plda, k).dtype == np.float64
+    assert plda.normalize_length is True and plda.subtract_train_set_mean is False and plda.dim == 12
+    ours = str(tmp_path / "plda")
+    plda.save_model(ours)
+    assert _layout_lines(ours) == _layout_lines(gold)
+    py39 = "/opt/conda/bin/python3.9"
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "make_golden_h5py.py")
+    if os.path.exists(py39) and subprocess.run([py39, "-c", "import h5py"], stderr=subprocess.DEVNULL).returncode == 0:
+        r = subprocess.run([py39, "-W", "ignore", script, "read", ours], stdout=subprocess.PIPE, text=True, check=True)
+        back = json.loads(r.stdout.strip().splitlines()[-1])
+        for k in ("mu", "transform", "psi", "offset"):
+            assert np.array_equal(np.array(back[k]), exp[k]) and back["_dtypes"][k] == "float64"
+        assert back["normalize_length"] == 1 and back["subtract_train_set_mean"] == 0
+        assert back["_shapes"]["normalize_length"] == [] and back["_dtypes"]["normalize_length"] == "int64"
 
 
 def test_twocovplda_constructor_keeps_the_reference_positional_order():

@@ -164,10 +164,11 @@ def read_datasets(path, names):
 
 
 def write_datasets(path, items, compress=True):
-    """Writes {name: value} into a NEW file `path`.  Arrays become float64 (floating input) or int64 datasets with
-    unlimited maxshape, one chunk = the whole array, gzip(4) + fletcher32 when `compress` (what h5py writes for the
-    reference's create_dataset(..., maxshape=(None, ...), compression='gzip', fletcher32=True)); Python / numpy
-    scalars become scalar datasets."""
+    """Writes {name: value} into a NEW file `path`.  Arrays become float64 (floating input) or int64 datasets, one
+    chunk = the whole array, gzip(4) then fletcher32 when `compress`; 1-D arrays with fixed extent, n-D arrays with
+    unlimited maxshape; Python / numpy scalars become contiguous scalar datasets.  This is the layout h5py 3.3
+    produces for the reference's calls (tests/golden/plda_h5py.h5, oracle/make_golden_h5py.py): the reference passes
+    `maxshape=(None)` -- a plain None, not a tuple -- for its vectors and `(None, None)` for the matrix."""
     L = _lib()
     f = L.H5Fcreate(os.fsencode(path), _H5F_ACC_TRUNC, _H5P_DEFAULT, _H5P_DEFAULT)
     if f < 0:
@@ -186,14 +187,14 @@ def write_datasets(path, items, compress=True):
                 sp = _check(L.H5Screate(0), "scalar dataspace")              # H5S_SCALAR
             else:
                 dims = (_hsize * a.ndim)(*a.shape)
-                maxd = (_hsize * a.ndim)(*([_H5S_UNLIMITED] * a.ndim))
+                maxd = (_hsize * a.ndim)(*([_H5S_UNLIMITED] * a.ndim)) if a.ndim > 1 else None
                 sp = _check(L.H5Screate_simple(a.ndim, dims, maxd), "dataspace of '%s'" % name)
                 plist = _check(L.H5Pcreate(L._dcpl), "dataset creation properties")
-                chunk = (_hsize * a.ndim)(*[max(1, s) for s in a.shape])     # (unlimited dims need chunks)
+                chunk = (_hsize * a.ndim)(*[max(1, s) for s in a.shape])     # (filters / unlimited dims need chunks)
                 _check(L.H5Pset_chunk(plist, a.ndim, chunk), "chunk shape of '%s'" % name)
                 if compress and a.size:
-                    _check(L.H5Pset_fletcher32(plist), "fletcher32")
                     _check(L.H5Pset_deflate(plist, 4), "gzip")
+                    _check(L.H5Pset_fletcher32(plist), "fletcher32")
             try:
                 d = _check(L.H5Dcreate2(f, name.encode(), mem, sp, _H5P_DEFAULT, plist, _H5P_DEFAULT),
                            "create dataset '%s'" % name)
