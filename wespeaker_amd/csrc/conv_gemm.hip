@@ -1878,6 +1878,20 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots = 2 * cus;
   }
+  // fp32 back-end, plain 1x1 layer with a bias / ReLU / BN epilogue: whole rounds of 128x128 tiles go to the
+  // persistent kernel (gemm_f32_stream.hip), the remaining rows re-enter below with m_begin set
+  if constexpr (PREC == 0) {
+    if (mode == 3) {
+      const int srows = gemm_f32_stream_rows(p, slots / 2);
+      if (srows > 0) {
+        hipError_t e = launch_gemm_f32_stream(p, srows, slots / 2, stream);
+        if (e != hipSuccess || p.m_begin + srows >= p.M) return e;
+        ConvGemmParams rest = p;
+        rest.m_begin = p.m_begin + srows;
+        return launch_prec<PREC>(rest, stream);
+      }
+    }
+  }
   // f16 back-end, plain 1x1 layer: the K-tile-64 kernels (binary16 activations when the producer left
   // them -- then the fp32 tensor may not even exist, so every tile size must take this route)
   const bool fast16 = PREC == 2 && mode == 3 && p.splitk <= 1 && p.K % FBK == 0 && p.N > 64 &&

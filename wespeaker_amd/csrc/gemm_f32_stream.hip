@@ -1,0 +1,534 @@
+// Persistent fp32 GEMM for the plain 1x1 layers (the dominant class of the parity-grade back-end).
+//
+// Replaces the conv1d(k=1) / linear ATen calls of the reference forward whose epilogue is only
+// bias -> ReLU -> BN affine (wespeaker/models/ecapa_tdnn.py:85-106 Conv1dReluBn as used at :133-157 for the
+// two 1x1 convolutions of every SE-Res2Block, and :196 for the cat convolution): 6 x 512^2 + 1536^2 of
+// ECAPA-512 = 87 % of its FLOPs.  Everything else (taps, residuals, masks, pooling, split-K) stays on
+// conv_gemm.hip.
+//
+// Why a separate kernel.  The 128x128 tile kernel of conv_gemm.hip runs its K loop at
+// ~0.89 of the fp32 MFMA rate, but a K = 512 tile is only 16 K-tiles long: prologue (exposed first loads),
+// epilogue (all 512 resident workgroups store their 64 KB at the same moment) and the 3.09-round tile count
+// take the layer to 0.67-0.72.  Here ONE workgroup per CU stays resident and walks its tiles:
+//   * the operands are a continuous stream of 32-KB K-tiles (128 rows of A + 128 rows of W, 128 B each)
+//     copied global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of three stages, two K-tiles
+//     ahead of the MFMAs and straight across tile boundaries: no prologue per tile.  Unpadded 128-B rows,
+//     the 16-B chunk index XOR-swizzled with (row >> 1) & 7 on the SOURCE address and on the fragment reads
+//     (every ds_read_b128 lane group then hits 16 distinct 16-B slots);
+//   * every non-MFMA instruction is issued behind one MFMA (an fp32 MFMA holds the pipe for 64 cycles):
+//     DMA pieces, fragment reads, the barrier's waits, and the whole epilogue;
+//   * the LAST K-tile of a tile runs block-major (all 16 k-steps of one 32x32 accumulator block, then the
+//     next block: a dependent fp32 MFMA chain issues at the full rate), so a finished block's epilogue --
+//     wave-private 32x36 LDS transpose, bias / ReLU / BN, 128-B row segments to HBM, column sums -- runs in the
+//     shadow of the next block's MFMAs (only the last block's is exposed).  Same k order per accumulator as
+//     conv_gemm.hip: the outputs are bit-identical;
+//   * only whole rounds of tiles are taken (the dispatcher hands the remaining rows to the 64x64 kernel),
+//     XCD-aware order inside a round (an XCD's 32 workgroups share A row panels in its private L2).
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace wsamd {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int S_BM = 128, S_BN = 128, S_BK = 32;
+constexpr int S_NSTAGE = 3;
+constexpr int S_STAGE_BYTES = (S_BM + S_BN) * S_BK * 4;       // 32 KiB
+constexpr int S_W_BYTE0 = S_BM * S_BK * 4;                    // W rows behind the A rows of a stage
+constexpr int S_SCR_STRIDE = 36;                              // floats per row of the transpose scratch
+constexpr int S_SCR_BYTES = 32 * S_SCR_STRIDE * 4;            // per wavefront
+
+__device__ __forceinline__ void s_dma_16B(const void* g, void* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void s_wait_lds_vm_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // this wavefront's fragment reads of the stage are complete, its DMA pieces of the next stage have landed
+  // (all but the N newest VMEM operations), then the workgroup barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
+}
+
+#ifdef WS_TRACE
+__device__ unsigned long long g_stream_trace[256];
+#define WS_SSTAMP(i)                                                                   \
+  { const int _i = (i); if (blockIdx.x == 9 && threadIdx.x == 0 && _i < 128) g_stream_trace[_i] = __builtin_readcyclecounter(); }
+// fine stamps inside ONE K-tile of each kind (slots 128..: regular, 144..: first, 160..: last)
+#define WS_FSTAMP(on, slot)                                                            \
+  if ((on) && blockIdx.x == 9 && threadIdx.x == 0) g_stream_trace[(slot)] = __builtin_readcyclecounter();
+#else
+#define WS_SSTAMP(i)
+#define WS_FSTAMP(on, slot)
+#endif
+
+// NW = 4: 2 x 2 wavefronts of 64x64 outputs, one wavefront per SIMD (512 registers each);
+// NW = 8: 2 x 4 wavefronts of 64x32 outputs, two per SIMD.
+template <int NW, bool COLSUM>
+__global__ __launch_bounds__(64 * NW, NW / 4)
+void gemm_f32_stream_kernel(const ConvGemmParams p) {
+  constexpr int WN = NW / 2;                 // wavefront columns
+  constexpr int TN = 4 / WN;                 // 32-column blocks per wavefront (2 or 1); TM = 2
+  constexpr int GM = 8 * TN;                 // MFMAs per k-group (8 k) of a K-tile
+  constexpr int NP = 32 / NW;                // 1-KiB DMA pieces per wavefront and K-tile
+  constexpr int NF = 2 + TN;                 // fragment reads per k-group
+  constexpr int SCR_OFF = S_NSTAGE * S_STAGE_BYTES;
+  constexpr int VEC_OFF = SCR_OFF + NW * S_SCR_BYTES;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int r8 = lane >> 3, c8 = lane & 7;
+  const int nk = p.K / S_BK;
+  const int tiles_n = p.N / S_BN;
+  const int n_tiles = p.n_big;
+  const int HW = p.Hout * p.Wout;
+
+  // ---- this workgroup's tile sequence: seq -> round * grid + (XCD-contiguous index inside the round)
+  const int nwg = gridDim.x;
+  int remap;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    remap = xcd * q + (xcd < r ? xcd : r) + local;
+  }
+  if (remap >= n_tiles) return;
+  const int my_nt = (n_tiles - remap + nwg - 1) / nwg;
+  auto tile_of = [&](int seq, int& m0, int& n0) {
+    const int work = seq * nwg + remap;
+    const int tm = work / tiles_n;
+    m0 = p.m_begin + tm * S_BM;
+    n0 = (work - tm * tiles_n) * S_BN;
+  };
+
+  // ---- per-channel epilogue vectors of ALL columns, once per workgroup: [bias | scale | shift][N]
+  {
+    float* vec = reinterpret_cast<float*>(ldsb + VEC_OFF);
+    for (int i = tid; i < p.N; i += 64 * NW) {
+      vec[i] = p.bias ? p.bias[i] : 0.f;
+      vec[p.N + i] = p.post_scale ? p.post_scale[i] : 1.f;
+      vec[2 * p.N + i] = p.post_scale ? p.post_shift[i] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- operand stream (prefetch side).  Piece q of a stage = rows [8 (q & 15), +8) of A (q < 16) or W;
+  // lane l of the piece: row rr = l >> 3, physical 16-B chunk pc = l & 7 <- logical chunk pc ^ key(row).
+  const bool w_side = wave >= NW / 2;                    // this wavefront copies W rows (else A rows)
+  const char* gbase = w_side ? reinterpret_cast<const char*>(p.W) : reinterpret_cast<const char*>(p.A);
+  unsigned voff[NP];
+  const int g_ld = w_side ? p.ldw : p.lda, g_off = w_side ? 0 : p.a_off;
+  auto set_tile_offsets = [&](int seq) {
+    int m0, n0;
+    tile_of(seq, m0, n0);
+    const int row0 = w_side ? n0 : m0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = (wave * NP + i) & 15;
+      const int row = q * 8 + r8;
+      const int c = c8 ^ ((row >> 1) & 7);
+      voff[i] = (unsigned)(((row0 + row) * g_ld + g_off) * 4 + c * 16);
+    }
+  };
+  int pf_seq = 0, pf_kt = 0, pf_stage = 0;
+  set_tile_offsets(0);
+  auto dma_piece = [&](int i) {
+    // wave-uniform 64-bit base (operand + K offset) + 32-bit lane offset: the saddr form of the instruction
+    const char* kb = gbase + (size_t)(unsigned)(pf_kt * (S_BK * 4));
+    s_dma_16B(kb + voff[i], ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024);
+  };
+  auto pf_advance = [&]() {
+    pf_stage = pf_stage == S_NSTAGE - 1 ? 0 : pf_stage + 1;
+    if (++pf_kt == nk) {
+      if (pf_seq + 1 < my_nt) {
+        pf_kt = 0;
+        ++pf_seq;
+        set_tile_offsets(pf_seq);
+      } else {
+        pf_kt = nk - 1;       // past the end: repeat the last K-tile (keeps the vmcnt arithmetic uniform)
+      }
+    }
+  };
+
+  // ---- fragment addresses (bytes inside the current stage; advanced at every barrier)
+  int aaddr[4], waddr[4];
+  {
+    const int key = (li >> 1) & 7;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int pc = ((2 * g) | lh) ^ key;
+      aaddr[g] = (wm * 64 + li) * 128 + pc * 16;
+      waddr[g] = S_W_BYTE0 + (wn * 32 * TN + li) * 128 + pc * 16;
+    }
+  }
+  int cur_stage = 0;
+  auto advance_frag_addrs = [&]() {
+    const int d = cur_stage == S_NSTAGE - 1 ? -(S_NSTAGE - 1) * S_STAGE_BYTES : S_STAGE_BYTES;
+    cur_stage = cur_stage == S_NSTAGE - 1 ? 0 : cur_stage + 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { aaddr[g] += d; waddr[g] += d; }
+  };
+
+  f32x4 fa[2][2], fb[2][TN];                 // [slot][block]: one 16-B read feeds 4 MFMAs (k = 8g + 4lh + s)
+  auto frag_read = [&](int slot, int g, int idx) {        // idx 0,1: A blocks; 2..: W blocks
+    if (idx < 2) fa[slot][idx] = *reinterpret_cast<const f32x4*>(ldsb + aaddr[g] + idx * 4096);
+    else fb[slot][idx - 2] = *reinterpret_cast<const f32x4*>(ldsb + waddr[g] + (idx - 2) * 4096);
+  };
+
+  f32x16 acc[2][TN];
+  bool trace_now = false;                    // (WS_TRACE builds: fine stamps inside the K-tile that sets it)
+  (void)trace_now;
+
+  // ---- epilogue state
+  float* scr = reinterpret_cast<float*>(ldsb + SCR_OFF + wave * S_SCR_BYTES);
+  const float* vec = reinterpret_cast<const float*>(ldsb + VEC_OFF);
+  // raw buffer descriptors of D / D2: one store instruction per row = lane offset (VGPR) + row offset (SGPR),
+  // no 64-bit address arithmetic on the vector ALU
+  const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.D, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t d2_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.D2 ? p.D2 : p.D, 0, 0xffffffff, 0x00020000);
+  // ReLU as ONE integer max per value: the int image of a float is >= 0 exactly for +0, positive values, +inf and
+  // positive NaNs, so max(bits, 0) maps every negative value (and -0) to +0 and keeps NaN a NaN like relu_f
+  // does; without an activation the bound is INT_MIN (identity)
+  const int relu_bits = p.act == ACT_RELU ? 0 : (int)0x80000000;
+  // the tile whose blocks are being finished
+  struct TileOut {
+    unsigned dvoff;        // byte offset of D[m0 + wm*64 + r8][d_off + n0 + wn*32*TN + 4 c8]
+    unsigned d2voff;       // the same for D2 (columns n - d2_col0)
+    int ncol;              // n0 + wn*32*TN + 4 c8: first of this lane's 4 columns in block 0
+    int nblk;              // n0 + wn*32*TN (wave-uniform)
+    int rb;                // rows of the wavefront's 64-row half that belong to its first image
+    int t64;               // (m0 + wm*64) / 64
+  };
+  TileOut cur = {};
+  auto set_tile_out = [&](int seq, TileOut& t) {
+    int m0, n0;
+    tile_of(seq, m0, n0);
+    const int mh = m0 + wm * 64;
+    t.nblk = n0 + wn * 32 * TN;
+    t.ncol = t.nblk + c8 * 4;
+    t.dvoff = (unsigned)(((mh + r8) * p.ldd + p.d_off + t.ncol) * 4);
+    t.d2voff = p.D2 ? (unsigned)(((mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4) : 0u;
+    t.rb = COLSUM ? (mh / HW + 1) * HW - mh : 64;
+    t.t64 = mh >> 6;
+  };
+  f32x4 cs[TN][2];                           // column sums of the stored values: [block column][image part]
+#pragma unroll
+  for (int in = 0; in < TN; ++in) cs[in][0] = cs[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
+
+  // One block's epilogue in 15 steps (each small enough for the shadow of one MFMA).  im / in: the block,
+  // t: its tile; steps 0-1 take the accumulator quads `q` (C^T block: lane (li, lh) holds channels
+  // 8 g + 4 lh .. +3 of pixel li in registers 4 g .. 4 g + 3).
+  auto epi_step = [&](int step, int im, int in, const TileOut& t, const f32x16& q) {
+    if (step == 0 || step == 1) {
+#pragma unroll
+      for (int g = 2 * step; g < 2 * step + 2; ++g)
+        *reinterpret_cast<f32x4*>(&scr[li * S_SCR_STRIDE + 8 * g + 4 * lh]) =
+            (f32x4){q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]};
+    } else if (step == 2 || step == 3) {
+#pragma unroll
+      for (int i = 2 * (step - 2); i < 2 * (step - 2) + 2; ++i)
+        ev[i] = *reinterpret_cast<const f32x4*>(&scr[(r8 + 8 * i) * S_SCR_STRIDE + c8 * 4]);
+    } else if (step == 4) {
+      const int n = t.ncol + in * 32;
+      vb = *reinterpret_cast<const f32x4*>(&vec[n]);
+      vs = *reinterpret_cast<const f32x4*>(&vec[p.N + n]);
+      vt = *reinterpret_cast<const f32x4*>(&vec[2 * p.N + n]);
+    } else if (step >= 5 && step <= 8) {
+      const int i = step - 5;
+      f32x4 v = ev[i] + vb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (a scalar copy first: __builtin_bit_cast on a vector ELEMENT reads element 0 whatever the index)
+        const float f = v[e];
+        v[e] = __int_as_float(__builtin_elementwise_max(__float_as_int(f), relu_bits));
+      }
+      ev[i] = v * vs + vt;
+    } else if (step >= 9 && step <= 12) {
+      const int i = step - 9;
+      const int srow = im * 32 + 8 * i;
+      __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff, (srow * p.ldd + in * 32) * 4, 0);
+      // (d2_col0 is a multiple of 32: a 32-column block goes to D2 as a whole -- a wave-uniform branch)
+      if (p.D2 && t.nblk + in * 32 >= p.d2_col0)
+        __builtin_amdgcn_raw_buffer_store_b128(ev[i], d2_rsrc, t.d2voff, (srow * p.ldd2 + in * 32) * 4, 0);
+    } else if (COLSUM && (step == 13 || step == 14)) {
+#pragma unroll
+      for (int i = 2 * (step - 13); i < 2 * (step - 13) + 2; ++i) {
+        const float f0 = im * 32 + r8 + 8 * i < t.rb ? 1.f : 0.f, f1 = 1.f - f0;
+        cs[in][0] += ev[i] * f0;
+        cs[in][1] += ev[i] * f1;
+      }
+    }
+  };
+  // column sums of a finished tile: fold the 8 row groups (lane bits 3..5), lanes 0..7 store, reset.
+  // step 0..2: one butterfly round each; step 3: store + reset
+  auto colsum_step = [&](int step, const TileOut& t) {
+    if (!COLSUM) return;
+    if (step < 3) {
+      const int m = 8 << step;
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = cs[in][w][e];
+            cs[in][w][e] = f + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, __float_as_int(f)));
+          }
+    } else {
+      if (r8 == 0) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int w = 0; w < 2; ++w)
+            *reinterpret_cast<f32x4*>(p.colsum + ((size_t)t.t64 * 2 + w) * p.N + t.ncol + in * 32) = cs[in][w];
+      }
+#pragma unroll
+      for (int in = 0; in < TN; ++in) cs[in][0] = cs[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // everything of a block's epilogue behind its scratch writes (the last block of a tile has no MFMAs left to
+  // hide behind: ~250 exposed cycles per tile.  Deferring it into the next tile's first K-tile was built and
+  // measured: no gain, the stores then delay that K-tile's counted vmcnt wait)
+  auto finish_block = [&](int im, int in, const TileOut& t) {
+    const f32x16 none = {};
+#pragma unroll
+    for (int st = 2; st < 15; ++st) epi_step(st, im, in, t, none);
+  };
+  // ---- prologue: two K-tiles in flight, the first one landed, its first fragments in registers
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dma_piece(i);
+  pf_advance();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dma_piece(i);
+  pf_advance();
+  s_wait_lds_vm_barrier<NP>();
+#pragma unroll
+  for (int i = 0; i < NF; ++i) frag_read(0, 0, i);
+
+  // 4 * TM * TN MFMAs of one k-group from fragment slot `slot`; filler(i) is issued behind MFMA i
+  auto mma_group = [&](int slot, bool zero_c, auto&& filler) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          if (zero_c && s == 0) {
+            const f32x16 z = {};
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[slot][in][s], fa[slot][im][s], z, 0, 0, 0);
+          } else {
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[slot][in][s], fa[slot][im][s], acc[im][in], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          filler((s * 2 + im) * TN + in);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+  };
+
+  // One K-tile, MFMAs round-robin over the accumulator blocks.  FIRST: first K-tile of a tile (fresh accumulators).
+  auto ktile = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int fs = FIRST ? 144 : 128;
+    (void)fs;
+    WS_FSTAMP(trace_now, fs + 0)
+    mma_group(0, FIRST, [&](int i) {                       // g0: DMA pieces of K-tile +2, fragments of g1
+      if (i < NP) dma_piece(i);
+      if (i >= GM / 2 && i < GM / 2 + NF) frag_read(1, 1, i - GM / 2);
+    });
+    WS_FSTAMP(trace_now, fs + 1)
+    pf_advance();
+    WS_FSTAMP(trace_now, fs + 2)
+    mma_group(1, false, [&](int i) {                       // g1: fragments of g2
+      if (i >= GM / 2 && i < GM / 2 + NF) frag_read(0, 2, i - GM / 2);
+    });
+    WS_FSTAMP(trace_now, fs + 3)
+    mma_group(0, false, [&](int i) {                       // g2: fragments of g3
+      if (i >= GM / 2 && i < GM / 2 + NF) frag_read(1, 3, i - GM / 2);
+    });
+    WS_FSTAMP(trace_now, fs + 4)
+    s_wait_lds_vm_barrier<NP>();
+    WS_FSTAMP(trace_now, fs + 5)
+    advance_frag_addrs();
+    mma_group(1, false, [&](int i) {                       // g3 (fragments in registers): g0 of the next K-tile
+      if (i < NF) frag_read(0, 0, i);
+    });
+    WS_FSTAMP(trace_now, fs + 6)
+  };
+
+  // The last K-tile of a tile, block-major.
+  auto ktile_last = [&]() {
+    f32x4 la[2][4], lb[TN][4];                           // [block][k-group]
+#pragma unroll
+    for (int im = 0; im < 2; ++im) la[im][0] = fa[0][im];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) lb[in][0] = fb[0][in];
+    auto lread = [&](int idx, int g) {                   // idx 0,1: A blocks; 2..: W blocks
+      if (idx < 2) la[idx][g] = *reinterpret_cast<const f32x4*>(ldsb + aaddr[g] + idx * 4096);
+      else lb[idx - 2][g] = *reinterpret_cast<const f32x4*>(ldsb + waddr[g] + (idx - 2) * 4096);
+    };
+    // the reads still missing, in the order block 0 needs them: (A0, W0) of g1, g2, g3, then the rest
+    constexpr int NREST = 3 * NF - 6;                    // A1 (and W1) of g1..g3
+#pragma unroll
+    for (int b = 0; b < 2 * TN; ++b) {
+      WS_FSTAMP(trace_now, 160 + 2 * b)
+      const int im = b / TN, in = b - im * TN;
+      const int pim = (b - 1) / TN, pin = (b - 1) - pim * TN;      // the block finished behind this one
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(lb[in][g][s], la[im][g][s], acc[im][in], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          const int i = g * 4 + s;
+          if (b == 0) {
+            // (hipcc waits with lgkmcnt(0): a read is placed >= 4 MFMAs in front of the first MFMA that waits)
+            auto rest = [&](int j) {                     // j -> A1 g1..g3, then W1 g1..g3
+              if (j >= NREST) return;
+              if (j < 3) lread(1, j + 1);
+              else lread(3, j - 3 + 1);
+            };
+            if (i == 0) { lread(0, 1); lread(2, 1); lread(0, 2); lread(2, 2); }
+            else if (i == 4) { lread(0, 3); lread(2, 3); rest(0); rest(1); }
+            else if (i == 5) { rest(2); rest(3); }
+            else if (i == 6) { rest(4); rest(5); }
+            else if (i >= 7 && i < 7 + NP) dma_piece(i - 7);
+          } else {
+            if (i < 15) epi_step(i, pim, pin, cur, acc[pim][pin]);
+            if (b == 2 * TN - 1 && i >= 16 - NF) frag_read(0, 0, i - (16 - NF));     // next K-tile's first fragments
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (b == 0) {
+        WS_FSTAMP(trace_now, 160 + 1)
+        pf_advance();
+        s_wait_lds_vm_barrier<NP>();
+        advance_frag_addrs();
+      }
+    }
+    WS_FSTAMP(trace_now, 160 + 8)
+    // the last block: nothing left to hide behind
+    epi_step(0, 1, TN - 1, cur, acc[1][TN - 1]);
+    epi_step(1, 1, TN - 1, cur, acc[1][TN - 1]);
+    finish_block(1, TN - 1, cur);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) colsum_step(st, cur);
+    WS_FSTAMP(trace_now, 160 + 9)
+  };
+
+  int stamp = 0;
+  (void)stamp;
+  for (int seq = 0; seq < my_nt; ++seq) {
+    set_tile_out(seq, cur);
+    WS_SSTAMP(stamp++)
+    trace_now = seq == 1;
+    ktile(std::true_type{});
+    for (int kt = 1; kt + 1 < nk; ++kt) {
+      WS_SSTAMP(stamp++)
+      trace_now = seq == 1 && kt == 5;
+      ktile(std::false_type{});
+    }
+    WS_SSTAMP(stamp++)
+    trace_now = seq == 1;
+    ktile_last();
+    trace_now = false;
+  }
+  WS_SSTAMP(stamp++)
+  // drain the DMA pieces that ran past the end of the stream before the LDS goes away
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NW>
+constexpr size_t stream_lds_bytes(int N) {
+  return (size_t)S_NSTAGE * S_STAGE_BYTES + (size_t)NW * S_SCR_BYTES + (size_t)3 * N * 4;
+}
+
+template <int NW, bool COLSUM>
+hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  auto kern = gemm_f32_stream_kernel<NW, COLSUM>;
+  const size_t lds_bytes = stream_lds_bytes<NW>(p.N);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), stream_lds_bytes<NW>(1536), lds_granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int g_ws_stream = -1;          // env WS_STREAM: 0 off, 1 = 4 wavefronts, 2 = 8 wavefronts (default)
+
+#ifdef WS_TRACE
+unsigned long long* stream_trace_buffer_address() {
+  unsigned long long* q = nullptr;
+  (void)hipGetSymbolAddress(reinterpret_cast<void**>(&q), HIP_SYMBOL(g_stream_trace));
+  return q;
+}
+#endif
+
+// Rows of [p.m_begin, p.M) that the persistent kernel should take (a multiple of 128 rows = whole rounds of
+// 128x128 tiles over `cus` workgroups); 0 = not this kernel's problem.
+int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
+  if (g_ws_stream < 0) {
+    const char* ev = getenv("WS_STREAM");
+    g_ws_stream = ev ? atoi(ev) : 2;
+  }
+  if (!(g_ws_stream & 3)) return 0;
+  const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
+                     p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
+                     !p.bias_img && !p.residual && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
+                     p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
+  if (!plain) return 0;
+  if (p.N % S_BN != 0 || p.N > 1536 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
+  if (p.colsum && p.Hout * p.Wout < 64) return 0;
+  if ((p.m_begin & 63) || ((p.lda | p.a_off | p.ldd | p.d_off) & 3)) return 0;
+  if (p.D2 && (((p.ldd2 | p.d2_off) & 3) || (p.d2_col0 & 31))) return 0;
+  // 32-bit byte offsets
+  if ((long long)p.M * p.lda * 4 >= (1LL << 32) || (long long)p.M * p.ldd * 4 >= (1LL << 32) ||
+      (long long)p.N * p.ldw * 4 >= (1LL << 32) || (p.D2 && (long long)p.M * p.ldd2 * 4 >= (1LL << 32)))
+    return 0;
+  const long long tiles_n = p.N / S_BN, tiles_m = (p.M - p.m_begin) / S_BM;
+  const long long rounds = tiles_m * tiles_n / cus;
+  if (rounds < 2) return 0;
+  long long main_tiles_m = rounds * cus / tiles_n;
+  // The tiles beyond the whole rounds: one more (partial) round here costs a whole tile time, K/32 x ~4400 cycles;
+  // as 64x64 tiles on the tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the
+  // kernel boundary they cost ceil(4 rem / 512) rounds -- take the cheaper (K = 512: 48 tiles -> the tile kernel;
+  // K = N = 1536: 144 tiles -> here)
+  const long long rem = tiles_m * tiles_n - main_tiles_m * tiles_n, nk = p.K / S_BK;
+  if (rem > 0) {
+    const long long here = nk * 4400, there = (4 * rem + 2 * cus - 1) / (2 * cus) * nk * 2600 + 12000;
+    if (here <= there) main_tiles_m = tiles_m;
+  }
+  return (int)(main_tiles_m * S_BM);
+}
+
+hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, hipStream_t stream) {
+  ConvGemmParams p = p0;
+  p.tail_begin = p.m_begin + rows;
+  p.n_big = rows / S_BM * (p.N / S_BN);
+  const int grid = p.n_big < cus ? p.n_big : cus;
+  const bool w8 = (g_ws_stream & 3) != 1;
+  if (dispatch_log_enabled()) {
+    char k[96];
+    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%d waves> tiles=%d", w8 ? 8 : 4, p.n_big);
+    dispatch_log_note(p, k);
+  }
+  if (w8) return p.colsum ? launch_stream<8, true>(p, grid, stream) : launch_stream<8, false>(p, grid, stream);
+  return p.colsum ? launch_stream<4, true>(p, grid, stream) : launch_stream<4, false>(p, grid, stream);
+}
+
+}  // namespace wsamd

@@ -97,6 +97,12 @@ void dispatch_log_note(const ConvGemmParams& p, const char* kernel);
 size_t dispatch_log_dump(char* buf, size_t cap);      // text lines; returns the bytes the full report needs
 void dispatch_log_clear();
 
+// Persistent fp32 GEMM of the plain 1x1 layers (gemm_f32_stream.hip).  gemm_f32_stream_rows: how many rows of
+// [p.m_begin, p.M) that kernel takes (whole rounds of 128x128 tiles over `cus` workgroups; 0 = not its problem);
+// the caller sends the remaining rows through the tile kernels with m_begin advanced.
+int gemm_f32_stream_rows(const ConvGemmParams& p, int cus);
+hipError_t launch_gemm_f32_stream(const ConvGemmParams& p, int rows, int cus, hipStream_t stream);
+
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
 
