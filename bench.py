@@ -3,34 +3,42 @@
 (wav -> Kaldi fbank -> CMN -> forward, all in the HIP library) + PLDA trials/sec.
 
     python bench.py [--gpus N --steps K --warmup W] [--model M] [--precision P]
+    python bench.py --gpus 8 --workload vox1o            # fixed-size set, strong scaling
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of `--batch` utterances per GPU whose PCM16
-samples are already resident in HBM.  Utterances are sharded over ranks as independent blocks
-(weak scaling: per-GPU batch fixed); the only collective is the all_gather of the (B, E)
-embeddings, which is inside the timed region.  Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 and no torchrun environment launches itself: the process re-executes under
+`torch.distributed.run` with one rank per GPU (the reference's launcher spawns its per-GPU jobs the same way,
+tools/extract_embedding.sh:46-65).
 
-Which number is the headline.  The reference path north_star names is PyTorch **fp32**; the
-parity-grade back-end is therefore WS_PREC_FP32 (exact fp32 products on v_mfma_f32_32x32x2_f32) and
-`value` / `dtype` / `roofline` describe THAT run (`--precision fp32`, the default).  The two binary16
-MFMA back-ends are declared fast modes: f16x3 (fp32-grade split arithmetic) and f16 (binary16 operands,
-fp32 accumulation: meets north_star's 1e-4 cosine bar with a 500x margin in tests/, but it is narrower
-arithmetic than the reference's).  All three are timed on the same workload in the same process and
-reported under `backends`, each with its own ms/step, spread over several timed windows and its own
-`roofline` block (dominant kernel class measured live with HIP events on the launch stream).
+Two workload shapes:
 
---model selects the family (BASELINE.json configs 1-3): ECAPA_TDNN_GLOB_c512 (default, the metric's
-model), ECAPA_TDNN_GLOB_c1024, ResNet34, ResNet221, CAMPPlus, ... -- same legs for every model.
+* default (weak scaling): one "step" = one pass of the hot path over one batch of `--batch` utterances per GPU whose
+  PCM16 samples are already resident in HBM; the only collective is the all_gather of the (B, E) embeddings, inside
+  the timed region.  `value` = utterances of all ranks / max-over-ranks time.
+* `--total-utts U` / `--workload vox1o|stream10k` (strong scaling, BASELINE.json configs 2 and 3): a FIXED set of U
+  utterances is cut into contiguous shards by parallel.shard_range (tools/extract_embedding.sh:39-67's rule), every
+  rank walks its shard in `--batch`-utterance batches, ONE all_gather collects the (U, E) table, and rank 0 scores
+  the trial list (PLDA LLR + cosine) -- one step = the whole set, all of it inside the timed region.
 
-  cpu_baseline -- the oracle (CPU restatement of the reference, bit-identical to the reference's
-                  nn.Module on all golden cases; /root/reference itself cannot travel to the GPU box, hence
-                  kind "port"): numpy fbank + torch-fp32 forward, batch 1 per utterance like
-                  Speaker.extract_embedding_list, on a bounded sample (rank 0, N=1 only).
+Which number is the headline.  The reference path north_star names is PyTorch **fp32**; the parity-grade back-end is
+WS_PREC_FP32 (exact fp32 products on v_mfma_f32_32x32x2_f32) and `value` / `dtype` / `roofline` describe THAT run
+(`--precision fp32`, the default).  f16x3 and f16 are declared fast modes, timed on the same workload in the same
+process and reported under `backends`, each with its own `roofline` block (dominant kernel class measured live with
+HIP events on the launch stream).
+
+The default N = 1 line also carries: `configs` (ECAPA-1024, ResNet34, ResNet221, CAM++: value, ms/step, dominant
+fraction, and the two fixed-size sets at N = 1), `plda` (pair list + dense matrix, each with `roofline` and
+`cpu_baseline`), `self_check` (rows of the timed output against a small-batch run of the same utterances) and
+`cpu_baseline` (the oracle on the host cores; /root/reference cannot travel to the GPU box, hence kind "port").
+
+WS_BENCH_STUB=1 (tests only): a host stand-in for the extractor (no GPU, gloo) so that the launch / sharding /
+gather / JSON logic of THIS file can run on CPU at world size 2.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
 import sys
 import time
@@ -47,20 +55,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from wespeaker_amd import Frontend, NativeSpeakerModel, TwoCovPLDA, parallel  # noqa: E402
+from wespeaker_amd import parallel  # noqa: E402
 from fixtures import synth  # noqa: E402
+
+STUB = os.environ.get("WS_BENCH_STUB") == "1"
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 F16_MFMA_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
+HBM_PEAK_GBS = 8000.0               # HBM3E spec (6.3 TB/s is what a copy reaches)
+F64_MFMA_PEAK_TFLOPS = 78.6         # MI355X datasheet FP64 matrix figure (not in the local guide)
 BACKENDS = ("fp32", "f16x3", "f16")
 DOMINANT = "gemm_main"              # profile class 0: every conv/linear GEMM launch with N > 64
+METRIC = "embeddings/sec (2 s utts, ECAPA-512) + PLDA trials/sec at 1/2/4/8 MI355X"
 
 # per-GPU batch / engine chunk defaults: ECAPA = BASELINE configs[1]'s 256 x 2 s; the 2-D families get
-# what fills the chip at their row counts (ResNet221: 256-utterance chunks -- 64 left its ~300 launches per
-# forward latency-bound: 2034 -> 2264 utt/s fp32, 5131 -> 5933 f16; 512 adds 2-4 % for twice the workspace)
+# what fills the chip at their row counts (ResNet221: 256-utterance chunks)
 DEFAULT_BATCH = {"ECAPA": (256, 256), "ResNet34": (512, 512), "ResNet18": (512, 512),
                  "ResNe": (256, 256), "CAMPP": (512, 512)}
 EMBED_DIM = {"ECAPA": 192, "ResNe": 256, "CAMPP": 512}
+# BASELINE.json configs 2 / 3: (model, utterances, trials)
+WORKLOADS = {"vox1o": ("ResNet34", 4874, 37611), "stream10k": ("CAMPPlus", 10000, 0)}
 
 DTYPE_TEXT = {
     "fp32": "f32",
@@ -73,9 +87,10 @@ DTYPE_TEXT = {
 def kernel_text(model_name, prec):
     ecapa = model_name.startswith("ECAPA")
     if prec == "fp32":
-        return ("conv_gemm_dual_kernel<..,PREC=0> (whole rounds of 128x128 tiles + the 64x64 tiles of the remaining "
-                "rows in one grid; v_mfma_f32_32x32x2_f32, exact fp32 products) and conv_gemm_kernel<128,128,2,2,"
-                "..,PREC=0> where the tile count needs no remainder class: every conv/linear with N > 64")
+        return ("gemm_f32_stream_kernel (persistent: one workgroup per CU walks whole rounds of 128x128 tiles, "
+                "operands by LDS-DMA into a 3-stage ring, v_mfma_f32_32x32x2_f32, exact fp32 products: the plain "
+                "1x1 layers) + conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> (everything else and the "
+                "remaining rows): every conv/linear with N > 64")
     if prec == "f16x3":
         return ("conv_gemm_dual_kernel<..,PREC=1> / conv_gemm_kernel<128,128,2,2,..,PREC=1> (3 x "
                 "v_mfma_f32_32x32x16_f16 on hi/lo binary16 splits): every conv/linear with N > 64")
@@ -88,6 +103,27 @@ def kernel_text(model_name, prec):
             "maps by LDS-DMA) + conv3x3_direct_f16_kernel launches routed through the same class")
 
 
+# ------------------------------------------------------------------------------------------ launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch_if_needed(argv, gpus):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: become
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>` (one rank per GPU)."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+# ------------------------------------------------------------------------------------------ inputs
 def device_wavs(batch, num_samples, device, seed_base):
     """Synthetic PCM16 batch generated on the device (same recipe family as synth.synth_wav:
     gaussian noise sigma 3000 + 8000-amplitude tone with per-utterance f0 in [80, 400] Hz)."""
@@ -98,6 +134,23 @@ def device_wavs(batch, num_samples, device, seed_base):
     x = 3000.0 * torch.randn(batch, num_samples, device=device, generator=g)
     x = x + 8000.0 * torch.sin(2 * np.pi * f0 * t[None, :])
     return x.round().clamp(-32768, 32767).to(torch.int16).contiguous()
+
+
+class StubExtractor:
+    """Host stand-in (WS_BENCH_STUB=1, tests only): a fixed random projection of the samples."""
+
+    def __init__(self, embed_dim, num_samples):
+        g = torch.Generator().manual_seed(5)
+        self.w = torch.randn(num_samples, embed_dim, generator=g) / num_samples ** 0.5
+
+    def extract(self, fe, wav):
+        return wav.to(torch.float32) @ self.w
+
+    def set_precision(self, prec):
+        return self
+
+    def check_range(self):
+        pass
 
 
 def oracle_forward_fn(model_name, embed_dim):
@@ -146,16 +199,53 @@ def cpu_baseline(model_name, embed_dim, sample_utts, budget_s=8.0):
                       "loop), %s; best of 1/8/32 threads" % (best[2], best[3], model_name)}
 
 
-def main():
+def plda_cpu_baseline(params, enroll_t, test_t, idx_e, idx_t, budget_s=4.0):
+    """The reference's own scoring on the host cores (oracle/plda.py): the per-trial Python loop of eval_sv
+    (two_cov_plda.py:165-184, 246-256) on a bounded sample of the trial list, and the vectorised numpy closed
+    form (a dense 1000 x 1000 block) as the fair CPU figure."""
+    from oracle import plda as oplda
+    e = np.asarray(enroll_t, dtype=np.float64)
+    t = np.asarray(test_t, dtype=np.float64)
+    n_loop, t0 = 0, time.perf_counter()
+    chunk = 2000
+    while time.perf_counter() - t0 < budget_s and n_loop < len(idx_e):
+        sl = slice(n_loop, min(len(idx_e), n_loop + chunk))
+        oplda.llr_pairs(params, e, np.ones(e.shape[0]), t, idx_e[sl], idx_t[sl])
+        n_loop = sl.stop
+    loop_dt = time.perf_counter() - t0
+    ne, nt = min(1000, e.shape[0]), min(1000, t.shape[0])
+    oplda.llr_matrix_vectorised(params, e[:ne], np.ones(ne), t[:nt])
+    reps, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < budget_s / 2 or reps == 0:
+        oplda.llr_matrix_vectorised(params, e[:ne], np.ones(ne), t[:nt])
+        reps += 1
+    mat_dt = (time.perf_counter() - t1) / reps
+    return {"value": n_loop / loop_dt, "unit": "trials/s", "cores": 1, "kind": "port",
+            "sample": "%d trials of the list in %.1f s through oracle/plda.py's per-trial loop (the reference's "
+                      "eval_sv trial loop, two_cov_plda.py:246-256; pinned to the reference on "
+                      "tests/golden/plda_ref.npz)" % (n_loop, loop_dt),
+            "vectorised_numpy_trials_per_s": ne * nt / mat_dt,
+            "vectorised_sample": "dense %d x %d block, numpy float64 closed form (BLAS threads as numpy chooses), "
+                                 "%.1f ms per block" % (ne, nt, mat_dt * 1e3)}
+
+
+# ------------------------------------------------------------------------------------------ main
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU per step (0 = model default)")
     ap.add_argument("--chunk", type=int, default=0, help="engine forward chunk (0 = model default)")
-    ap.add_argument("--model", default="ECAPA_TDNN_GLOB_c512",
+    ap.add_argument("--model", default=None,
                     help="reference constructor name: ECAPA_TDNN[_GLOB]_c{512,1024}, ResNet{18,34,50,221,...}, "
-                         "CAMPPlus")
+                         "CAMPPlus (default: ECAPA_TDNN_GLOB_c512, or the workload's model)")
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS),
+                    help="vox1o: a VoxCeleb1-O-sized set (4874 utts, 37611 trials), ResNet34 unless --model says "
+                         "otherwise; stream10k: 10000 utts through CAM++ -- fixed total size, strong scaling")
+    ap.add_argument("--total-utts", type=int, default=0,
+                    help="fixed-size set of this many utterances sharded over the ranks (strong scaling)")
+    ap.add_argument("--set-trials", type=int, default=-1, help="trial pairs rank 0 scores per step of a fixed-size set")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--trials", type=int, default=1000000)
     ap.add_argument("--cpu-utts", type=int, default=1500)
@@ -163,33 +253,169 @@ def main():
                     help="timed windows of --steps steps per back-end (the first one of the headline back-end "
                          "is the contract's timed region = `value`; all of them give median / spread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the compact legs of the other BASELINE configs")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the --precision back-end: no other back-ends, no ECAPA-1024 leg, no PLDA, no CPU "
+                    help="only the --precision back-end: no other back-ends, no config legs, no PLDA, no CPU "
                          "baseline (for rocprofv3 runs: the kernel statistics then describe one workload)")
     ap.add_argument("--precision", default="fp32", choices=list(BACKENDS),
                     help="back-end of the headline (`value`): fp32 = the reference's arithmetic (default); "
                          "f16x3 / f16 are the declared fast modes, always reported under `backends`")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank, world, local_rank = parallel.init_distributed()
-    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    self_launch_if_needed(argv, args.gpus)
+
+    rank, world, local_rank = parallel.init_distributed("gloo" if STUB else None)
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node equal to --gpus, "
+                         "or just `python bench.py --gpus N`)" % (world, args.gpus))
     # WS_SHARE_GPU=1 (debug): all ranks use GPU 0 (with WS_DIST_BACKEND=gloo) so that the N > 1 control
     # flow can be exercised on a single-GPU box
-    device = torch.device("cuda", 0 if os.environ.get("WS_SHARE_GPU") else local_rank)
-    torch.cuda.set_device(device)
+    if STUB:
+        device = torch.device("cpu")
+    else:
+        device = torch.device("cuda", 0 if os.environ.get("WS_SHARE_GPU") else local_rank)
+        torch.cuda.set_device(device)
 
-    name = args.model
+    set_mode = args.workload != "default" or args.total_utts > 0
+    w_model, w_utts, w_trials = WORKLOADS.get(args.workload, (None, 0, 0))
+    name = args.model or w_model or "ECAPA_TDNN_GLOB_c512"
+    total_utts = args.total_utts or w_utts
+    set_trials = args.set_trials if args.set_trials >= 0 else (w_trials if args.workload != "default" else 37611)
     fam = name[:5]
     E = EMBED_DIM.get(fam, 256)
     dbatch, dchunk = DEFAULT_BATCH.get(name, DEFAULT_BATCH.get(fam, (256, 256)))
     batch = args.batch or dbatch
     chunk = args.chunk or min(dchunk, batch)
     num_samples = int(args.seconds * 16000)
-    sd = synth.synth_state_dict(name, 80, E, seed=42)
-    fe = Frontend(16000, 80, device=device)
-    T = fe.num_frames(num_samples)
-    model = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=E, device=device, max_batch=chunk, max_frames=T)
-    wav = device_wavs(batch, num_samples, device, seed_base=rank)
+
+    def sync():
+        if not STUB:
+            torch.cuda.synchronize(device)
+
+    nccl = world > 1 and dist.get_backend() == "nccl"
+
+    def fence():
+        if world > 1:
+            if nccl:
+                dist.barrier(device_ids=[device.index])
+            else:
+                dist.barrier()
+        sync()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_model(model_name, embed_dim, max_batch, frames):
+        if STUB:
+            return StubExtractor(embed_dim, num_samples)
+        from wespeaker_amd import NativeSpeakerModel
+        sd = synth.synth_state_dict(model_name, 80, embed_dim, seed=42)
+        return NativeSpeakerModel(model_name, sd, feat_dim=80, embed_dim=embed_dim, device=device,
+                                  max_batch=max_batch, max_frames=frames)
+
+    if STUB:
+        fe, T = None, 198
+    else:
+        from wespeaker_amd import Frontend
+        fe = Frontend(16000, 80, device=device)
+        T = fe.num_frames(num_samples)
+
+    # ======================================================================= fixed-size set (strong scaling)
+    def run_set(model_name, embed_dim, n_utts, n_trials, prec, steps, warmup, per_batch, per_chunk, model=None):
+        """U utterances cut into contiguous shards (parallel.shard_range), every rank walks its shard in batches,
+        one all_gather, rank 0 scores `n_trials` (PLDA LLR + cosine).  One step = the whole set."""
+        lo, hi = parallel.shard_range(n_utts, rank, world)
+        n_local = hi - lo
+        m = model or make_model(model_name, embed_dim, min(per_chunk, max(1, n_local)), T)
+        m.set_precision(prec)
+        if STUB:
+            g = torch.Generator().manual_seed(99)
+            allw = (3000.0 * torch.randn(n_utts, num_samples, generator=g)).round().to(torch.int16)
+            wav = allw[lo:hi].contiguous()
+        else:
+            wav = device_wavs(max(1, n_local), num_samples, device, seed_base=1000 + rank)[:n_local]
+        scorer = None
+        if rank == 0 and n_trials > 0 and not STUB:
+            from wespeaker_amd import TwoCovPLDA
+            from wespeaker_amd import score as wscore
+            pp = synth.synth_plda(embed_dim, seed=7)
+            plda = TwoCovPLDA.from_params(pp["mu"], pp["transform"], pp["psi"], pp["offset"], False, device=device)
+            ie, it = synth.synth_trial_pairs(n_trials, n_utts, n_utts, seed=99)
+            ie_d, it_d = torch.from_numpy(ie).to(device), torch.from_numpy(it).to(device)
+
+            def scorer(emb):
+                tt = plda.prepare_test(emb)
+                llr = plda.llr_pairs(tt, 1, tt, ie_d, it_d)
+                tab = wscore.UnitTable(emb, device=device)
+                cos = wscore.cosine_pairs(tab, tab, ie_d, it_d)
+                return llr, cos
+
+        def one_pass():
+            outs = [m.extract(fe, wav[b0:min(n_local, b0 + per_batch)]) for b0 in range(0, n_local, per_batch)]
+            local = torch.cat(outs, 0) if outs else torch.zeros((0, embed_dim), dtype=torch.float32, device=device)
+            emb = parallel.gather_rows(local, n_utts)
+            sc = scorer(emb) if scorer is not None else None
+            return emb, sc
+
+        for _ in range(warmup):
+            one_pass()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            emb, sc = one_pass()
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        m.check_range()
+        res = {"model": model_name, "precision": prec, "total_utts": n_utts, "trials_scored_per_step": n_trials,
+               "value": n_utts * steps / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3,
+               "steps": steps, "shard": "rank r of %d takes utterances [r*ceil(U/G), (r+1)*ceil(U/G)) "
+                                         "(parallel.shard_range = tools/extract_embedding.sh's split rule)" % world,
+               "per_rank_utts": parallel.shard_size(n_utts, world), "batch": per_batch}
+        if sc is not None:
+            res["trials_per_s_inside_the_step"] = n_trials * steps / dt
+            res["scores_finite"] = bool(torch.isfinite(sc[0]).all()) and bool(torch.isfinite(sc[1]).all())
+        if rank == 0:
+            assert emb.shape == (n_utts, embed_dim) and bool(torch.isfinite(emb).all())
+            res["embedding_checksum"] = float(emb.double().abs().sum().item())
+        return res, m
+
+    if set_mode:
+        res, _ = run_set(name, E, total_utts, set_trials, args.precision, args.steps, args.warmup, batch, chunk)
+        if rank == 0:
+            line = {
+                "metric": METRIC, "value": res["value"], "unit": "embeddings/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
+                "config": {"workload": "%s fbank80 E=%d, FIXED set of %d x %.0f s @16 kHz PCM16 utts sharded over %d "
+                                       "GPU(s) (wav resident in HBM -> fbank -> CMN -> forward -> all_gather -> rank 0 "
+                                       "scores %d trials: PLDA LLR + cosine), one step = the whole set"
+                                       % (name, E, total_utts, args.seconds, world, set_trials),
+                           "total_utts": total_utts, "trials": set_trials, "per_gpu_batch": batch,
+                           "engine_chunk": chunk, "frames": T, "parallelism": "utterance-sharded x%d" % world},
+                "set": res,
+            }
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            fence()
+            dist.destroy_process_group()
+        return
+
+    # ======================================================================= default: per-step batches (weak scaling)
+    model = make_model(name, E, chunk, T)
+    if STUB:
+        g = torch.Generator().manual_seed(1234 + rank)
+        wav = (3000.0 * torch.randn(batch, num_samples, generator=g)).round().to(torch.int16)
+    else:
+        wav = device_wavs(batch, num_samples, device, seed_base=rank)
     n_total = batch * world
 
     # N > 1: the all_gather of step k is issued asynchronously (RCCL's own stream) and joined two steps later, so it
@@ -209,69 +435,35 @@ def main():
             last = in_flight.pop(0).wait()
         return last
 
-    nccl = world > 1 and dist.get_backend() == "nccl"
-
-    def fence():
-        if world > 1:
-            if nccl:
-                dist.barrier(device_ids=[device.index])
-            else:
-                dist.barrier()
-        torch.cuda.synchronize(device)
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device if nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
     def timed_window(steps):
         """EXACTLY `steps` steps between two fences; max over ranks; HIP events bracket only the dominant
         kernel class inside it (events around all ~45 launches per chunk cost ~12 %)."""
         fence()
-        model.profile(1)
+        if not STUB:
+            model.profile(1)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         out = drain(out)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
-        prof = model.profile_read()[DOMINANT]
-        model.profile(False)
+        prof = None
+        if not STUB:
+            prof = model.profile_read()[DOMINANT]
+            model.profile(False)
         return dt, prof, out
 
-    def run_backend(prec, steps, warmup, windows):
-        model.set_precision(prec)
-        for _ in range(warmup):
-            step()
-        drain(None)
-        dts, profs, out = [], [], None
-        for _ in range(windows):
-            dt, prof, out = timed_window(steps)
-            dts.append(dt)
-            profs.append(prof)
-        model.check_range()                                    # binary16 back-ends: loud on overflow
-        # untimed pass with every kernel class bracketed, for the per-class breakdown only
-        model.profile(True)
-        bsteps = min(steps, 5)
-        for _ in range(bsteps):
-            step()
-        drain(None)
-        fence()
-        breakdown = model.profile_read()
-        model.profile(False)
-        vals = [n_total * steps / d for d in dts]
+    def roofline_block(m, model_name, prec, steps, dt0, profs, breakdown, bsteps, per_batch):
         g = profs[0]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         ach_all = [p["flops"] / (p["ms"] * 1e-3) / 1e12 for p in profs if p["ms"] > 0]
         peak = FP32_MFMA_PEAK_TFLOPS if prec == "fp32" else F16_MFMA_PEAK_TFLOPS
         total_ms = sum(breakdown[c]["ms"] for c in breakdown)
         gemm_ms = sum(breakdown[c]["ms"] for c in breakdown if c.startswith("gemm"))
-        flops_utt = model.flops(1, T)
-        whole = flops_utt * batch * steps / dts[0] / 1e12       # per GPU
+        flops_utt = m.flops(1, T)
+        whole = flops_utt * per_batch * steps / dt0 / 1e12       # per GPU
         roof = {
-            "kernel": kernel_text(name, prec), "bound": "mfma",
+            "kernel": kernel_text(model_name, prec), "bound": "mfma",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None,
             "achieved_median_over_windows": statistics.median(ach_all) if ach_all else None,
@@ -291,15 +483,13 @@ def main():
                             % (3 * achieved, 3 * achieved / peak))
         # HBM traffic of the dominant kernel class: separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed aggregate of the newest round
-        tag = "" if name == "ECAPA_TDNN_GLOB_c512" else "_" + name
-        for rnd in ("r02", "r01"):
+        tag = "" if model_name == "ECAPA_TDNN_GLOB_c512" else "_" + model_name
+        for rnd in ("r03", "r02", "r01"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_dominant_kernel_%s%s.json" % (rnd, prec, tag))
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fpmc:
                     pmc = json.load(fpmc)
                 # per launch of THIS line's class: the counted kernels' bytes per forward / the launches per step
-                # counted here (the counter table also holds the two split-K dispatches of the embedding layers,
-                # which share the kernel name: bytes negligible, but they would dilute a per-dispatch average)
                 per_fwd = pmc.get("dominant_bytes_per_forward")
                 lps = g["launches"] / float(steps)             # launches of the class per step (= per forward)
                 roof["traffic"] = per_fwd / lps if per_fwd and lps else pmc.get("traffic_bytes_per_launch")
@@ -311,90 +501,189 @@ def main():
                 if "mfma_busy_fraction_of_cycles" in pmc:
                     roof["pmc_mfma_busy_fraction_of_cycles"] = pmc["mfma_busy_fraction_of_cycles"]
                 break
+        return roof
+
+    def run_backend(prec, steps, warmup, windows):
+        model.set_precision(prec)
+        for _ in range(warmup):
+            step()
+        drain(None)
+        dts, profs, out = [], [], None
+        for _ in range(windows):
+            dt, prof, out = timed_window(steps)
+            dts.append(dt)
+            profs.append(prof)
+        model.check_range()                                    # binary16 back-ends: loud on overflow
+        vals = [n_total * steps / d for d in dts]
         block = {"precision": prec, "dtype": DTYPE_TEXT[prec], "value": vals[0], "unit": "embeddings/s",
                  "ms_per_step": dts[0] / steps * 1e3, "steps": steps, "warmup": warmup,
                  "windows_embeddings_per_s": [round(v, 1) for v in vals],
                  "median": statistics.median(vals), "min": min(vals), "max": max(vals),
-                 "spread_rel": (max(vals) - min(vals)) / statistics.median(vals),
-                 "roofline": roof}
+                 "spread_rel": (max(vals) - min(vals)) / statistics.median(vals)}
+        if not STUB:
+            # untimed pass with every kernel class bracketed, for the per-class breakdown only
+            model.profile(True)
+            bsteps = min(steps, 5)
+            for _ in range(bsteps):
+                step()
+            drain(None)
+            fence()
+            breakdown = model.profile_read()
+            model.profile(False)
+            block["roofline"] = roofline_block(model, name, prec, steps, dts[0], profs, breakdown, bsteps, batch)
         return block, out
 
     # ---- headline back-end first: W warmup steps, then the contract's timed region (window 0)
     blocks = {}
     blocks[args.precision], all_emb = run_backend(args.precision, args.steps, args.warmup, max(1, args.windows))
-    if not args.headline_only:
+
+    # ---- rows of the TIMED output against a small-batch run of the same utterances (the timed kernels did the work)
+    self_check = None
+    if rank == 0 and not STUB:
+        rows = sorted({0, 1, batch // 2, batch - 1})
+        small = model.extract(fe, wav[rows])
+        big = all_emb[rows].to(small.device)
+        rel = ((big - small).norm(dim=1) / small.norm(dim=1)).max().item()
+        tol = 2e-4 if args.precision != "f16" else 5e-3
+        self_check = {"rows": rows, "max_rel_l2_vs_small_batch_run": rel, "tolerance": tol, "ok": bool(rel <= tol),
+                      "what": "rows of the last timed step's output vs the same utterances extracted as a batch of "
+                              "%d (other tile shapes / kernels; not bit-equal: a row's position in the 64-row tiles "
+                              "moves the fp32 summation order of the SE / context statistics)" % len(rows)}
+        assert self_check["ok"], self_check
+
+    if not args.headline_only and not STUB:
         for other in [m for m in BACKENDS if m != args.precision]:
             blocks[other], _ = run_backend(other, max(3, min(args.steps, 10)), 2, max(1, min(args.windows, 3)))
     model.set_precision(args.precision)
 
-    # ---- BASELINE.json configs[1] beside the default headline: ECAPA-TDNN-1024, same 256 x 2 s batch
-    big_info = None
-    if rank == 0 and not args.headline_only and name == "ECAPA_TDNN_GLOB_c512":
-        big_name = "ECAPA_TDNN_GLOB_c1024"
-        big = NativeSpeakerModel(big_name, synth.synth_ecapa_state_dict(big_name, 80, 192, seed=42),
-                                 feat_dim=80, embed_dim=192, device=device, max_batch=chunk, max_frames=T)
-        big_info = {"model": big_name, "unit": "embeddings/s per GPU", "backends": {}}
-        for prec in ((args.precision, "f16") if args.precision != "f16" else ("f16",)):
-            big.set_precision(prec)
-            for _ in range(2):
-                big.extract(fe, wav)
-            torch.cuda.synchronize(device)
-            kb = max(3, min(args.steps, 10))
-            tb = time.perf_counter()
-            for _ in range(kb):
-                big.extract(fe, wav)
-            torch.cuda.synchronize(device)
-            bdt = (time.perf_counter() - tb) / kb
-            big_info["backends"][prec] = {"value": batch / bdt, "ms_per_step": bdt * 1e3, "steps": kb,
-                                          "model_tflops": big.flops(1, T) * batch / bdt / 1e12}
-        del big
+    # ---- the other BASELINE.json configs, compact: per model one fp32 leg with its dominant-class fraction (HIP
+    # events) + the f16 rate; and the two fixed-size sets (configs 2 / 3) at this N
+    configs = None
+    if rank == 0 and world == 1 and not args.headline_only and not args.no_configs and not STUB \
+            and name == "ECAPA_TDNN_GLOB_c512":
+        configs = {}
+        keep = {}
+        for cname in ("ECAPA_TDNN_GLOB_c1024", "ResNet34", "ResNet221", "CAMPPlus"):
+            cfam = cname[:5]
+            cE = EMBED_DIM.get(cfam, 256)
+            cb, cc = DEFAULT_BATCH.get(cname, DEFAULT_BATCH.get(cfam, (256, 256)))
+            cm = make_model(cname, cE, cc, T)
+            cw = wav if cb == batch else device_wavs(cb, num_samples, device, seed_base=77)
+            leg = {"model": cname, "batch": cb, "unit": "embeddings/s"}
+            for prec in ("fp32", "f16"):
+                cm.set_precision(prec)
+                ks = 3 if cname == "ResNet221" else 6
+                for _ in range(2):
+                    cm.extract(fe, cw)
+                sync()
+                cm.profile(1)
+                tb = time.perf_counter()
+                for _ in range(ks):
+                    cm.extract(fe, cw)
+                sync()
+                cdt = time.perf_counter() - tb
+                pr = cm.profile_read()[DOMINANT]
+                cm.profile(False)
+                cm.check_range()
+                peak = FP32_MFMA_PEAK_TFLOPS if prec == "fp32" else F16_MFMA_PEAK_TFLOPS
+                ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12 if pr["ms"] > 0 else 0.0
+                whole = cm.flops(1, T) * cb * ks / cdt / 1e12
+                leg[prec] = {"value": cb * ks / cdt, "ms_per_step": cdt / ks * 1e3, "steps": ks,
+                             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                          "frac": ach / peak, "kernel": "dominant class (every conv/linear with "
+                                          "N > 64), HIP events inside this window",
+                                          "whole_step_frac_of_peak": whole / peak}}
+            configs[cname] = leg
+            keep[cname] = cm
+        # configs 2 / 3 as fixed-size sets on this one GPU (N > 1: `bench.py --gpus N --workload vox1o|stream10k`)
+        sets = {}
+        for wl, mname in (("vox1o", "ResNet34"), ("vox1o", "ResNet221"), ("stream10k", "CAMPPlus")):
+            _, u, tr = WORKLOADS[wl]
+            cfam = mname[:5]
+            cb, cc = DEFAULT_BATCH.get(mname, DEFAULT_BATCH.get(cfam, (256, 256)))
+            r, _ = run_set(mname, EMBED_DIM.get(cfam, 256), u, tr, "fp32", 1 if mname == "ResNet221" else 2, 1,
+                           cb, cc, model=keep[mname])
+            sets["%s_%s" % (wl, mname)] = r
+        configs["fixed_size_sets_n1_fp32"] = sets
+        del keep
 
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
-    if rank == 0 and not args.headline_only:
-        p = synth.synth_plda(192, seed=7)
+    if rank == 0 and not args.headline_only and not STUB:
+        from wespeaker_amd import TwoCovPLDA
+        D = 192
+        p = synth.synth_plda(D, seed=7)
         plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
         n_emb = 10000
-        emb_tab, _ = synth.synth_embeddings(2 * n_emb, 192, seed=11)
+        emb_tab, _ = synth.synth_embeddings(2 * n_emb, D, seed=11)
         emb_tab = torch.from_numpy(emb_tab).to(device)
         ie, it = synth.synth_trial_pairs(args.trials, n_emb, n_emb, seed=99)
         ie_d, it_d = torch.from_numpy(ie).to(device), torch.from_numpy(it).to(device)
         nn = 1          # multisession_avg=True: every enrollment model counts as one session
 
-        def plda_step():
-            e_t = plda.prepare_test(emb_tab[:n_emb])
-            t_t = plda.prepare_test(emb_tab[n_emb:])
-            return plda.llr_pairs(e_t, nn, t_t, ie_d, it_d)
+        def timed(fn, k):
+            for _ in range(2):
+                fn()
+            sync()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            ev0.record()
+            for _ in range(k):
+                fn()
+            ev1.record()
+            sync()
+            return (time.perf_counter() - t1) / k, ev0.elapsed_time(ev1) * 1e-3 / k
 
-        for _ in range(2):
-            plda_step()
-        torch.cuda.synchronize(device)
         k = max(3, min(args.steps, 20))
-        t1 = time.perf_counter()
-        for _ in range(k):
-            plda_step()
-        torch.cuda.synchronize(device)
-        pdt = (time.perf_counter() - t1) / k
-        e_t = plda.prepare_test(emb_tab[:1000])
-        t_t = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
-        for _ in range(2):
-            plda.llr_matrix(e_t, nn, t_t)
-        torch.cuda.synchronize(device)
-        t2 = time.perf_counter()
-        for _ in range(k):
-            plda.llr_matrix(e_t, nn, t_t)
-        torch.cuda.synchronize(device)
-        mdt = (time.perf_counter() - t2) / k
-        plda_info = {"pairs_trials_per_s": args.trials / pdt, "pairs_ms": pdt * 1e3,
-                     "pairs_workload": "%d index pairs over 2x%d embeddings D=192 incl. transform"
-                                       % (args.trials, n_emb),
-                     "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
-                     "matrix_workload": "dense 1000x1000 LLR matrix D=192", "dtype": "f64"}
+        e_t = plda.prepare_test(emb_tab[:n_emb])
+        t_t = plda.prepare_test(emb_tab[n_emb:])
+
+        def plda_step():
+            a = plda.prepare_test(emb_tab[:n_emb])
+            b = plda.prepare_test(emb_tab[n_emb:])
+            return plda.llr_pairs(a, nn, b, ie_d, it_d)
+
+        pdt, _ = timed(plda_step, k)
+        _, pair_dev = timed(lambda: plda.llr_pairs(e_t, nn, t_t, ie_d, it_d), k)
+        e1k = plda.prepare_test(emb_tab[:1000])
+        t1k = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
+        mdt, mat_dev = timed(lambda: plda.llr_matrix(e1k, nn, t1k), k)
+        # a trial gathers one enrollment and one test row (uniform n: D doubles each), reads its two
+        # int32 indices and writes one double -- the tables (2 x 10 k x 192 x 8 B = 30.7 MB) live in L2 / Infinity
+        # Cache, so this is a cache-gather, priced against the HBM peak as the contract's unit
+        bpt = 2 * D * 8 + 8 + 8
+        pair_gbs = args.trials * bpt / pair_dev / 1e9
+        mat_tf = 2.0 * 1000 * 1000 * D / mat_dev / 1e12
+        plda_info = {
+            "pairs_trials_per_s": args.trials / pdt, "pairs_ms": pdt * 1e3,
+            "pairs_workload": "%d index pairs over 2x%d embeddings D=%d incl. transform" % (args.trials, n_emb, D),
+            "pairs_kernel_only_trials_per_s": args.trials / pair_dev, "pairs_kernel_only_ms": pair_dev * 1e3,
+            "roofline": {"kernel": "plda_llr_pairs (16 lanes per trial, double2 gathers of the [g*e] and [t] rows, "
+                                   "16-lane shuffle reduce)",
+                         "bound": "hbm", "achieved": pair_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": pair_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_trial": bpt,
+                         "note": "gather rows come from L2 / Infinity Cache (30.7 MB of tables), not HBM: the fraction "
+                                 "is algorithmic gather bytes over the HBM peak; HBM itself only sees the 8 MB index "
+                                 "list and the 8 MB score vector per launch"},
+            "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
+            "matrix_workload": "dense 1000x1000 LLR matrix D=%d" % D,
+            "matrix_roofline": {"kernel": "plda_gemm_f64 (v_mfma_f64_16x16x4_f64, 64x64 tiles)", "bound": "mfma",
+                                "achieved": mat_tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": mat_tf / F64_MFMA_PEAK_TFLOPS,
+                                "note": "0.38 GFLOP + 8 MB of output in one %.0f-us launch: latency-bound at this "
+                                        "size, not MFMA-bound" % (mat_dev * 1e6)},
+            "dtype": "f64"}
+        if world == 1 and not args.no_cpu_baseline:
+            plda_info["cpu_baseline"] = plda_cpu_baseline(
+                {"mu": p["mu"], "transform": p["transform"], "psi": p["psi"], "offset": p["offset"],
+                 "normalize_length": False},
+                e_t.cpu().numpy(), t_t.cpu().numpy(), ie, it)
 
     if rank == 0:
         head = blocks[args.precision]
         line = {
-            "metric": "embeddings/sec (2 s utts, ECAPA-512) + PLDA trials/sec at 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": head["value"],
             "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -414,7 +703,8 @@ def main():
                              "`backends`" % args.precision,
             "value_median_over_windows": head["median"],
             "value_spread_rel": head["spread_rel"],
-            "roofline": head["roofline"],
+            "roofline": head.get("roofline"),
+            "self_check": self_check,
             "backends": blocks,
             "fast_mode": ({"precision": "f16", "value": blocks["f16"]["value"],
                            "median": blocks["f16"]["median"],
@@ -422,9 +712,11 @@ def main():
             "plda_trials_per_s": plda_info["pairs_trials_per_s"] if plda_info else None,
             "plda": plda_info,
         }
-        if big_info:
-            line["config1_ecapa_tdnn_1024"] = big_info
-        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
+        if configs:
+            line["configs"] = configs
+        if STUB:
+            line["embedding_checksum"] = float(all_emb.double().abs().sum().item())
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only and not STUB:
             heavy = name.startswith("ResNet") and name not in ("ResNet18", "ResNet34")
             line["cpu_baseline"] = cpu_baseline(name, E, args.cpu_utts, budget_s=6.0 if heavy else 8.0)
         assert all_emb.shape == (n_total, E) and bool(torch.isfinite(all_emb).all())

@@ -26,7 +26,10 @@ def test_header_symbols_exported_and_bound(built_lib):
 
 
 def test_pure_host_entry_points(built_lib):
-    assert built_lib.ws_version() >= 100
+    # the library, the header and the ctypes bindings agree on the C-ABI version
+    with open(os.path.join(ROOT, "include", "wespeaker_amd.h")) as f:
+        header_version = int(re.search(r"#define\s+WS_VERSION\s+(\d+)", f.read()).group(1))
+    assert built_lib.ws_version() == header_version == _lib.ABI_VERSION
     # frame-count known answers from the reference: 2 s @ 16 kHz -> 198 frames
     # (runtime/server/x86_gpu/README.md:35-53), num_frames + 2 == seg_length in 10 ms units
     assert built_lib.ws_num_frames(32000, 16000) == 198

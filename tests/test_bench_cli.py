@@ -1,0 +1,53 @@
+"""bench.py's own launch / sharding / gather / JSON logic on CPU (world size 2, gloo) with the host stand-in for
+the extractor (WS_BENCH_STUB=1): `python bench.py --gpus 2` must launch itself -- the driver's N = 1 command form
+used at N > 1 -- like the reference's launcher spawns its per-GPU jobs (tools/extract_embedding.sh:46-65)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env_extra=None):
+    env = dict(os.environ, WS_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                      # a clean shell: the self-launch path
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_fixed_size_set_two_ranks_equals_one_rank():
+    """--total-utts: contiguous shards (37 utterances -> 19 + 18), one gather, strong scaling; the gathered table of the
+    self-launched two-rank run equals the one-rank run's."""
+    one = run_bench("--gpus", "1", "--total-utts", "37", "--batch", "8", "--steps", "2", "--warmup", "1")
+    two = run_bench("--gpus", "2", "--total-utts", "37", "--batch", "8", "--steps", "2", "--warmup", "1")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert two["set"]["per_rank_utts"] == 19 and one["set"]["per_rank_utts"] == 37
+    assert two["config"]["total_utts"] == 37 and two["steps"] == 2 and two["warmup"] == 1
+    assert two["value"] > 0 and two["unit"] == "embeddings/s"
+    a, b = one["set"]["embedding_checksum"], two["set"]["embedding_checksum"]
+    assert abs(a - b) <= 1e-6 * abs(a)
+
+
+def test_default_mode_self_launch_is_weak_scaling():
+    d = run_bench("--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--windows", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["per_gpu_batch"] == 8
+    assert d["value"] > 0 and d["higher_is_better"] is True
+    assert d["metric"].startswith("embeddings/sec")
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WS_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus" in r.stderr

@@ -684,6 +684,49 @@ def test_full_size_resnet34_f16_spot_check():
     assert bool(torch.isfinite(full).all())
 
 
+@pytest.mark.parametrize("name,E,batch,prec", [
+    ("ECAPA_TDNN_GLOB_c1024", 192, 256, "fp32"),
+    ("ResNet34", 256, 512, "fp32"),
+    ("ResNet221", 256, 256, "fp32"), ("ResNet221", 256, 256, "f16"),
+    ("CAMPPlus", 512, 512, "fp32"), ("CAMPPlus", 512, 512, "f16"),
+])
+def test_full_size_every_bench_workload(name, E, batch, prec):
+    """Every (workload, back-end) pair bench.py reports that had no full-size check: the BASELINE batch of 2 s
+    utterances at the engine chunk bench.py uses -- the shapes at which the dispatcher picks its big-tile / persistent
+    kernels (tests/golden/dispatch_* pins WHICH kernel, this pins that it is RIGHT) and at which the activation maps
+    come closest to the 2^31-element guards.  Oracle rows spread over the tile phases, equality with a small-batch
+    run of the same utterances, run-to-run bits, finiteness of all rows."""
+    from oracle import campplus as ocampplus
+    from oracle import resnet as oresnet
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_state_dict(name, 80, E, seed=13)
+    model = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=E, max_batch=batch, max_frames=198)
+    fe = Frontend(16000, 80)
+    wav = device_wavs(batch, 32000, model.device, 31)
+    model.set_precision(prec)
+    full = model.extract(fe, wav)
+    rows = [0, 1, 63, batch // 2 - 1, batch // 2, batch - 65, batch - 2, batch - 1]
+    if name == "ResNet221":
+        rows = rows[::2] + [batch - 1]                       # the oracle takes ~1 s per utterance here
+    feats = np.stack([ofbank.speaker_features(wav[i].cpu().numpy()) for i in rows])
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    if name.startswith("ECAPA"):
+        ref = oecapa.ecapa_forward(sdt, feats).numpy()
+    elif name.startswith("ResNet"):
+        ref = oresnet.resnet_forward(sdt, feats, name).numpy()
+    else:
+        ref = ocampplus.campplus_forward(sdt, feats).numpy()
+    tol = 5e-4 if prec == "fp32" else (F16_REL_TOL_DEEP if name == "ResNet221" else F16_REL_TOL)
+    got = full[rows].cpu().numpy()
+    assert _cos_err(got, ref).max() < COS_TOL, _cos_err(got, ref).max()
+    assert _rel_err(got, ref).max() < tol, _rel_err(got, ref).max()
+    small = model.extract(fe, wav[rows])
+    assert _rel_err(small.cpu().numpy(), got).max() < (1e-5 if prec == "fp32" else tol)
+    assert torch.equal(model.extract(fe, wav), full)          # same launch sequence -> same bits
+    assert bool(torch.isfinite(full).all())
+
+
 def test_full_size_plda_one_million_trials():
     """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
@@ -1094,12 +1137,15 @@ def test_extract_driver_two_ranks_on_one_gpu(tmp_path):
     base = [sys.executable, "-m", "wespeaker_amd.extract", "--exp_dir", mdir, "--model_path",
             os.path.join(mdir, "avg_model.pt"), "--data_type", "raw", "--data_list", str(tmp_path / "raw.list"),
             "--wavs_num", str(n), "--nj", "4", "--batch_size", "1"]
-    env = dict(os.environ, PYTHONPATH=root, WS_SHARE_GPU="1", WS_DIST_BACKEND="gloo")
+    # WS_COLLECTIVES_ON_GPU: the gather=True collectives carry GPU tensors like under nccl / RCCL (whose process
+    # group has no CPU path -- the placement bug of round 2 could only show on a multi-GPU node)
+    env = dict(os.environ, PYTHONPATH=root, WS_SHARE_GPU="1", WS_DIST_BACKEND="gloo", WS_COLLECTIVES_ON_GPU="1")
     r1 = subprocess.run(base + ["--store_dir", "one"], env=env, cwd=root, stdout=subprocess.PIPE,
                         stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29871"] + base[1:] + ["--store_dir", "two"],
+                         "--master-addr", "127.0.0.1", "--master-port", "29871"] + base[1:] +
+                        ["--store_dir", "two", "--gather_npz", str(tmp_path / "gathered.npz")],
                         env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r2.returncode == 0, r2.stdout[-2000:]
     d1, d2 = os.path.join(mdir, "embeddings", "one"), os.path.join(mdir, "embeddings", "two")
@@ -1110,6 +1156,9 @@ def test_extract_driver_two_ranks_on_one_gpu(tmp_path):
     assert list(m1) == list(m2) == ["utt%02d" % i for i in range(n)]
     assert all(np.array_equal(m1[k], m2[k]) for k in m1)
     assert open(os.path.join(d2, "extract.result")).read().startswith("Successfully extract embedding")
+    # gather=True: every row of the list, in list order, on rank 0 -- equal to what the arks hold
+    g = np.load(str(tmp_path / "gathered.npz"))
+    assert list(g["keys"]) == list(m2) and np.array_equal(g["emb"], np.stack([m2[k] for k in m2]))
 
 
 # =============================== ragged batches: utterances of different lengths in one device batch

@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwespeaker_amd.so")
 
 _lib = None
 
+ABI_VERSION = 101      # = WS_VERSION of include/wespeaker_amd.h
+
 # name -> (restype, argtypes); also used by the ABI test to check every header symbol is exported
 SIGNATURES = {
     "ws_version": (c_int, []),
@@ -97,6 +99,11 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        # the signatures above are those of include/wespeaker_amd.h at WS_VERSION: a stale build would take
+        # shifted arguments silently
+        if handle.ws_version() != ABI_VERSION:
+            raise NativeError("%s reports C-ABI version %d, these bindings are for %d: rebuild it "
+                              "(python -m wespeaker_amd.build)" % (LIB_PATH, handle.ws_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -42,14 +42,22 @@ bool read_wav(const std::string& path, std::vector<int16_t>* pcm, int* sample_ra
   uint32_t rate = 0;
   while (f.read(id, 4) && f.read(reinterpret_cast<char*>(&size), 4)) {
     if (std::memcmp(id, "fmt ", 4) == 0) {
+      if (size < 16 || size > 4096) return false;          // a PCM fmt chunk is 16 bytes (+ extension)
       std::vector<char> b(size);
-      f.read(b.data(), size);
+      if (!f.read(b.data(), size)) return false;
       std::memcpy(&fmt, b.data(), 2); std::memcpy(&channels, b.data() + 2, 2);
       std::memcpy(&rate, b.data() + 4, 4); std::memcpy(&bits, b.data() + 14, 2);
     } else if (std::memcmp(id, "data", 4) == 0) {
       if (fmt != 1 || bits != 16 || channels == 0) return false;
+      // the header may lie (0xFFFFFFFF from a streamed recording): never more than the file still holds
+      const std::streamoff here = f.tellg();
+      f.seekg(0, std::ios::end);
+      const std::streamoff left = f.tellg() - here;
+      f.seekg(here);
+      if (left < 0) return false;
+      if ((std::streamoff)size > left) size = (uint32_t)left;
       std::vector<int16_t> raw(size / 2);
-      f.read(reinterpret_cast<char*>(raw.data()), size);
+      f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * 2));
       const size_t got = (size_t)f.gcount() / 2 / channels;
       pcm->resize(got);
       for (size_t i = 0; i < got; ++i) (*pcm)[i] = raw[i * channels];

@@ -49,7 +49,7 @@ struct ws_plda {
 
 extern "C" {
 
-int ws_version(void) { return 100; }
+int ws_version(void) { return WS_VERSION; }
 const char* ws_last_error(void) { return get_error(); }
 
 int ws_num_frames(int num_samples, int sample_rate) {
@@ -303,9 +303,17 @@ int ws_engine_load(const char* path, int device_id, int max_batch, int max_frame
       fail(WS_ERR_INVALID_ARG, "truncated tensor header");
       break;
     }
+    // every dimension checked on its own and the product before it is formed: a negative pair or a wrapped
+    // product must not pass as a small positive element count
     int64_t numel = 1;
-    for (int d = 0; d < ndim; ++d) numel *= shape[d];
-    if (numel < 0 || numel > (int64_t)1 << 31) { fail(WS_ERR_SHAPE, "implausible tensor size"); break; }
+    bool shape_ok = true;
+    for (int d = 0; d < ndim && shape_ok; ++d) {
+      if (shape[d] < 0 || shape[d] > ((int64_t)1 << 31) || (shape[d] > 0 && numel > ((int64_t)1 << 31) / shape[d]))
+        shape_ok = false;
+      else
+        numel *= shape[d];
+    }
+    if (!shape_ok) { fail(WS_ERR_SHAPE, "implausible tensor size"); break; }
     data.resize((size_t)numel);
     if (numel && !rd(data.data(), 4 * (size_t)numel)) { fail(WS_ERR_INVALID_ARG, "truncated tensor data"); break; }
     const int r = ws_engine_set_tensor(eng, key.c_str(), data.data(), ndim, shape);

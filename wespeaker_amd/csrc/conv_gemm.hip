@@ -1966,7 +1966,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
                         (p.d_off & 7) == 0 && (!p.colsum || p.Hout * p.Wout >= 64);
   // (the row mask of ragged batches lives in that binary16 epilogue only -- the fp32 quadrant epilogue has no row
   // operands -- and is written for H = 1; other masked layers stay on the 128x128 kernels)
-  const bool mask_ok = !p.row_len || (epi16_ok && p.Hout == 1);
+  // (its lenA / lenB logic lets a 64-row group span at most two utterances: frames per slot >= 64)
+  const bool mask_ok = !p.row_len || (epi16_ok && p.Hout == 1 && p.Hout * p.Wout >= 64);
   if (use_dma && big && p.N % 256 == 0 && p.N >= (big >= 3 ? 512 : 1024) && !p.pool_partial && !p.bias_img &&
       !p.residual && !p.residual16 && !p.seg_scale && mask_ok) {
     const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;

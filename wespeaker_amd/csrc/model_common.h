@@ -64,9 +64,10 @@ struct ModelBase : Model {
   }
   int take_nonfinite() override {
     if (!nonfinite_host) return 0;
-    const int n = *reinterpret_cast<volatile int*>(nonfinite_host);
-    *reinterpret_cast<volatile int*>(nonfinite_host) = 0;
-    return n;
+    // one atomic exchange: a forward still running on another stream may atomicAdd_system into the counter at
+    // any moment; read-then-clear would drop what lands in between.  (ws_engine_check_range synchronises only the
+    // stream it is given: the count covers what that stream has finished.)
+    return __atomic_exchange_n(reinterpret_cast<int*>(nonfinite_host), 0, __ATOMIC_ACQ_REL);
   }
   // ---- ragged batches: per-utterance valid lengths at the four time-stride levels of the 2-D models
   // (level l+1 = (level l - 1) / 2 + 1, the output width of a k3/p1/s2 -- or k1/s2, k5/p2/s2 -- conv)

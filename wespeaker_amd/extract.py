@@ -608,20 +608,22 @@ def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, b
         return result
     # ---- all ranks: the whole list in list order (job j sits at rows [lo_j, hi_j) for raw/scp lists)
     E = extractor.embed_dim if extractor is not None else 0
+    # (an nccl = RCCL process group has no CPU path: every tensor a collective touches lives on this rank's GPU)
+    # (WS_COLLECTIVES_ON_GPU=1: the same placement under gloo -- how the single-GPU test box runs this branch)
+    use_cuda = multi and (dist.get_backend() == "nccl" or os.environ.get("WS_COLLECTIVES_ON_GPU") == "1")
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
     if multi:
-        e_t = torch.tensor([E])
+        e_t = torch.tensor([E], dtype=torch.int64, device=dev)
         dist.all_reduce(e_t, op=dist.ReduceOp.MAX)
         E = int(e_t.item())
     local = np.concatenate([e for _, e in my_emb]) if my_emb else np.zeros((0, E), np.float32)
     local_keys = [k for _, ks in my_keys for k in ks]
     if not multi:
         return local_keys, local
-    counts = torch.zeros(world, dtype=torch.int64)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
     counts[rank] = local.shape[0]
     dist.all_reduce(counts)
     per = int(counts.max().item())
-    use_cuda = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
     block = torch.zeros((per, E), dtype=torch.float32, device=dev)
     block[:local.shape[0]] = torch.from_numpy(local).to(dev)
     full = parallel.gather_rows(block, per * world).cpu().numpy()
@@ -657,6 +659,9 @@ def main(argv=None):
     ap.add_argument("--max_batch", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpus", default=None, help="accepted for compatibility; ranks map to LOCAL_RANK")
+    ap.add_argument("--gather_npz", default=None,
+                    help="also all_gather the embeddings (every rank gets the whole list in list order); rank 0 "
+                         "writes them here as keys / emb arrays")
     args = ap.parse_args(argv)
     rank, world, local_rank = parallel.init_distributed()
     # WS_SHARE_GPU=1 (debug / single-GPU boxes, with WS_DIST_BACKEND=gloo): every rank uses GPU 0
@@ -671,11 +676,14 @@ def main(argv=None):
                                     precision=args.precision)
         return ex
 
-    run_jobs(read_lists(args.data_list), args.data_type, embed_dir, make, args.nj or world, rank, world,
-             batch_size=args.batch_size, chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
-             max_batch=args.max_batch, resample_rate=fc["resample_rate"], num_workers=args.num_workers,
-             seed=args.seed, resample_fn=_gpu_resampler(device), wavs_num=args.wavs_num,
-             store_dir=args.store_dir)
+    out = run_jobs(read_lists(args.data_list), args.data_type, embed_dir, make, args.nj or world, rank, world,
+                   batch_size=args.batch_size, chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
+                   max_batch=args.max_batch, resample_rate=fc["resample_rate"], num_workers=args.num_workers,
+                   seed=args.seed, resample_fn=_gpu_resampler(device), wavs_num=args.wavs_num,
+                   store_dir=args.store_dir, gather=bool(args.gather_npz))
+    if args.gather_npz and rank == 0:
+        keys, emb = out
+        np.savez(args.gather_npz, keys=np.asarray(keys), emb=emb)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
