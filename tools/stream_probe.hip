@@ -4,7 +4,7 @@
 //         wespeaker_amd/csrc/gemm_f32_stream.hip wespeaker_amd/csrc/conv3x3_direct.hip -o tools/bin/stream_probe
 // For every layer shape of the fp32 back-end's dominant class: whole-output bit compare (D, D2), column sums within
 // rounding, three repeats per mode (race screen), then timing.  Modes (WS_STREAM): 0 tile kernels, 1 four wavefronts,
-// 2 eight wavefronts.  -DWS_TRACE adds per-K-tile cycle stamps.
+// 2 eight wavefronts, 3 the 256x128 tile with eight wavefronts, 4 the dispatcher's choice between 2 and 3.  -DWS_TRACE adds per-K-tile cycle stamps.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(scale, h.data() + 4777, 1536 * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(shift, h.data() + 9777, 1536 * 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int modes[] = {0, 1, 2};
+  const int modes[] = {0, 2, 3, 4};
   for (auto& c : cases) {
     ConvGemmParams p; memset(&p, 0, sizeof(p));
     p.prec = 0;
@@ -104,8 +104,8 @@ int main(int argc, char** argv) {
     // timing: the chip needs milliseconds of load to reach its steady clock, so every measurement is preceded by
     // 40 untimed launches of the same mode, and the modes are walked forwards and then backwards
     for (int pass = 0; pass < 2; ++pass)
-    for (int mi = 0; mi < 3; ++mi) {
-      const int mode = modes[pass == 0 ? mi : 2 - mi];
+    for (int mi = 0; mi < 4; ++mi) {
+      const int mode = modes[pass == 0 ? mi : 3 - mi];
       g_ws_stream = mode;
       for (int i = 0; i < 40; ++i) CK(launch_conv_gemm(p, 0));
       CK(hipDeviceSynchronize());
@@ -117,23 +117,29 @@ int main(int argc, char** argv) {
       const double us = ms * 1e3 / iters, tf = 2.0 * c.M * c.N * c.K / (us * 1e-6) / 1e12;
       printf("  mode %d: %8.1f us  %6.1f TF  (%.3f of 157.3)\n", mode, us, tf, tf / 157.3);
 #ifdef WS_TRACE
-      if (mode == 1 || mode == 2) {
-        unsigned long long tr[256];
-        CK(hipMemcpy(tr, stream_trace_buffer_address(), sizeof(tr), hipMemcpyDeviceToHost));
+      if (mode >= 1) {
+        unsigned long long trb[512];
+        CK(hipMemcpy(trb, stream_trace_buffer_address(), sizeof(trb), hipMemcpyDeviceToHost));
+        for (int wv = 0; wv < (mode == 1 ? 1 : 2); ++wv) {
+        const unsigned long long* tr = trb + 256 * wv;
         const int nk = c.K / 32, show = nk * 3 + 2 < 127 ? nk * 3 + 2 : 127;
-        printf("    K-tile stamps (cycles; ideal 4096): ");
+        printf("    [wave %d, t0 %+lld] K-tile stamps (cycles; ideal 4096 per 64 MFMAs per SIMD): ", 4 * wv, (long long)(tr[0] - trb[0]));
         for (int i = 1; i < show; ++i) printf("%s%lld", (i - 1) % nk == 0 ? " | " : " ", (long long)(tr[i] - tr[i - 1]));
         printf("\n    regular K-tile: g0 %lld adv %lld g1 %lld g2 %lld wait+barrier %lld g3 %lld\n",
                (long long)(tr[129] - tr[128]), (long long)(tr[130] - tr[129]), (long long)(tr[131] - tr[130]),
                (long long)(tr[132] - tr[131]), (long long)(tr[133] - tr[132]), (long long)(tr[134] - tr[133]));
-        printf("    first K-tile:   g0 %lld adv %lld g1 %lld g2 %lld wait+barrier %lld g3 %lld\n",
+        printf("    first K-tile:   g0 %lld adv %lld g1 %lld g2 %lld wait+barrier %lld g3 %lld   (starts %+lld after wave 0's)\n",
                (long long)(tr[145] - tr[144]), (long long)(tr[146] - tr[145]), (long long)(tr[147] - tr[146]),
-               (long long)(tr[148] - tr[147]), (long long)(tr[149] - tr[148]), (long long)(tr[150] - tr[149]));
-        const int nb = mode == 1 ? 4 : 2;
+               (long long)(tr[148] - tr[147]), (long long)(tr[149] - tr[148]), (long long)(tr[150] - tr[149]),
+               (long long)(tr[144] - trb[144]));
+        printf("    of the wait+barrier: regular K-tile vmcnt/lgkmcnt wait %lld, first K-tile %lld\n",
+               (long long)(tr[177] - tr[132]), (long long)(tr[178] - tr[148]));
+        const int nb = mode == 2 ? 2 : 4;
         printf("    last K-tile:    block0 %lld wait+barrier %lld", (long long)(tr[161] - tr[160]), (long long)(tr[162] - tr[161]));
         for (int b = 1; b < nb; ++b)
           printf(" block%d %lld", b, (long long)(tr[b + 1 < nb ? 160 + 2 * (b + 1) : 168] - tr[160 + 2 * b]));
-        printf(" tail %lld\n", (long long)(tr[169] - tr[168]));
+        printf(" tail %lld   (starts %+lld after wave 0's)\n", (long long)(tr[169] - tr[168]), (long long)(tr[160] - trb[160]));
+        }
       }
 #endif
     }

@@ -37,10 +37,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int S_BM = 128, S_BN = 128, S_BK = 32;
-constexpr int S_NSTAGE = 3;
-constexpr int S_STAGE_BYTES = (S_BM + S_BN) * S_BK * 4;       // 32 KiB
-constexpr int S_W_BYTE0 = S_BM * S_BK * 4;                    // W rows behind the A rows of a stage
+constexpr int S_BN = 128, S_BK = 32;
 constexpr int S_SCR_STRIDE = 36;                              // floats per row of the transpose scratch
 constexpr int S_SCR_BYTES = 32 * S_SCR_STRIDE * 4;            // per wavefront
 
@@ -49,39 +46,88 @@ __device__ __forceinline__ void s_dma_16B(const void* g, void* lds_base) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 #endif
 }
+#ifdef WS_TRACE
+__device__ unsigned long long g_stream_trace[512];      // [wavefront 0 | wavefront 4] x 256 slots
+__device__ int g_trace_split = 1;
+#endif
 template <int N>
 __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 #if defined(__HIP_DEVICE_COMPILE__)
   // this wavefront's fragment reads of the stage are complete, its DMA pieces of the next stage have landed
   // (all but the N newest VMEM operations), then the workgroup barrier
+#ifdef WS_EXPERIMENT_NOBARRIER      // timing experiment only (results are wrong): what does the rendezvous cost?
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#elif defined(WS_TRACE)             // the wait and the rendezvous stamped separately (slot 176: after the wait)
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+  if (g_trace_split && blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256))
+    g_stream_trace[176 + threadIdx.x] = __builtin_readcyclecounter();
+  asm volatile("s_barrier" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 #endif
 }
 
 #ifdef WS_TRACE
-__device__ unsigned long long g_stream_trace[256];
 #define WS_SSTAMP(i)                                                                   \
-  { const int _i = (i); if (blockIdx.x == 9 && threadIdx.x == 0 && _i < 128) g_stream_trace[_i] = __builtin_readcyclecounter(); }
+  { const int _i = (i); if (blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256) && _i < 128) g_stream_trace[_i + threadIdx.x] = __builtin_readcyclecounter(); }
 // fine stamps inside ONE K-tile of each kind (slots 128..: regular, 144..: first, 160..: last)
 #define WS_FSTAMP(on, slot)                                                            \
-  if ((on) && blockIdx.x == 9 && threadIdx.x == 0) g_stream_trace[(slot)] = __builtin_readcyclecounter();
+  if ((on) && blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256)) g_stream_trace[(slot) + threadIdx.x] = __builtin_readcyclecounter();
 #else
 #define WS_SSTAMP(i)
 #define WS_FSTAMP(on, slot)
 #endif
 
-// NW = 4: 2 x 2 wavefronts of 64x64 outputs, one wavefront per SIMD (512 registers each);
-// NW = 8: 2 x 4 wavefronts of 64x32 outputs, two per SIMD.
-template <int NW, bool COLSUM>
-__global__ __launch_bounds__(64 * NW, NW / 4)
+// Wavefront grid WM x WN, every wavefront 64 rows x 32 TN columns (TM = 2 row blocks); BM = 64 WM rows, BN = 128:
+//   <2, 2>     four wavefronts of 64x64, 128x128 tile (one wavefront per SIMD)
+//   <2, 1>     eight wavefronts of 64x32, 128x128 tile
+//   <4, 2>     eight wavefronts of 64x64, 256x128 tile, ring of 48-KB K-tiles: two wavefronts per SIMD (a lone
+//              wavefront issues an fp32 MFMA every ~68 cycles, two reach 64) AND 16 fragment reads per 64 MFMAs
+//              instead of 24 -- the K loop of the first two forms runs at ~4400 cycles per 64 MFMAs per SIMD with
+//              or without its barrier (measured with the barrier compiled out): it pays for the fragment reads
+//              and the issue cadence, not for the rendezvous.
+// Three stages always: the DMA pieces of K-tile j + 2 are issued in k-group 0 of K-tile j (stage (j+2)%3 was last
+// read in K-tile j - 1), i.e. two K-tile times in flight.  (A two-stage ring for the 256x128 form -- pieces issued
+// behind the barrier, one K-tile time in flight -- was measured: every K-tile then waits ~350 cycles for its data.)
+// LDS: 3 x 48 KB of stages leave no room for anything else, so (a) the epilogue's transpose scratch of a wavefront
+// lives in the stage that the tile's last K-tile has just left, inside the slice that the SAME wavefront's next
+// DMA pieces will overwrite (nobody else touches it in between), and (b) the bias / scale / shift values are not
+// kept for all N columns: every wavefront DMAs the 3 x 64 values of ITS columns at the start of each tile.
+template <int WM, int TN, bool COLSUM>
+__global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
-  constexpr int WN = NW / 2;                 // wavefront columns
-  constexpr int TN = 4 / WN;                 // 32-column blocks per wavefront (2 or 1); TM = 2
+  constexpr int WN = 4 / TN;                 // wavefront columns
+  constexpr int NW = WM * WN;
+  constexpr int S_BM = 64 * WM;
+  constexpr int S_STAGE_BYTES = (S_BM + S_BN) * S_BK * 4;       // 32 / 48 KiB
+  constexpr int S_W_BYTE0 = S_BM * S_BK * 4;                    // W rows behind the A rows of a stage
+  constexpr int S_NSTAGE = 3;
+  constexpr int APIECES = S_BM / 8;          // 1-KiB pieces of A rows per stage (8 rows of 128 B each)
   constexpr int GM = 8 * TN;                 // MFMAs per k-group (8 k) of a K-tile
-  constexpr int NP = 32 / NW;                // 1-KiB DMA pieces per wavefront and K-tile
+  constexpr int NP = (APIECES + 16) / NW;    // 1-KiB DMA pieces per wavefront and K-tile
   constexpr int NF = 2 + TN;                 // fragment reads per k-group
+  static_assert((APIECES + 16) % NW == 0 && NP <= 8, "pieces divide over the wavefronts");
+  // the scratch inside the wavefront's own DMA slice of the free stage when it fits, else behind the stages
+  constexpr bool SCR_ALIAS = NP * 1024 >= S_SCR_BYTES;
   constexpr int SCR_OFF = S_NSTAGE * S_STAGE_BYTES;
-  constexpr int VEC_OFF = SCR_OFF + NW * S_SCR_BYTES;
+  constexpr int VEC_OFF = SCR_OFF + (SCR_ALIAS ? 0 : NW * S_SCR_BYTES);
+  constexpr int VEC_WAVE_BYTES = 2 * 3 * 64 * 4;               // [tile parity][bias | scale | shift][64 columns]
+  // VMEM operations that may stay in flight at a K-tile's barrier: the pieces of K-tile j + 2; in the FIRST K-tile of
+  // a tile also the three channel-vector pieces and the stores of the previous tile's epilogue, which were all
+  // issued behind the pieces this barrier needs (vmcnt retires in order): 4 row stores per 32x32 block (more with
+  // D2: then the wait is a little early, never late) and the column sums
+  constexpr int WAITN = NP;
+  constexpr int WAITN_FIRST = NP + 3 + 2 * TN * 4 + (COLSUM ? 2 * TN : 0);
+  // DEFER (16-MFMA k-groups only: enough free gaps): the last block of a tile has no MFMAs of its own tile left to
+  // hide behind, and the two wavefronts of a SIMD reach that point together -- ~1200 (plain) to ~3500 (column sums)
+  // idle cycles per tile.  Its accumulators go through the scratch into registers at once (the scratch is about to
+  // be overwritten by this wavefront's DMA pieces); maths, stores and the column-sum fold run behind the MFMAs of
+  // the NEXT tile's first K-tile.  Those stores are issued behind that K-tile's DMA pieces, so the K-tile after it
+  // lets them stay in flight too (WAITN_SECOND).
+  constexpr bool DEFER = GM == 16;
+  constexpr int WAITN_SECOND = DEFER ? NP + 4 + (COLSUM ? 2 * TN : 0) : NP;
+  static_assert(WAITN_FIRST < 64, "vmcnt is six bits");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
 
@@ -113,41 +159,50 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     n0 = (work - tm * tiles_n) * S_BN;
   };
 
-  // ---- per-channel epilogue vectors of ALL columns, once per workgroup: [bias | scale | shift][N]
-  {
-    float* vec = reinterpret_cast<float*>(ldsb + VEC_OFF);
-    for (int i = tid; i < p.N; i += 64 * NW) {
-      vec[i] = p.bias ? p.bias[i] : 0.f;
-      vec[p.N + i] = p.post_scale ? p.post_scale[i] : 1.f;
-      vec[2 * p.N + i] = p.post_scale ? p.post_shift[i] : 0.f;
-    }
-  }
-  __syncthreads();
-
-  // ---- operand stream (prefetch side).  Piece q of a stage = rows [8 (q & 15), +8) of A (q < 16) or W;
-  // lane l of the piece: row rr = l >> 3, physical 16-B chunk pc = l & 7 <- logical chunk pc ^ key(row).
-  const bool w_side = wave >= NW / 2;                    // this wavefront copies W rows (else A rows)
-  const char* gbase = w_side ? reinterpret_cast<const char*>(p.W) : reinterpret_cast<const char*>(p.A);
+  // ---- operand stream (prefetch side).  Piece q of a stage = rows [8 q, +8) of A (q < APIECES) or rows
+  // [8 (q - APIECES), +8) of W; wavefront w copies pieces [w NP, (w + 1) NP).
+  // lane l of a piece: row rr = l >> 3, physical 16-B chunk pc = l & 7 <- logical chunk pc ^ key(row).
   unsigned voff[NP];
-  const int g_ld = w_side ? p.ldw : p.lda, g_off = w_side ? 0 : p.a_off;
+  auto piece_is_w = [&](int i) { return wave * NP + i >= APIECES; };          // wave-uniform
   auto set_tile_offsets = [&](int seq) {
     int m0, n0;
     tile_of(seq, m0, n0);
-    const int row0 = w_side ? n0 : m0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int q = (wave * NP + i) & 15;
+      const bool isw = piece_is_w(i);
+      const int q = wave * NP + i - (isw ? APIECES : 0);
       const int row = q * 8 + r8;
       const int c = c8 ^ ((row >> 1) & 7);
-      voff[i] = (unsigned)(((row0 + row) * g_ld + g_off) * 4 + c * 16);
+      const int ld = isw ? p.ldw : p.lda, off = isw ? 0 : p.a_off, row0 = isw ? n0 : m0;
+      voff[i] = (unsigned)(((row0 + row) * ld + off) * 4 + c * 16);
     }
   };
   int pf_seq = 0, pf_kt = 0, pf_stage = 0;
   set_tile_offsets(0);
   auto dma_piece = [&](int i) {
     // wave-uniform 64-bit base (operand + K offset) + 32-bit lane offset: the saddr form of the instruction
+    const char* gbase = piece_is_w(i) ? reinterpret_cast<const char*>(p.W) : reinterpret_cast<const char*>(p.A);
     const char* kb = gbase + (size_t)(unsigned)(pf_kt * (S_BK * 4));
     s_dma_16B(kb + voff[i], ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024);
+  };
+  // the channel vectors of tile `seq`: three 256-B pieces (64 lanes x 4 B) of this wavefront's columns into its
+  // private slots; always three, so that every wavefront counts the same VMEM operations (a missing vector is read
+  // from the 16 zero bytes / replaced by constants in the epilogue)
+  char* const vec_w = ldsb + VEC_OFF + wave * VEC_WAVE_BYTES;
+  auto vec_pieces = [&](int seq) {
+    int m0, n0;
+    tile_of(seq, m0, n0);
+    int col = n0 + wn * 32 * TN + lane;
+    col = col < p.N ? col : p.N - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    char* dst = vec_w + (seq & 1) * (3 * 64 * 4);
+    const float* zero = p.zeros;
+    __builtin_amdgcn_global_load_lds(p.bias ? p.bias + col : zero, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(p.post_scale ? p.post_scale + col : zero,
+                                     (__attribute__((address_space(3))) void*)(dst + 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(p.post_scale ? p.post_shift + col : zero,
+                                     (__attribute__((address_space(3))) void*)(dst + 512), 4, 0, 0);
+#endif
   };
   auto pf_advance = [&]() {
     pf_stage = pf_stage == S_NSTAGE - 1 ? 0 : pf_stage + 1;
@@ -188,12 +243,14 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   };
 
   f32x16 acc[2][TN];
+  int cur_seq = 0;
   bool trace_now = false;                    // (WS_TRACE builds: fine stamps inside the K-tile that sets it)
   (void)trace_now;
 
   // ---- epilogue state
-  float* scr = reinterpret_cast<float*>(ldsb + SCR_OFF + wave * S_SCR_BYTES);
-  const float* vec = reinterpret_cast<const float*>(ldsb + VEC_OFF);
+  // (SCR_ALIAS: re-pointed by the last K-tile of every tile into the stage it has just left)
+  float* scr = reinterpret_cast<float*>(ldsb + (SCR_ALIAS ? wave * NP * 1024 : SCR_OFF + wave * S_SCR_BYTES));
+  const bool has_post = p.post_scale != nullptr;
   // raw buffer descriptors of D / D2: one store instruction per row = lane offset (VGPR) + row offset (SGPR),
   // no 64-bit address arithmetic on the vector ALU
   const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.D, 0, 0xffffffff, 0x00020000);
@@ -207,16 +264,19 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   struct TileOut {
     unsigned dvoff;        // byte offset of D[m0 + wm*64 + r8][d_off + n0 + wn*32*TN + 4 c8]
     unsigned d2voff;       // the same for D2 (columns n - d2_col0)
+    const float* vec;      // this wavefront's [bias | scale | shift][64] slots of the tile
     int ncol;              // n0 + wn*32*TN + 4 c8: first of this lane's 4 columns in block 0
     int nblk;              // n0 + wn*32*TN (wave-uniform)
     int rb;                // rows of the wavefront's 64-row half that belong to its first image
     int t64;               // (m0 + wm*64) / 64
   };
-  TileOut cur = {};
+  TileOut cur = {}, prev = {};
+  bool pending = false;                      // DEFER: `prev`'s last block is waiting in ev[]
   auto set_tile_out = [&](int seq, TileOut& t) {
     int m0, n0;
     tile_of(seq, m0, n0);
     const int mh = m0 + wm * 64;
+    t.vec = reinterpret_cast<const float*>(vec_w + (seq & 1) * (3 * 64 * 4));
     t.nblk = n0 + wn * 32 * TN;
     t.ncol = t.nblk + c8 * 4;
     t.dvoff = (unsigned)(((mh + r8) * p.ldd + p.d_off + t.ncol) * 4);
@@ -243,10 +303,10 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       for (int i = 2 * (step - 2); i < 2 * (step - 2) + 2; ++i)
         ev[i] = *reinterpret_cast<const f32x4*>(&scr[(r8 + 8 * i) * S_SCR_STRIDE + c8 * 4]);
     } else if (step == 4) {
-      const int n = t.ncol + in * 32;
-      vb = *reinterpret_cast<const f32x4*>(&vec[n]);
-      vs = *reinterpret_cast<const f32x4*>(&vec[p.N + n]);
-      vt = *reinterpret_cast<const f32x4*>(&vec[2 * p.N + n]);
+      const int n = in * 32 + c8 * 4;
+      vb = *reinterpret_cast<const f32x4*>(&t.vec[n]);
+      vs = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[64 + n]) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      vt = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[128 + n]) : (f32x4){0.f, 0.f, 0.f, 0.f};
     } else if (step >= 5 && step <= 8) {
       const int i = step - 5;
       f32x4 v = ev[i] + vb;
@@ -300,13 +360,13 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       for (int in = 0; in < TN; ++in) cs[in][0] = cs[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  // everything of a block's epilogue behind its scratch writes (the last block of a tile has no MFMAs left to
-  // hide behind: ~250 exposed cycles per tile.  Deferring it into the next tile's first K-tile was built and
-  // measured: no gain, the stores then delay that K-tile's counted vmcnt wait)
-  auto finish_block = [&](int im, int in, const TileOut& t) {
+  // the epilogue of a tile's LAST block behind its scratch round trip (ev[] holds its rows): d = 0 channel vectors,
+  // 1-4 row maths, 5-8 row stores, 9-10 column-sum accumulation, 11-13 column-sum butterfly, 14 column-sum store
+  constexpr int DEF_STEPS = 15;
+  auto deferred_step = [&](int d, const TileOut& t) {
     const f32x16 none = {};
-#pragma unroll
-    for (int st = 2; st < 15; ++st) epi_step(st, im, in, t, none);
+    if (d < 11) epi_step(d + 4, 1, TN - 1, t, none);
+    else colsum_step(d - 11, t);
   };
   // ---- prologue: two K-tiles in flight, the first one landed, its first fragments in registers
 #pragma unroll
@@ -315,7 +375,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
   for (int i = 0; i < NP; ++i) dma_piece(i);
   pf_advance();
-  s_wait_lds_vm_barrier<NP>();
+  s_wait_lds_vm_barrier<NP>();                // (the second K-tile stays in flight)
 #pragma unroll
   for (int i = 0; i < NF; ++i) frag_read(0, 0, i);
 
@@ -340,28 +400,58 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   };
 
   // One K-tile, MFMAs round-robin over the accumulator blocks.  FIRST: first K-tile of a tile (fresh accumulators).
-  auto ktile = [&](auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
+  auto ktile = [&](auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;        // 0 regular, 1 first K-tile of a tile, 2 the one after it
+    constexpr bool FIRST = KIND == 1;
+    // DEFER: deferred step d of the previous tile sits in the d-th gap of k-groups 0..2 that carries neither a DMA
+    // piece nor a fragment read -- all of them in front of this K-tile's barrier
+    auto deferred_at = [&](int g, int i) {
+      if (!(FIRST && DEFER)) return;
+      int d = 0;
+      bool hit = false;
+#pragma unroll
+      for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+        for (int ii = 0; ii < GM; ++ii) {
+          const bool busy = (gg == 0 && ii < NP) || (ii >= GM / 2 && ii < GM / 2 + NF);
+          if (!busy) {
+            if (gg == g && ii == i && d < DEF_STEPS) hit = true;
+            if (!hit) ++d;
+          }
+        }
+      if (hit && pending) deferred_step(d, prev);
+    };
     const int fs = FIRST ? 144 : 128;
     (void)fs;
     WS_FSTAMP(trace_now, fs + 0)
     mma_group(0, FIRST, [&](int i) {                       // g0: DMA pieces of K-tile +2, fragments of g1
+      if (FIRST && i == 0) vec_pieces(cur_seq);            // (first K-tile of a tile: its channel vectors)
       if (i < NP) dma_piece(i);
       if (i >= GM / 2 && i < GM / 2 + NF) frag_read(1, 1, i - GM / 2);
+      deferred_at(0, i);
     });
     WS_FSTAMP(trace_now, fs + 1)
     pf_advance();
     WS_FSTAMP(trace_now, fs + 2)
     mma_group(1, false, [&](int i) {                       // g1: fragments of g2
       if (i >= GM / 2 && i < GM / 2 + NF) frag_read(0, 2, i - GM / 2);
+      deferred_at(1, i);
     });
     WS_FSTAMP(trace_now, fs + 3)
     mma_group(0, false, [&](int i) {                       // g2: fragments of g3
       if (i >= GM / 2 && i < GM / 2 + NF) frag_read(1, 3, i - GM / 2);
+      deferred_at(2, i);
     });
     WS_FSTAMP(trace_now, fs + 4)
-    s_wait_lds_vm_barrier<NP>();
+    if (FIRST && cur_seq > 0) s_wait_lds_vm_barrier<WAITN_FIRST>();
+    else if (FIRST) s_wait_lds_vm_barrier<NP + 3>();       // (the very first tile: no epilogue stores in flight)
+    else if (KIND == 2 && cur_seq > 0) s_wait_lds_vm_barrier<WAITN_SECOND>();
+    else s_wait_lds_vm_barrier<WAITN>();
     WS_FSTAMP(trace_now, fs + 5)
+#ifdef WS_TRACE
+    if (trace_now && blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256))
+      g_stream_trace[(FIRST ? 178 : 177) + threadIdx.x] = g_stream_trace[176 + threadIdx.x];
+#endif
     advance_frag_addrs();
     mma_group(1, false, [&](int i) {                       // g3 (fragments in registers): g0 of the next K-tile
       if (i < NF) frag_read(0, 0, i);
@@ -415,31 +505,44 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       if (b == 0) {
         WS_FSTAMP(trace_now, 160 + 1)
         pf_advance();
-        s_wait_lds_vm_barrier<NP>();
+        s_wait_lds_vm_barrier<WAITN>();
+        // the stage this K-tile has just left is free until this wavefront's own pieces of K-tile +3 land in it
+        if (SCR_ALIAS) scr = reinterpret_cast<float*>(ldsb + cur_stage * S_STAGE_BYTES + wave * NP * 1024);
         advance_frag_addrs();
       }
     }
     WS_FSTAMP(trace_now, 160 + 8)
-    // the last block: nothing left to hide behind
+    // the last block: through the scratch into ev[] now; the rest behind the next tile's MFMAs (DEFER) or here
     epi_step(0, 1, TN - 1, cur, acc[1][TN - 1]);
     epi_step(1, 1, TN - 1, cur, acc[1][TN - 1]);
-    finish_block(1, TN - 1, cur);
+    epi_step(2, 1, TN - 1, cur, acc[1][TN - 1]);
+    epi_step(3, 1, TN - 1, cur, acc[1][TN - 1]);
+    if (DEFER) {
+      prev = cur;
+      pending = true;
+    } else {
 #pragma unroll
-    for (int st = 0; st < 4; ++st) colsum_step(st, cur);
+      for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, cur);
+    }
     WS_FSTAMP(trace_now, 160 + 9)
   };
 
   int stamp = 0;
   (void)stamp;
   for (int seq = 0; seq < my_nt; ++seq) {
+    cur_seq = seq;
     set_tile_out(seq, cur);
     WS_SSTAMP(stamp++)
     trace_now = seq == 1;
-    ktile(std::true_type{});
-    for (int kt = 1; kt + 1 < nk; ++kt) {
+    ktile(std::integral_constant<int, 1>{});
+    pending = false;
+    WS_SSTAMP(stamp++)
+    trace_now = false;
+    ktile(std::integral_constant<int, 2>{});
+    for (int kt = 2; kt + 1 < nk; ++kt) {
       WS_SSTAMP(stamp++)
       trace_now = seq == 1 && kt == 5;
-      ktile(std::false_type{});
+      ktile(std::integral_constant<int, 0>{});
     }
     WS_SSTAMP(stamp++)
     trace_now = seq == 1;
@@ -447,21 +550,24 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     trace_now = false;
   }
   WS_SSTAMP(stamp++)
+  if (DEFER && pending) {
+#pragma unroll
+    for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, prev);
+  }
   // drain the DMA pieces that ran past the end of the stream before the LDS goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NW>
-constexpr size_t stream_lds_bytes(int N) {
-  return (size_t)S_NSTAGE * S_STAGE_BYTES + (size_t)NW * S_SCR_BYTES + (size_t)3 * N * 4;
-}
-
-template <int NW, bool COLSUM>
+template <int WM, int TN, bool COLSUM>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
+  constexpr int NW = WM * (4 / TN), NP = (8 * WM + 16) / NW;
+  constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
+  constexpr size_t lds_bytes = (size_t)3 * (64 * WM + S_BN) * S_BK * 4 + (alias ? 0 : (size_t)NW * S_SCR_BYTES) +
+                               (size_t)NW * 2 * 3 * 64 * 4;
+  static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
-  auto kern = gemm_f32_stream_kernel<NW, COLSUM>;
-  const size_t lds_bytes = stream_lds_bytes<NW>(p.N);
-  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), stream_lds_bytes<NW>(1536), lds_granted);
+  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM>;
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
   return hipGetLastError();
@@ -469,7 +575,9 @@ hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) 
 
 }  // namespace
 
-int g_ws_stream = -1;          // env WS_STREAM: 0 off, 1 = 4 wavefronts, 2 = 8 wavefronts (default)
+// env WS_STREAM: 0 off; 1 = 128x128 tile, four wavefronts; 2 = 128x128 tile, eight wavefronts; 3 = 256x128 tile,
+// eight wavefronts; 4 (default) = 2 or 3, whichever the cost model below prefers for the problem
+int g_ws_stream = -1;
 
 #ifdef WS_TRACE
 unsigned long long* stream_trace_buffer_address() {
@@ -479,20 +587,65 @@ unsigned long long* stream_trace_buffer_address() {
 }
 #endif
 
-// Rows of [p.m_begin, p.M) that the persistent kernel should take (a multiple of 128 rows = whole rounds of
-// 128x128 tiles over `cus` workgroups); 0 = not this kernel's problem.
+namespace {
+// Cycles per K-tile of one tile (measured, steady state) and the per-tile overhead of the first / last K-tile.
+struct StreamPlan { int mode, bm, rows; long long cycles; };
+StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
+  const int bm = mode == 3 ? 256 : 128;
+  const long long per_kt = mode == 3 ? 8500 : 4400, per_tile = mode == 3 ? 5500 : 2500;
+  const long long tiles_n = p.N / S_BN, tiles_m = (p.M - p.m_begin) / bm, nk = p.K / S_BK;
+  const long long total = tiles_m * tiles_n, rounds = total / cus;
+  StreamPlan pl = {mode, bm, 0, 0};
+  if (rounds < 2) return pl;
+  const long long tile_time = nk * per_kt + per_tile;
+  long long main_tiles_m = rounds * cus / tiles_n;
+  // The tiles beyond the whole rounds: one more (partial) round here costs a whole tile time; as 64x64 tiles on the
+  // tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the kernel boundary they cost
+  // ceil(rem64 / 512) rounds -- take the cheaper.  Rows beyond the last whole tile row always go there.
+  const long long rem = total - main_tiles_m * tiles_n;
+  const long long rest_rows = (p.M - p.m_begin) - tiles_m * bm;
+  auto tile_kernel = [&](long long rows) {
+    if (rows <= 0) return 0LL;
+    const long long t64 = (rows + 63) / 64 * ((p.N + 63) / 64);
+    return (t64 + 2 * cus - 1) / (2 * cus) * nk * 2600 + 12000;
+  };
+  long long cyc = (main_tiles_m * tiles_n / cus) * tile_time;
+  const long long here = tile_time + tile_kernel(rest_rows);
+  const long long there = tile_kernel((tiles_m - main_tiles_m) * bm + rest_rows);
+  if (rem > 0 && here <= there) {
+    main_tiles_m = tiles_m;
+    cyc += here;
+  } else {
+    cyc += there;
+  }
+  pl.rows = (int)(main_tiles_m * bm);
+  pl.cycles = cyc;
+  return pl;
+}
+StreamPlan plan(const ConvGemmParams& p, int cus) {
+  const int m = g_ws_stream;
+  if (m >= 1 && m <= 3) return plan_mode(p, cus, m);
+  const StreamPlan a = plan_mode(p, cus, 2), b = plan_mode(p, cus, 3);
+  if (!b.rows) return a;
+  if (!a.rows) return b;
+  return b.cycles <= a.cycles ? b : a;
+}
+}  // namespace
+
+// Rows of [p.m_begin, p.M) that the persistent kernel should take (whole tile rows: whole rounds of tiles over
+// `cus` workgroups, or all of them); 0 = not this kernel's problem.
 int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   if (g_ws_stream < 0) {
     const char* ev = getenv("WS_STREAM");
-    g_ws_stream = ev ? atoi(ev) : 2;
+    g_ws_stream = ev ? atoi(ev) : 4;
   }
-  if (!(g_ws_stream & 3)) return 0;
+  if (g_ws_stream <= 0) return 0;
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
                      !p.bias_img && !p.residual && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
                      p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
   if (!plain) return 0;
-  if (p.N % S_BN != 0 || p.N > 1536 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
+  if (p.N % S_BN != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
   if (p.colsum && p.Hout * p.Wout < 64) return 0;
   if ((p.m_begin & 63) || ((p.lda | p.a_off | p.ldd | p.d_off) & 3)) return 0;
   if (p.D2 && (((p.ldd2 | p.d2_off) & 3) || (p.d2_col0 & 31))) return 0;
@@ -500,35 +653,25 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   if ((long long)p.M * p.lda * 4 >= (1LL << 32) || (long long)p.M * p.ldd * 4 >= (1LL << 32) ||
       (long long)p.N * p.ldw * 4 >= (1LL << 32) || (p.D2 && (long long)p.M * p.ldd2 * 4 >= (1LL << 32)))
     return 0;
-  const long long tiles_n = p.N / S_BN, tiles_m = (p.M - p.m_begin) / S_BM;
-  const long long rounds = tiles_m * tiles_n / cus;
-  if (rounds < 2) return 0;
-  long long main_tiles_m = rounds * cus / tiles_n;
-  // The tiles beyond the whole rounds: one more (partial) round here costs a whole tile time, K/32 x ~4400 cycles;
-  // as 64x64 tiles on the tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the
-  // kernel boundary they cost ceil(4 rem / 512) rounds -- take the cheaper (K = 512: 48 tiles -> the tile kernel;
-  // K = N = 1536: 144 tiles -> here)
-  const long long rem = tiles_m * tiles_n - main_tiles_m * tiles_n, nk = p.K / S_BK;
-  if (rem > 0) {
-    const long long here = nk * 4400, there = (4 * rem + 2 * cus - 1) / (2 * cus) * nk * 2600 + 12000;
-    if (here <= there) main_tiles_m = tiles_m;
-  }
-  return (int)(main_tiles_m * S_BM);
+  return plan(p, cus).rows;
 }
 
 hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, hipStream_t stream) {
   ConvGemmParams p = p0;
+  const StreamPlan pl = plan(p0, cus);
+  if (pl.rows != rows) return hipErrorInvalidValue;      // (rows must come from gemm_f32_stream_rows)
   p.tail_begin = p.m_begin + rows;
-  p.n_big = rows / S_BM * (p.N / S_BN);
+  const int mode = pl.mode, bm = pl.bm;
+  p.n_big = rows / bm * (p.N / S_BN);
   const int grid = p.n_big < cus ? p.n_big : cus;
-  const bool w8 = (g_ws_stream & 3) != 1;
   if (dispatch_log_enabled()) {
     char k[96];
-    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%d waves> tiles=%d", w8 ? 8 : 4, p.n_big);
+    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx128 tile, %d waves> tiles=%d", bm, mode == 1 ? 4 : 8, p.n_big);
     dispatch_log_note(p, k);
   }
-  if (w8) return p.colsum ? launch_stream<8, true>(p, grid, stream) : launch_stream<8, false>(p, grid, stream);
-  return p.colsum ? launch_stream<4, true>(p, grid, stream) : launch_stream<4, false>(p, grid, stream);
+  if (mode == 1) return p.colsum ? launch_stream<2, 2, true>(p, grid, stream) : launch_stream<2, 2, false>(p, grid, stream);
+  if (mode == 2) return p.colsum ? launch_stream<2, 1, true>(p, grid, stream) : launch_stream<2, 1, false>(p, grid, stream);
+  return p.colsum ? launch_stream<4, 2, true>(p, grid, stream) : launch_stream<4, 2, false>(p, grid, stream);
 }
 
 }  // namespace wsamd
