@@ -87,10 +87,10 @@ DTYPE_TEXT = {
 def kernel_text(model_name, prec):
     ecapa = model_name.startswith("ECAPA")
     if prec == "fp32":
-        return ("gemm_f32_stream_kernel (persistent: one workgroup per CU walks whole rounds of 128x128 tiles, "
-                "operands by LDS-DMA into a 3-stage ring, v_mfma_f32_32x32x2_f32, exact fp32 products: the plain "
-                "1x1 layers) + conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> (everything else and the "
-                "remaining rows): every conv/linear with N > 64")
+        return ("gemm_f32_stream_kernel (persistent: one workgroup of eight 64x64 wavefronts per CU walks whole rounds "
+                "of 256x128 tiles, operands by LDS-DMA into a 3-stage ring of 48-KB K-tiles, v_mfma_f32_32x32x2_f32, "
+                "exact fp32 products: the plain 1x1 layers) + conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> "
+                "(everything else and the remaining rows): every conv/linear with N > 64")
     if prec == "f16x3":
         return ("conv_gemm_dual_kernel<..,PREC=1> / conv_gemm_kernel<128,128,2,2,..,PREC=1> (3 x "
                 "v_mfma_f32_32x32x16_f16 on hi/lo binary16 splits): every conv/linear with N > 64")
@@ -607,6 +607,33 @@ def main(argv=None):
         configs["fixed_size_sets_n1_fp32"] = sets
         del keep
 
+    # ---- the same workload at larger per-GPU batches (fp32 headline back-end): what the fixed per-launch costs (~45
+    # launches, the latency-bound SE / pooling kernels, the partial last rounds of tiles) take at batch 256
+    batch_sweep = None
+    if rank == 0 and world == 1 and not args.headline_only and not STUB and not args.batch:
+        batch_sweep = {}
+        for b in (512, 1024):
+            bm = make_model(name, E, b, T)
+            bm.set_precision(args.precision)
+            bw = device_wavs(b, num_samples, device, seed_base=500 + b)
+            for _ in range(2):
+                bm.extract(fe, bw)
+            sync()
+            bm.profile(1)
+            ks = 5
+            tb = time.perf_counter()
+            for _ in range(ks):
+                bm.extract(fe, bw)
+            sync()
+            bdt = time.perf_counter() - tb
+            pr = bm.profile_read()[DOMINANT]
+            bm.profile(False)
+            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS
+            batch_sweep[str(b)] = {"value": b * ks / bdt, "unit": "embeddings/s", "ms_per_step": bdt / ks * 1e3,
+                                   "steps": ks, "engine_chunk": b,
+                                   "dominant_frac": (pr["flops"] / (pr["ms"] * 1e-3) / 1e12 / peak) if pr["ms"] else None}
+            del bm, bw
+
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
     if rank == 0 and not args.headline_only and not STUB:
@@ -714,6 +741,8 @@ def main(argv=None):
         }
         if configs:
             line["configs"] = configs
+        if batch_sweep:
+            line["throughput_vs_per_gpu_batch"] = batch_sweep
         if STUB:
             line["embedding_checksum"] = float(all_emb.double().abs().sum().item())
         if world == 1 and not args.no_cpu_baseline and not args.headline_only and not STUB:
