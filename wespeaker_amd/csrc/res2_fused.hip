@@ -23,6 +23,20 @@ namespace wsamd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef WS_TRACE
+__device__ unsigned long long g_res2_trace[128];          // [wavefront 0 | wavefront 4] x 64 stamps
+unsigned long long* res2_trace_buffer_address() {
+  unsigned long long* q = nullptr;
+  (void)hipGetSymbolAddress(reinterpret_cast<void**>(&q), HIP_SYMBOL(g_res2_trace));
+  return q;
+}
+#define WS_RSTAMP(i)                                                                              \
+  if (blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256))                                \
+    g_res2_trace[(i) + (threadIdx.x >> 2)] = __builtin_readcyclecounter();
+#else
+#define WS_RSTAMP(i)
+#endif
+
 template <int W, int MTW>
 __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p) {
   constexpr int NT = W / 16;            // output column tiles
@@ -48,6 +62,7 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
   if (own_lo >= T) return;                              // (ragged batch: a tile beyond this utterance's end)
   const int tbase = p.tiles > 1 ? own_lo - 7 * d : 0;
 
+  WS_RSTAMP(0)
   // zero the whole X once: padding rows and rows outside [0, T) stay zero for all steps
   for (int i = tid * 4; i < rows_total * XS; i += 512 * 4)
     *reinterpret_cast<f32x4*>(&X[i]) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -81,7 +96,9 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
     for (int g = 0; g < KG; ++g) bw[g] = *reinterpret_cast<const f32x4*>(wrow + g * 16);
   };
   load_weights(0);
+  WS_RSTAMP(1)
   for (int step = 0; step < 7; ++step) {
+    WS_RSTAMP(2 + step * 5)
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[step] + c0);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale[step] + c0);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift[step] + c0);
@@ -116,31 +133,36 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
       const int tap = g / (W / 16), cg = g % (W / 16);
       return xbase + (mt * 16 + tap * d) * XS + cg * 16;
     };
+    // (the fragments of k-group g + 1 are requested BEFORE the MFMAs of k-group g, into the other of two register
+    // sets: with one set and `a = next` behind the MFMAs hipcc reused the registers and issued each read behind the
+    // group's last MFMA -- an exposed LDS round trip every 8 MFMAs, ~0.65 of the MFMA rate for the whole chain)
 #pragma unroll
     for (int mp = 0; mp < MTW; mp += 2) {
       const bool two = mp + 1 < MTW;
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(xaddr(mp, 0));
-      f32x4 a1 = two ? *reinterpret_cast<const f32x4*>(xaddr(mp + 1, 0)) : a0;
+      f32x4 fa[2][2];
+      fa[0][0] = *reinterpret_cast<const f32x4*>(xaddr(mp, 0));
+      fa[0][1] = two ? *reinterpret_cast<const f32x4*>(xaddr(mp + 1, 0)) : fa[0][0];
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
-        f32x4 n0 = a0, n1 = a1;
         if (g + 1 < KG) {
-          n0 = *reinterpret_cast<const f32x4*>(xaddr(mp, g + 1));
-          if (two) n1 = *reinterpret_cast<const f32x4*>(xaddr(mp + 1, g + 1));
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], a0[s], acc[mp], 0, 0, 0);
-          if (two)
-            acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], a1[s], acc[mp + 1], 0, 0, 0);
+          fa[(g + 1) & 1][0] = *reinterpret_cast<const f32x4*>(xaddr(mp, g + 1));
+          if (two) fa[(g + 1) & 1][1] = *reinterpret_cast<const f32x4*>(xaddr(mp + 1, g + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
-        a0 = n0; a1 = n1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[mp] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], fa[g & 1][0][s], acc[mp], 0, 0, 0);
+          if (two)
+            acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][s], fa[g & 1][1][s], acc[mp + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    WS_RSTAMP(3 + step * 5)
     // the weight registers are free now: fetch the next step's weights under the epilogue
     if (step < 6) load_weights(step + 1);
     __syncthreads();                                    // everyone finished reading X
+    WS_RSTAMP(4 + step * 5)
     // C/D layout 16x16: col = lane & 15 (time step), row = (lane >> 4) * 4 + reg (channel)
     const float* y1e = p.y1 + (m_base + tbase + tb) * ld1 + (step + 1) * W + c0;
     float* y2u = p.y2 + (m_base + tbase + tb) * ld2 + step * W + c0;
@@ -158,8 +180,11 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
               v + (PF ? y1n[PF ? mt : 0] : *reinterpret_cast<const f32x4*>(y1e + (long long)(mt * 16) * ld1));
       }
     }
+    WS_RSTAMP(5 + step * 5)
     __syncthreads();
+    WS_RSTAMP(6 + step * 5)
   }
+  WS_RSTAMP(40)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,6 +438,10 @@ template <int W, int MTW>
 static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
   chain_tiling_for(chain_cap(W, MTW), p.T, p.dil, &p.tiles, &p.tile_rows);
   const size_t lds = (size_t)(chain_cap(W, MTW) + 2 * p.dil) * (W + 8) * sizeof(float);
+  // (Round 3, measured and dropped: two copies of the running activation -- step s reads X[s & 1] and writes the
+  // other, one barrier per step, every pair of row tiles finished right behind its own MFMAs, next weights
+  // requested a step ahead.  Bit-identical, and not a microsecond faster: PMC says the matrix pipe is busy 0.59 of
+  // this kernel's cycles either way.)
   auto kern = res2_chain_kernel<W, MTW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   {
