@@ -229,6 +229,82 @@ def plda_cpu_baseline(params, enroll_t, test_t, idx_e, idx_t, budget_s=4.0):
                                  "%.1f ms per block" % (ne, nt, mat_dt * 1e3)}
 
 
+def plda_leg(args, device, with_cpu_baseline):
+    """1 M synthetic trial pairs over 2 x 10 k embeddings (incl. the transform) + a dense 1000 x 1000 matrix, float64;
+    roofline of the pair kernel (cache-gather bound) and of the dense GEMM, CPU baseline = the reference's own
+    per-trial loop (oracle/plda.py) on a bounded sample + vectorised numpy."""
+    from wespeaker_amd import TwoCovPLDA
+    D = 192
+    p = synth.synth_plda(D, seed=7)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
+    n_emb = 10000
+    emb_tab, _ = synth.synth_embeddings(2 * n_emb, D, seed=11)
+    emb_tab = torch.from_numpy(emb_tab).to(device)
+    ie, it = synth.synth_trial_pairs(args.trials, n_emb, n_emb, seed=99)
+    ie_d, it_d = torch.from_numpy(ie).to(device), torch.from_numpy(it).to(device)
+    nn = 1          # multisession_avg=True: every enrollment model counts as one session
+
+    def timed(fn, k):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        ev0.record()
+        for _ in range(k):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t1) / k, ev0.elapsed_time(ev1) * 1e-3 / k
+
+    k = max(3, min(args.steps, 20))
+    e_t = plda.prepare_test(emb_tab[:n_emb])
+    t_t = plda.prepare_test(emb_tab[n_emb:])
+
+    def plda_step():
+        a = plda.prepare_test(emb_tab[:n_emb])
+        b = plda.prepare_test(emb_tab[n_emb:])
+        return plda.llr_pairs(a, nn, b, ie_d, it_d)
+
+    pdt, _ = timed(plda_step, k)
+    _, pair_dev = timed(lambda: plda.llr_pairs(e_t, nn, t_t, ie_d, it_d), k)
+    e1k = plda.prepare_test(emb_tab[:1000])
+    t1k = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
+    mdt, mat_dev = timed(lambda: plda.llr_matrix(e1k, nn, t1k), k)
+    # SURVEY 8(d): a trial gathers one enrollment and one test row (uniform n: D doubles each), reads its two
+    # int32 indices and writes one double -- the tables (2 x 10 k x 192 x 8 B = 30.7 MB) live in L2 / Infinity
+    # Cache, so this is a cache-gather, priced against the HBM peak as the contract's unit
+    bpt = 2 * D * 8 + 8 + 8
+    pair_gbs = args.trials * bpt / pair_dev / 1e9
+    mat_tf = 2.0 * 1000 * 1000 * D / mat_dev / 1e12
+    plda_info = {
+        "pairs_trials_per_s": args.trials / pdt, "pairs_ms": pdt * 1e3,
+        "pairs_workload": "%d index pairs over 2x%d embeddings D=%d incl. transform" % (args.trials, n_emb, D),
+        "pairs_kernel_only_trials_per_s": args.trials / pair_dev, "pairs_kernel_only_ms": pair_dev * 1e3,
+        "roofline": {"kernel": "plda_llr_pairs (16 lanes per trial, double2 gathers of the [g*e] and [t] rows, "
+                               "16-lane shuffle reduce)",
+                     "bound": "hbm", "achieved": pair_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": pair_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_trial": bpt,
+                     "note": "gather rows come from L2 / Infinity Cache (30.7 MB of tables), not HBM: the fraction "
+                             "is algorithmic gather bytes over the HBM peak; HBM itself only sees the 8 MB index "
+                             "list and the 8 MB score vector per launch"},
+        "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
+        "matrix_workload": "dense 1000x1000 LLR matrix D=%d" % D,
+        "matrix_roofline": {"kernel": "plda_gemm_f64 (v_mfma_f64_16x16x4_f64, 64x64 tiles)", "bound": "mfma",
+                            "achieved": mat_tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": mat_tf / F64_MFMA_PEAK_TFLOPS,
+                            "note": "0.38 GFLOP + 8 MB of output in one %.0f-us launch: latency-bound at this "
+                                    "size, not MFMA-bound" % (mat_dev * 1e6)},
+        "dtype": "f64"}
+    if with_cpu_baseline:
+        plda_info["cpu_baseline"] = plda_cpu_baseline(
+            {"mu": p["mu"], "transform": p["transform"], "psi": p["psi"], "offset": p["offset"],
+             "normalize_length": False},
+            e_t.cpu().numpy(), t_t.cpu().numpy(), ie, it)
+        return plda_info
+
+
 # ------------------------------------------------------------------------------------------ main
 def parse_args(argv):
     ap = argparse.ArgumentParser()
@@ -253,6 +329,8 @@ def parse_args(argv):
                     help="timed windows of --steps steps per back-end (the first one of the headline back-end "
                          "is the contract's timed region = `value`; all of them give median / spread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plda-only", action="store_true",
+                    help="only the PLDA leg (for rocprofv3: the kernel table then holds the plda_* kernels alone)")
     ap.add_argument("--no-configs", action="store_true", help="skip the compact legs of the other BASELINE configs")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the --precision back-end: no other back-ends, no config legs, no PLDA, no CPU "
@@ -279,6 +357,12 @@ def main(argv=None):
     else:
         device = torch.device("cuda", 0 if os.environ.get("WS_SHARE_GPU") else local_rank)
         torch.cuda.set_device(device)
+
+    if args.plda_only:
+        info = plda_leg(args, device, not args.no_cpu_baseline)
+        print(json.dumps({"metric": METRIC, "unit": "trials/s", "value": info["pairs_trials_per_s"], "n_gpus": 1,
+                          "plda": info}), flush=True)
+        return
 
     set_mode = args.workload != "default" or args.total_utts > 0
     w_model, w_utts, w_trials = WORKLOADS.get(args.workload, (None, 0, 0))
@@ -637,75 +721,7 @@ def main(argv=None):
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
     if rank == 0 and not args.headline_only and not STUB:
-        from wespeaker_amd import TwoCovPLDA
-        D = 192
-        p = synth.synth_plda(D, seed=7)
-        plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False, device=device)
-        n_emb = 10000
-        emb_tab, _ = synth.synth_embeddings(2 * n_emb, D, seed=11)
-        emb_tab = torch.from_numpy(emb_tab).to(device)
-        ie, it = synth.synth_trial_pairs(args.trials, n_emb, n_emb, seed=99)
-        ie_d, it_d = torch.from_numpy(ie).to(device), torch.from_numpy(it).to(device)
-        nn = 1          # multisession_avg=True: every enrollment model counts as one session
-
-        def timed(fn, k):
-            for _ in range(2):
-                fn()
-            sync()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t1 = time.perf_counter()
-            ev0.record()
-            for _ in range(k):
-                fn()
-            ev1.record()
-            sync()
-            return (time.perf_counter() - t1) / k, ev0.elapsed_time(ev1) * 1e-3 / k
-
-        k = max(3, min(args.steps, 20))
-        e_t = plda.prepare_test(emb_tab[:n_emb])
-        t_t = plda.prepare_test(emb_tab[n_emb:])
-
-        def plda_step():
-            a = plda.prepare_test(emb_tab[:n_emb])
-            b = plda.prepare_test(emb_tab[n_emb:])
-            return plda.llr_pairs(a, nn, b, ie_d, it_d)
-
-        pdt, _ = timed(plda_step, k)
-        _, pair_dev = timed(lambda: plda.llr_pairs(e_t, nn, t_t, ie_d, it_d), k)
-        e1k = plda.prepare_test(emb_tab[:1000])
-        t1k = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
-        mdt, mat_dev = timed(lambda: plda.llr_matrix(e1k, nn, t1k), k)
-        # a trial gathers one enrollment and one test row (uniform n: D doubles each), reads its two
-        # int32 indices and writes one double -- the tables (2 x 10 k x 192 x 8 B = 30.7 MB) live in L2 / Infinity
-        # Cache, so this is a cache-gather, priced against the HBM peak as the contract's unit
-        bpt = 2 * D * 8 + 8 + 8
-        pair_gbs = args.trials * bpt / pair_dev / 1e9
-        mat_tf = 2.0 * 1000 * 1000 * D / mat_dev / 1e12
-        plda_info = {
-            "pairs_trials_per_s": args.trials / pdt, "pairs_ms": pdt * 1e3,
-            "pairs_workload": "%d index pairs over 2x%d embeddings D=%d incl. transform" % (args.trials, n_emb, D),
-            "pairs_kernel_only_trials_per_s": args.trials / pair_dev, "pairs_kernel_only_ms": pair_dev * 1e3,
-            "roofline": {"kernel": "plda_llr_pairs (16 lanes per trial, double2 gathers of the [g*e] and [t] rows, "
-                                   "16-lane shuffle reduce)",
-                         "bound": "hbm", "achieved": pair_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pair_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_trial": bpt,
-                         "note": "gather rows come from L2 / Infinity Cache (30.7 MB of tables), not HBM: the fraction "
-                                 "is algorithmic gather bytes over the HBM peak; HBM itself only sees the 8 MB index "
-                                 "list and the 8 MB score vector per launch"},
-            "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
-            "matrix_workload": "dense 1000x1000 LLR matrix D=%d" % D,
-            "matrix_roofline": {"kernel": "plda_gemm_f64 (v_mfma_f64_16x16x4_f64, 64x64 tiles)", "bound": "mfma",
-                                "achieved": mat_tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": mat_tf / F64_MFMA_PEAK_TFLOPS,
-                                "note": "0.38 GFLOP + 8 MB of output in one %.0f-us launch: latency-bound at this "
-                                        "size, not MFMA-bound" % (mat_dev * 1e6)},
-            "dtype": "f64"}
-        if world == 1 and not args.no_cpu_baseline:
-            plda_info["cpu_baseline"] = plda_cpu_baseline(
-                {"mu": p["mu"], "transform": p["transform"], "psi": p["psi"], "offset": p["offset"],
-                 "normalize_length": False},
-                e_t.cpu().numpy(), t_t.cpu().numpy(), ie, it)
+        plda_info = plda_leg(args, device, world == 1 and not args.no_cpu_baseline)
 
     if rank == 0:
         head = blocks[args.precision]

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-end verification + measurement bundle for ONE gpurun call (run from the repo root on the GPU box):
-#   gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r03'
 # Everything lands in gpurun_out/<tag>_*; tools/collect_profiles.sh <tag> copies the judged artefacts to profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
@@ -14,20 +14,28 @@ fi
 # the driver's line (default: ECAPA-512, fp32 headline + both fast modes + config 1 + PLDA + cpu baseline)
 python bench.py > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/${TAG}_bench_n1.err"; cut -c1-200 "$OUT/${TAG}_bench_n1.json"
 # the other families of BASELINE.json (configs 2-3) through the same bench.py
+rm -f "$OUT/${TAG}_bench_models.jsonl" "$OUT/${TAG}_bench_sets.jsonl"
 for m in ECAPA_TDNN_GLOB_c1024 ResNet34 ResNet221 CAMPPlus; do
-  python bench.py --model $m --steps 10 --windows 3 --cpu-utts 300 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_models.jsonl"
+  python bench.py --model $m --steps 10 --windows 3 --cpu-utts 300 --no-configs 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_models.jsonl"
 done
+# BASELINE configs 2 / 3 as fixed-size sets (strong scaling; at N = 1 here, `--gpus N` on a multi-GPU node)
+python bench.py --workload vox1o --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
+python bench.py --workload vox1o --model ResNet221 --steps 2 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
+python bench.py --workload stream10k --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
 cd /tmp && export TMPDIR=/tmp
 # kernel tables: one headline-only run per back-end / family, so every table describes ONE workload
 prof() {  # name, bench args...
   local name=$1; shift
   rm -rf "$OUT/prof_$name"
-  rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o p -- python "$REPO/bench.py" --headline-only --steps 20 --windows 1 "$@" > "$OUT/prof_$name.log" 2>&1
+  local base="--headline-only --steps 20 --windows 1"
+  [ "$name" = plda ] && base=""
+  rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o p -- python "$REPO/bench.py" $base "$@" > "$OUT/prof_$name.log" 2>&1
   python "$REPO/tools/rocprof_summary.py" "$(ls $OUT/prof_$name/*.db 2>/dev/null | head -1)" > "$OUT/${TAG}_kernel_stats_$name.md" 2>/dev/null
   head -4 "$OUT/${TAG}_kernel_stats_$name.md" | cut -c1-150
   rm -rf "$OUT/prof_$name"            # the .db files are tens of MB: gpurun_out/ only travels back under 64 MiB
 }
 prof fp32 --precision fp32
+prof plda --plda-only --no-cpu-baseline
 prof f16 --precision f16
 prof f16x3 --precision f16x3
 prof ResNet34_f16 --model ResNet34 --precision f16 --steps 5
@@ -48,11 +56,11 @@ pmc() {  # prec, needle, [model]
   grep -E "traffic_bytes_per_launch|mfma_busy|\"traffic_bytes\"" "$OUT/${TAG}_pmc_dominant_kernel_$prec$tag.json"
   rm -rf "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3"
 }
-pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
+pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
 pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64, 64"
 # the 2-D families: whole-forward HBM bytes tell whether their MFMA fraction is the binding limit at all
 pmc f16 "gemm_f16_dma_kernel|gemm_f16_p8_kernel|conv3x3_direct_f16_kernel" ResNet221
-pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel" ResNet34
-pmc fp32 "conv_gemm_dual_kernel|conv_gemm_kernel" CAMPPlus
+pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel" ResNet34
+pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel" CAMPPlus
 cd "$REPO"
 ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '

@@ -120,6 +120,13 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
     st[b] = first; ln[b] = last - first + 1; off[b] = (int)wts.size();
     for (int i = first; i <= last; ++i) wts.push_back(row[i]);
   }
+  // fbank_kernel's mel phase holds at most 12 x 4 taps of a filter in registers (80 bins at 16 kHz: <= 37)
+  for (int b = 0; b < num_mel_bins; ++b)
+    if (ln[b] > 48) {
+      delete fe;
+      set_error("ws_frontend_create: mel filter %d spans %d FFT bins (> 48): too few mel bins for this kernel", b, ln[b]);
+      return WS_ERR_INVALID_ARG;
+    }
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.alloc(bytes);
     if (e != hipSuccess) return e;

@@ -40,124 +40,154 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 
 // twiddle[m] = exp(-2 pi i m / 512), m = 0..511
-__global__ __launch_bounds__(64 * FRAMES_PER_BLOCK) void fbank_kernel(
+// Persistent workgroups (round 3): the mel tables and the twiddle factors are staged into LDS ONCE per workgroup and
+// every wavefront then walks frames wave, wave + W, ... (before, each workgroup lived for four frames and paid the
+// ~5.5-KB table staging + a barrier in front of them; the FFT stages read their twiddles through dependent global
+// loads).  The mel phase requests all taps of a pass before the first multiply (trip count = the longest filter of
+// the pass, uniform across the wavefront) instead of one exposed LDS round trip per tap: ~10 -> 1 per pass.
+// Same arithmetic in the same order: the outputs are bit-identical to the previous kernel.
+__global__ __launch_bounds__(64 * FRAMES_PER_BLOCK, 6) void fbank_kernel(      // six workgroups per CU: <= 80 VGPRs
     const FbankTables tb, const void* __restrict__ wav, int wav_dtype, int N, long long wav_stride,
     float scale, const float* __restrict__ window, int T, long long total_frames,
     float* __restrict__ feats, const int* __restrict__ frames) {
   __shared__ __attribute__((aligned(16))) float2 bufA[FRAMES_PER_BLOCK][CN];
   __shared__ __attribute__((aligned(16))) float2 bufB[FRAMES_PER_BLOCK][CN + 4];
-  // mel filter table staged once per workgroup (4 frames share it): the per-tap weight reads of
-  // the filterbank loop then come from LDS instead of dependent global loads
   __shared__ float mel_w_s[MEL_W_MAX];
-  __shared__ int mel_start_s[128], mel_len_s[128], mel_off_s[128];
+  __shared__ int mel_start_s[128], mel_len_s[128], mel_off_s[128], pass_max_s[8];
+  __shared__ __attribute__((aligned(16))) float2 tw_s[FFT_N];
   for (int i = threadIdx.x; i < tb.mel_w_total; i += 64 * FRAMES_PER_BLOCK) mel_w_s[i] = tb.mel_w[i];
-  for (int i = threadIdx.x; i < tb.num_bins; i += 64 * FRAMES_PER_BLOCK) {
-    mel_start_s[i] = tb.mel_start[i]; mel_len_s[i] = tb.mel_len[i]; mel_off_s[i] = tb.mel_off[i];
+  for (int i = threadIdx.x; i < 128; i += 64 * FRAMES_PER_BLOCK) {
+    const bool has = i < tb.num_bins;
+    mel_start_s[i] = has ? tb.mel_start[i] : 0; mel_len_s[i] = has ? tb.mel_len[i] : 0; mel_off_s[i] = has ? tb.mel_off[i] : 0;
+  }
+  for (int i = threadIdx.x; i < FFT_N; i += 64 * FRAMES_PER_BLOCK) {
+    tw_s[i] = reinterpret_cast<const float2*>(tb.twiddle)[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {                        // longest filter of each 16-bin pass
+    int mx = 0;
+    for (int q = 0; q < 16; ++q) { const int l = mel_len_s[threadIdx.x * 16 + q]; mx = l > mx ? l : mx; }
+    pass_max_s[threadIdx.x] = mx;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long frame = (long long)blockIdx.x * FRAMES_PER_BLOCK + wave;
-  const bool live = frame < total_frames;
-  if (!live) frame = total_frames - 1;          // keep control flow uniform for the barriers
-  const int b = (int)(frame / T), f = (int)(frame - (long long)b * T);
-  // ragged batch: utterance b has frames[b] <= T frames; the rows beyond are written as zeros (they are
-  // the zero padding the first convolution sees).  Only wave-level synchronisation follows, so the whole
-  // wavefront may leave here.
-  if (frames && f >= frames[b]) {
-    if (live)
-      for (int i = lane; i < tb.num_bins; i += 64) feats[frame * tb.num_bins + i] = 0.f;
-    return;
-  }
-  const long long s0 = (long long)b * wav_stride + (long long)f * tb.frame_shift;
   const int L = tb.frame_len;                   // 400
-
   float* xs = reinterpret_cast<float*>(bufB[wave]);   // raw samples (<= 512 floats)
   float* zr = reinterpret_cast<float*>(bufA[wave]);   // windowed, zero padded = complex input
+  const float2* tw = tw_s;
 
-  // 1. load + DC offset
-  float part = 0.f;
-  for (int j = lane; j < L; j += 64) {
-    float v;
-    if (wav_dtype == 0) v = (float)reinterpret_cast<const short*>(wav)[s0 + j];
-    else v = reinterpret_cast<const float*>(wav)[s0 + j];
-    v *= scale;
-    xs[j] = v;
-    part += v;
-  }
-  const float mean = wave_sum_f(part) / (float)L;
-  wave_sync();
-  // 2. pre-emphasis (replicate-pad first sample) + window, zero pad to 512
-  for (int j = lane; j < FFT_N; j += 64) {
-    float y = 0.f;
-    if (j < L) {
-      const float cur = xs[j] - mean;
-      const float prev = xs[j > 0 ? j - 1 : 0] - mean;
-      y = (cur - 0.97f * prev) * window[j];
+  for (long long frame = (long long)blockIdx.x * FRAMES_PER_BLOCK + wave; frame < total_frames;
+       frame += (long long)gridDim.x * FRAMES_PER_BLOCK) {
+    const int b = (int)(frame / T), f = (int)(frame - (long long)b * T);
+    // ragged batch: utterance b has frames[b] <= T frames; the rows beyond are written as zeros (they are
+    // the zero padding the first convolution sees).  Only wave-level synchronisation is used in this loop.
+    if (frames && f >= frames[b]) {
+      for (int i = lane; i < tb.num_bins; i += 64) feats[frame * tb.num_bins + i] = 0.f;
+      continue;
     }
-    zr[j] = y;
-  }
-  wave_sync();
+    const long long s0 = (long long)b * wav_stride + (long long)f * tb.frame_shift;
 
-  // 3. 256-point complex FFT, Stockham radix-4: A -> B -> A -> B -> A
-  float2* src = bufA[wave];
-  float2* dst = bufB[wave];
-  const float2* tw = reinterpret_cast<const float2*>(tb.twiddle);
-#pragma unroll
-  for (int stage = 0; stage < 4; ++stage) {
-    const int Ns = 1 << (2 * stage);              // 1, 4, 16, 64
-    const int k = lane & (Ns - 1);
-    float2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
-    if (stage > 0) {
-      const int step = (FFT_N / (Ns * 4)) * k;     // index into the 512-th roots table
-      v1 = cmul(v1, tw[step]);
-      v2 = cmul(v2, tw[2 * step]);
-      v3 = cmul(v3, tw[3 * step]);
+    // 1. load + DC offset
+    float part = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      float v;
+      if (wav_dtype == 0) v = (float)reinterpret_cast<const short*>(wav)[s0 + j];
+      else v = reinterpret_cast<const float*>(wav)[s0 + j];
+      v *= scale;
+      xs[j] = v;
+      part += v;
     }
-    // DFT-4 (forward: multiply by -i = (y, -x))
-    const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-    const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-    const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-    const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i * (v1 - v3)
-    const int d0 = ((lane - k) << 2) + k;          // (lane / Ns) * Ns * 4 + k
-    dst[d0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-    dst[d0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
-    dst[d0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-    dst[d0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+    const float mean = wave_sum_f(part) / (float)L;
     wave_sync();
-    float2* t = src; src = dst; dst = t;
-  }
-  // result Z[0..255] in src (= bufA)
+    // 2. pre-emphasis (replicate-pad first sample) + window, zero pad to 512
+    for (int j = lane; j < FFT_N; j += 64) {
+      float y = 0.f;
+      if (j < L) {
+        const float cur = xs[j] - mean;
+        const float prev = xs[j > 0 ? j - 1 : 0] - mean;
+        y = (cur - 0.97f * prev) * window[j];
+      }
+      zr[j] = y;
+    }
+    wave_sync();
 
-  // 4. unpack to the real-input spectrum and take the power: P[k], k = 0..256 -> floats in dst
-  float* P = reinterpret_cast<float*>(dst);
-  for (int k = lane; k <= CN; k += 64) {
-    const float2 zk = src[k & (CN - 1)];
-    const float2 zc = src[(CN - k) & (CN - 1)];
-    // E = (Z[k] + conj(Z[N-k])) / 2 ; O = (Z[k] - conj(Z[N-k])) / (2i)
-    const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
-    const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
-    const float2 w = tw[k & (FFT_N - 1)];          // exp(-2 pi i k / 512); k = 256 -> (-1, 0)
-    const float xr = er + (orr * w.x - oi * w.y);
-    const float xi = ei + (orr * w.y + oi * w.x);
-    P[k] = xr * xr + xi * xi;
-  }
-  wave_sync();
+    // 3. 256-point complex FFT, Stockham radix-4: A -> B -> A -> B -> A
+    float2* src = bufA[wave];
+    float2* dst = bufB[wave];
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+      const int Ns = 1 << (2 * stage);              // 1, 4, 16, 64
+      const int k = lane & (Ns - 1);
+      float2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+      if (stage > 0) {
+        const int step = (FFT_N / (Ns * 4)) * k;     // index into the 512-th roots table
+        v1 = cmul(v1, tw[step]);
+        v2 = cmul(v2, tw[2 * step]);
+        v3 = cmul(v3, tw[3 * step]);
+      }
+      // DFT-4 (forward: multiply by -i = (y, -x))
+      const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+      const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i * (v1 - v3)
+      const int d0 = ((lane - k) << 2) + k;          // (lane / Ns) * Ns * 4 + k
+      dst[d0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+      dst[d0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+      dst[d0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+      dst[d0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+      wave_sync();
+      float2* t = src; src = dst; dst = t;
+    }
+    // result Z[0..255] in src (= bufA)
 
-  // 5. mel filterbank + log.  Four lanes per mel bin (16 bins per pass): the triangular filters grow
-  // from 2 to ~37 taps, so one lane per bin left the longest filter on the critical path
-  // (~55 dependent LDS round trips per frame); split taps + two shuffles need ~28.
-  for (int b0 = 0; b0 < tb.num_bins; b0 += 16) {
-    const int bin = b0 + (lane >> 2), sub = lane & 3;
-    const bool has = bin < tb.num_bins;
-    const int bb = has ? bin : 0;
-    const int st = mel_start_s[bb], len = has ? mel_len_s[bb] : 0;
-    const float* w = mel_w_s + mel_off_s[bb];
-    float acc = 0.f;
-    for (int i = sub; i < len; i += 4) acc += w[i] * P[st + i];
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
-    if (live && has && sub == 0) feats[frame * tb.num_bins + bin] = v;
+    // 4. unpack to the real-input spectrum and take the power: P[k], k = 0..256 -> floats in dst
+    float* P = reinterpret_cast<float*>(dst);
+    for (int k = lane; k <= CN; k += 64) {
+      const float2 zk = src[k & (CN - 1)];
+      const float2 zc = src[(CN - k) & (CN - 1)];
+      // E = (Z[k] + conj(Z[N-k])) / 2 ; O = (Z[k] - conj(Z[N-k])) / (2i)
+      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+      const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+      const float2 w = tw[k & (FFT_N - 1)];          // exp(-2 pi i k / 512); k = 256 -> (-1, 0)
+      const float xr = er + (orr * w.x - oi * w.y);
+      const float xi = ei + (orr * w.y + oi * w.x);
+      P[k] = xr * xr + xi * xi;
+    }
+    wave_sync();
+
+    // 5. mel filterbank + log.  Four lanes per mel bin (16 bins per pass), taps i = sub, sub + 4, ...: every tap of
+    // the pass is requested before the first multiply (masked taps read P[st] with weight 0: acc + 0 * P is acc)
+    for (int b0 = 0; b0 < tb.num_bins; b0 += 16) {
+      const int bin = b0 + (lane >> 2), sub = lane & 3;
+      const bool has = bin < tb.num_bins;
+      const int st = mel_start_s[bin], len = mel_len_s[bin];
+      const float* w = mel_w_s + mel_off_s[bin];
+      const int its = (pass_max_s[b0 >> 4] + 3) >> 2;                   // wave-uniform
+      float acc = 0.f;
+#pragma unroll
+      for (int h0 = 0; h0 < 12; h0 += 6) {          // six taps in flight at a time (registers: six workgroups per CU)
+        if (h0 < its) {
+          float wv[6], pv[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            if (h0 + q < its) {
+              const int i = sub + 4 * (h0 + q);
+              const bool ok = i < len;
+              wv[q] = ok ? w[i] : 0.f;
+              pv[q] = P[st + (ok ? i : 0)];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            if (h0 + q < its) acc += wv[q] * pv[q];
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      if (has && sub == 0) feats[frame * tb.num_bins + bin] = v;
+    }
+    wave_sync();                                  // the next frame reuses bufA / bufB
   }
 }
 
@@ -167,10 +197,19 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
   if (T <= 0 || B <= 0) return hipSuccess;
   if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128)
     return hipErrorInvalidValue;
+  // the longest triangular filter must fit the mel phase's 12 x 4 taps
   const long long total = (long long)B * T;
-  const unsigned blocks = (unsigned)((total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  long long blocks = (total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const long long resident = (long long)cus * 6;         // ~26 KB of LDS per workgroup: six per CU
+  if (blocks > resident) blocks = resident;
   const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
-  hipLaunchKernelGGL(fbank_kernel, dim3(blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
+  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
                      wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
   return hipGetLastError();
 }
