@@ -727,6 +727,51 @@ def test_full_size_every_bench_workload(name, E, batch, prec):
     assert bool(torch.isfinite(full).all())
 
 
+def test_persistent_fp32_gemm_against_the_tile_kernels(tmp_path):
+    """gemm_f32_stream.hip (the persistent kernel of the plain 1x1 layers) keeps the tile kernels' k order per
+    accumulator, so its GEMM outputs are the tile kernels' bits (tools/stream_probe compares whole layers); only its
+    per-tile column sums are folded in another order.  Whole models, with WS_STREAM=0 (tile kernels only), each form
+    forced (2: 128x128 tile, 3: 256x128 tile) and the dispatcher's choice: ResNet221 (no column sums) must give the
+    same BITS, the ECAPA models (SE means / context statistics from column sums) the same embeddings to 1e-6.
+    ECAPA-512 (column sums, dual store), ECAPA-1024 (K = 3072 layer), and a batch whose row count is not a multiple of
+    the tile rows."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fixtures import synth\n"
+        "from bench import device_wavs\n"
+        "from wespeaker_amd import Frontend, NativeSpeakerModel\n"
+        "dev = torch.device('cuda:0'); fe = Frontend(16000, 80, device=dev); out = {}\n"
+        "for name, E, B in (('ECAPA_TDNN_GLOB_c512', 192, 256), ('ECAPA_TDNN_GLOB_c1024', 192, 256),\n"
+        "                   ('ResNet221', 256, 64), ('ECAPA_TDNN_c512', 192, 171)):\n"
+        "    sd = synth.synth_state_dict(name, 80, E, seed=5)\n"
+        "    m = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=E, device=dev, max_batch=B, max_frames=198)\n"
+        "    out[name] = m.extract(fe, device_wavs(B, 32000, dev, 17)).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % root)
+    res = {}
+    for mode in ("0", "2", "3", ""):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("WS_STREAM", None)
+        if mode:
+            env["WS_STREAM"] = mode
+        path = str(tmp_path / ("emb_%s.npz" % (mode or "auto")))
+        r = subprocess.run([sys.executable, str(script), path], env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        res[mode] = np.load(path)
+    for mode in ("2", "3", ""):
+        for k in res["0"].files:
+            assert np.isfinite(res[mode][k]).all()
+            if k.startswith("ResNet"):
+                assert np.array_equal(res["0"][k], res[mode][k]), (mode, k, np.abs(res["0"][k] - res[mode][k]).max())
+            else:
+                assert _rel_err(res[mode][k], res["0"][k]).max() < 1e-6, (mode, k)
+
+
 def test_full_size_plda_one_million_trials():
     """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
