@@ -255,6 +255,23 @@ struct EcapaModel : ModelBase {
       a1.bias_img = bias_img;
     }
     a1.row_len = L0;
+    if (gemm_precision == 0 && !no_fuse && astp_fused_supported(T, 1536, 128)) {
+      // linear1 -> tanh -> linear2 -> softmax over time -> weighted mean / std: one workgroup per utterance,
+      // neither the bottleneck activations nor the logits leave the chip (astp_fused.hip)
+      if (prof.enabled) {
+        const double m = (double)B * T;
+        prof.begin(0, 2.0 * m * 128 * 1536 * 2, 4.0 * (2.0 * m * 1536 + 2.0 * 128 * 1536 + 2.0 * B * 1536), st);
+      }
+      if (dispatch_log_enabled()) {
+        ConvGemmParams note = a1;
+        note.N = 1536 + 128;
+        dispatch_log_note(note, "astp_fused_kernel (linear1 + tanh + linear2 + softmax pooling)");
+      }
+      hipError_t fe = launch_astp_fused(h, 1536, B, T, arena.at(pool1.w), pool1.ldw, glob ? nullptr : a1.bias,
+                                        glob ? bias_img : nullptr, arena.at(pool2.w), pool2.ldw, pooled, L0, st);
+      prof.end(st);
+      WS_LAUNCH(fe);
+    } else {
     WS_LAUNCH(gemm(a1, st));
     if (T >= 64 && !no_fuse) {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
@@ -272,6 +289,7 @@ struct EcapaModel : ModelBase {
       WS_LAUNCH(other(8.0 * B * (double)T * 1536, st, [&] {
         return launch_astp_pool(e, 1536, h, 1536, B, T, 1536, pooled, st, L0);
       }));
+    }
     }
     // BN + Linear (+bn2), folded: split-K GEMM over K = 3072
     WS_LAUNCH(gemm_splitk(conv1d(final_lin, pooled, 3072, 0, emb, embed_dim, 0, B, 1, 1, ACT_NONE),
