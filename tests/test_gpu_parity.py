@@ -1237,7 +1237,11 @@ RAGGED_CASES = [("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 399, 5, 201]),
                 ("ECAPA_TDNN_GLOB_c512", 192, [1203, 417, 798, 416, 500]),
                 ("ECAPA_TDNN_c1024", 192, [600, 450]),
                 ("ResNet34", 256, [1001, 640, 431]),
-                ("CAMPPlus", 512, [1500, 1001, 777])]
+                ("CAMPPlus", 512, [1500, 1001, 777]),
+                # 160 < T <= 208: the one-kernel attentive pooling (astp_fused.hip) with per-utterance lengths,
+                # a full 208-frame window, and its shortest window
+                ("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 208, 5, 203]),
+                ("ECAPA_TDNN_c512", 192, [161, 100, 161])]
 
 
 @pytest.mark.parametrize("name,E,lens", RAGGED_CASES)

@@ -35,9 +35,11 @@ namespace wsamd {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F_RB = 13;                       // row blocks of 16 frames
 constexpr int F_ROWS = 16 * F_RB;              // 208
+constexpr int F_WHOLE = 10;                    // T > 160: row blocks 0..9 lie inside every utterance
 constexpr int F_NH = 128;                      // bottleneck width
 constexpr int F_BK = 32;
 constexpr int F_APIECES = F_ROWS / 8;          // 26 pieces of 8 rows x 128 B
@@ -80,6 +82,15 @@ __device__ __forceinline__ float f_tanh(float x) {
   return __builtin_copysignf(t, x);
 }
 
+#ifdef WS_TRACE
+__device__ unsigned long long g_astp_trace[2 * 64];       // [wavefront 0 | wavefront 4] x 64 slots, workgroup 9
+#define WS_ASTAMP(i)                                                                                    \
+  { const int _i = (i); if (blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256) && _i < 64)     \
+      g_astp_trace[_i + (threadIdx.x >> 2)] = __builtin_readcyclecounter(); }
+#else
+#define WS_ASTAMP(i)
+#endif
+
 struct AstpFusedParams {
   const float* h; int ldh;          // [B*T][ldh] (1536 channels used)
   const float* w1; int ldw1;        // [128][ldw1], columns 0..1535 multiply h
@@ -91,6 +102,7 @@ struct AstpFusedParams {
   int B, T;
 };
 
+template <bool RAGGED>
 __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
@@ -107,9 +119,11 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) offA[jj] = r16 * 128 + (((4 * jj + q4) ^ (r16 & 7)) * 16);
   const int offW = F_W_BYTE0 + wave * 16 * 128;
-  int offH[8];
+  // H fragment of (block b, k chunk j = 2 m + jl): the XOR key only reaches the low three chunk bits, so
+  // byte = offH[jl] + 128 m + 8192 b: two lane registers, everything else is an immediate of ds_read_b128
+  int offH[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) offH[j] = r16 * 512 + (((4 * j + q4) ^ (r16 & 7)) * 16);
+  for (int jl = 0; jl < 2; ++jl) offH[jl] = r16 * 512 + (((4 * jl + q4) ^ (r16 & 7)) * 16);
 
   {
     // one utterance per workgroup (nothing carries over between utterances, so there is nothing to gain from a
@@ -130,16 +144,18 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
       const int grow = isw ? row : (row < T ? row : T - 1);
       voff[i] = (unsigned)((grow * (isw ? p.ldw1 : p.ldh)) * 4 + c * 16);
     }
+    auto dma_piece = [&](int kt, int stage, int i) {
+      const int q = wave * F_NP + i;
+      const bool isw = (q < F_PIECES ? q : F_PIECES - 1) >= F_APIECES;       // wave-uniform
+      const char* gb = isw ? reinterpret_cast<const char*>(p.w1) : reinterpret_cast<const char*>(hu);
+      f_dma_16B(gb + (size_t)(unsigned)(kt * (F_BK * 4)) + voff[i], ldsb + stage * F_STAGE_BYTES + q * 1024);
+    };
     auto dma_ktile = [&](int kt, int stage) {
 #pragma unroll
-      for (int i = 0; i < F_NP; ++i) {
-        const int q = wave * F_NP + i;
-        const bool isw = (q < F_PIECES ? q : F_PIECES - 1) >= F_APIECES;       // wave-uniform
-        const char* gb = isw ? reinterpret_cast<const char*>(p.w1) : reinterpret_cast<const char*>(hu);
-        f_dma_16B(gb + (size_t)(unsigned)(kt * (F_BK * 4)) + voff[i], ldsb + stage * F_STAGE_BYTES + q * 1024);
-      }
+      for (int i = 0; i < F_NP; ++i) dma_piece(kt, stage, i);
     };
 
+    WS_ASTAMP(0);
     dma_ktile(0, 0);
     dma_ktile(1, 1);
 
@@ -148,26 +164,68 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
     for (int b = 0; b < F_RB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---------------------------------------------------------------- phase A: H = tanh(X W1^T + bias)
+    // While the partner wavefront of the SIMD issues MFMAs back to back, NOTHING of this wavefront is issued (measured:
+    // 14 ds_reads or 150 VALU instructions stretch to the end of the partner's MFMA burst, whatever s_setprio says), so
+    // fragment reads / DMA issue as a separate phase cost their full length.  Hence one instruction stream per
+    // wavefront in which every non-MFMA instruction sits behind an MFMA: the MFMAs of K-tile kt run on fragments read
+    // during K-tile kt - 1, and the register of a fragment is refilled from stage kt + 1 right behind the MFMAs that
+    // consumed it.  The rendezvous at the top of K-tile kt says: K-tile kt + 1 has landed (kt + 2 may be in flight)
+    // and nobody reads stage kt any more -- it is refilled with K-tile kt + 3.
+    f32x4 fA[2][F_RB], fB[2];
+    dma_ktile(2, 2);
+    f_wait_vm_barrier<2 * F_NP>();                 // K-tile 0 has landed (1 and 2 in flight)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      fB[jj] = *reinterpret_cast<const f32x4*>(ldsb + offW + offA[jj]);
+#pragma unroll
+      for (int b = 0; b < F_RB; ++b) fA[jj][b] = *reinterpret_cast<const f32x4*>(ldsb + b * 2048 + offA[jj]);
+    }
     int stage = 0;
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) f_wait_vm_barrier<F_NP>(); else f_wait_vm_barrier<0>();
-      if (kt + 2 < nk) dma_ktile(kt + 2, stage >= 1 ? stage - 1 : 2);
-      const char* sb = ldsb + stage * F_STAGE_BYTES;
+      if (kt == 10) WS_ASTAMP(5);
+      if (kt == 11) WS_ASTAMP(6);
+      const int nxt = stage == F_NSTAGE - 1 ? 0 : stage + 1;
+      const bool more = kt + 1 < nk;               // (the last K-tile re-reads its own stage: harmless, unused)
+      if (kt == 10 || kt == 11) WS_ASTAMP(56 + 2 * (kt - 10));
+      if (kt + 2 < nk) f_wait_vm_barrier<F_NP>(); else f_wait_vm_barrier<0>();
+      if (kt == 10 || kt == 11) WS_ASTAMP(57 + 2 * (kt - 10));
+      const char* nb = ldsb + (more ? nxt : stage) * F_STAGE_BYTES;
+      const bool fill = kt + 3 < nk;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const f32x4 fb = *reinterpret_cast<const f32x4*>(sb + offW + offA[jj]);
 #pragma unroll
-        for (int b = 0; b < F_RB; ++b) {
-          const f32x4 fa = *reinterpret_cast<const f32x4*>(sb + b * 2048 + offA[jj]);
+        for (int b = 0; b < F_RB; b += 2) {
+          const f32x4 a0 = fA[jj][b], a1 = fA[jj][b + 1 < F_RB ? b + 1 : b], w = fB[jj];
+          if (b + 1 < F_RB) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[b] = f_mfma(fa[s], fb[s], acc[b]);
+            for (int s = 0; s < 4; ++s) {
+              acc[b] = f_mfma(a0[s], w[s], acc[b]);
+              acc[b + 1] = f_mfma(a1[s], w[s], acc[b + 1]);
+              if (s == 0) {            // behind the first MFMAs of the pair: one DMA piece / the refills
+                const int piece = jj * 7 + b / 2;          // 0..13
+                if (fill && piece < F_NP) dma_piece(kt + 3, stage, piece);
+              }
+              if (s == 1) fA[jj][b] = *reinterpret_cast<const f32x4*>(nb + b * 2048 + offA[jj]);
+              if (s == 2) fA[jj][b + 1] = *reinterpret_cast<const f32x4*>(nb + (b + 1) * 2048 + offA[jj]);
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[b] = f_mfma(a0[s], w[s], acc[b]);
+            fA[jj][b] = *reinterpret_cast<const f32x4*>(nb + b * 2048 + offA[jj]);
+            fB[jj] = *reinterpret_cast<const f32x4*>(nb + offW + offA[jj]);
+          }
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
-      stage = stage == F_NSTAGE - 1 ? 0 : stage + 1;
+      stage = nxt;
     }
+    WS_ASTAMP(1);
     // every wavefront has read its last fragments, no DMA is in flight: H may overwrite the ring
     f_wait_vm_barrier<0>();
+    WS_ASTAMP(2);
     {
       const int n = wave * 16 + r16;
       const float bv = p.bias_img ? p.bias_img[(long long)u * F_NH + n] : (p.bias ? p.bias[n] : 0.f);
@@ -182,7 +240,9 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
         }
       }
     }
+    WS_ASTAMP(3);
     __syncthreads();
+    WS_ASTAMP(4);
 
     // ---------------------------------------------------------------- phase B: logits -> softmax -> weighted sums
     const __amdgpu_buffer_rsrc_t x_rsrc =
@@ -199,11 +259,6 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
 #pragma unroll
       for (int j = 0; j < 8; ++j) fw[j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j);
     };
-    auto read_h = [&](int step, f32x4 (&f)[4]) {          // step = 2 b + (half of K)
-      const char* base = ldsb + (step >> 1) * 8192;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) f[jj] = *reinterpret_cast<const f32x4*>(base + offH[4 * (step & 1) + jj]);
-    };
     f32x4 fw[2][8];
     load_w2(wave, fw[0]);
 #pragma unroll 1
@@ -213,8 +268,9 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
         const int sl = (it + half) * 8 + wave;
         const int c0 = 16 * sl;
         if (it + half + 1 < F_SLICES) load_w2(sl + 8, fw[half ^ 1]);
-        // (the 52 lane offsets and 52 row masks of a slice are two instructions each; opaque copies of their
-        // inputs keep the compiler from hoisting all of them out of the slice loop and spilling them)
+        // x of this slice: requested now, used after the MFMAs.  Row block b is a scalar offset (T > 160: the first
+        // ten blocks are whole, only the last three clamp to the utterance's last frame).  Opaque copies of the lane
+        // offsets keep the compiler from hoisting the per-slice address arithmetic out of the slice loop (it spills).
         int xo[4], lo = last_off, lim = len - 4 * q4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -223,61 +279,107 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
         }
         asm volatile("" : "+v"(lo));
         asm volatile("" : "+v"(lim));
-        // x of this slice: requested now, used after the MFMAs
-        float xv[F_RB][4];
+        f32x2 xv[F_RB][2];
 #pragma unroll
         for (int b = 0; b < F_RB; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int vo = min(xo[r] + b * blk_bytes, lo);
-            xv[b][r] = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, vo, c0 * 4, 0));
+            float v;
+            if (b < F_WHOLE)
+              v = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xo[r], c0 * 4 + b * blk_bytes, 0));
+            else
+              v = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(
+                  x_rsrc, min(xo[r] + b * blk_bytes, lo), c0 * 4, 0));
+            xv[b][r >> 1][r & 1] = v;
           }
+        WS_ASTAMP(8 + 4 * (it + half));
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         f32x4 lg[F_RB];
-        f32x4 fa[2][4];
-        read_h(0, fa[0]);
 #pragma unroll
-        for (int step = 0; step < 2 * F_RB; ++step) {
-          const int b = step >> 1, jh = step & 1;
-          if (step + 1 < 2 * F_RB) read_h(step + 1, fa[(step + 1) & 1]);
-          if (jh == 0) lg[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < F_RB; ++b) lg[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // k chunk outermost, row blocks in pairs with alternating MFMAs (see phase A); the fragments of the next
+        // pair are read before the MFMAs of this one
+        f32x4 fa[2][2];
+        auto read_pair = [&](int idx, f32x4 (&f)[2]) {       // idx = 7 j + pair; the last pair of a chunk is block 12 alone
+          const int j = idx / 7, pr = idx - 7 * j;
+          f[0] = *reinterpret_cast<const f32x4*>(ldsb + offH[j & 1] + ((2 * pr) * 8192 + (j >> 1) * 128));
+          if (pr < 6) f[1] = *reinterpret_cast<const f32x4*>(ldsb + offH[j & 1] + ((2 * pr + 1) * 8192 + (j >> 1) * 128));
+        };
+        read_pair(0, fa[0]);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
+        for (int idx = 0; idx < 56; ++idx) {
+          const int j = idx / 7, pr = idx - 7 * j, b = 2 * pr;
+          if (idx + 1 < 56) read_pair(idx + 1, fa[(idx + 1) & 1]);
+          if (pr < 6) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) lg[b] = f_mfma(fa[step & 1][jj][s], fw[half][4 * jh + jj][s], lg[b]);
+            for (int s = 0; s < 4; ++s) {
+              lg[b] = f_mfma(fa[idx & 1][0][s], fw[half][j][s], lg[b]);
+              lg[b + 1] = f_mfma(fa[idx & 1][1][s], fw[half][j][s], lg[b + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              lg[b] = f_mfma(fa[idx & 1][0][s], fw[half][j][s], lg[b]);
+            }
+          }
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-        // softmax over the live frames of column c0 + r16 (exp2 domain, the max folded into one fma)
+        WS_ASTAMP(9 + 4 * (it + half));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the softmax, the stores and the next slice's load requests win the issue arbitration against the other
+        // wavefront's MFMAs (which need one issue slot in 32 cycles): without this they are starved for as long as
+        // the other wavefront has MFMAs to issue, and the two wavefronts of a SIMD take turns instead of overlapping
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        // softmax over the live frames of column c0 + r16 (exp2 domain, the max folded into one fma; packed fp32
+        // arithmetic on register pairs).  Rows past the utterance only exist in the last three blocks unless the
+        // batch is ragged.
         constexpr float LOG2E = 1.4426950408889634f;
         float mx = -1e30f;
 #pragma unroll
         for (int b = 0; b < F_RB; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            mx = 16 * b + r < lim ? fmaxf(mx, lg[b][r]) : mx;
+            if (RAGGED || b >= F_WHOLE) mx = 16 * b + r < lim ? fmaxf(mx, lg[b][r]) : mx;
+            else mx = fmaxf(mx, lg[b][r]);
           }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float ml = mx * LOG2E;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        WS_ASTAMP(11 + 4 * (it + half));
+        f32x2 s0v = {0.f, 0.f}, s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+        const f32x2 mlv = {ml, ml};
 #pragma unroll
         for (int b = 0; b < F_RB; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float e = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-            e = __builtin_amdgcn_exp2f(__builtin_fmaf(lg[b][r], LOG2E, -ml));
+          for (int hp = 0; hp < 2; ++hp) {
+            const f32x2 l2 = {lg[b][2 * hp], lg[b][2 * hp + 1]};
+            const f32x2 arg = l2 * LOG2E - mlv;
+            f32x2 e = {0.f, 0.f};
+#if defined(WS_EXP_NOSOFTMAX)       // timing experiment only (wrong results): how much of phase B is the VALU work?
+            e = arg;
+#elif defined(__HIP_DEVICE_COMPILE__)
+            e[0] = __builtin_amdgcn_exp2f(arg[0]);
+            e[1] = __builtin_amdgcn_exp2f(arg[1]);
 #endif
-            e = 16 * b + r < lim ? e : 0.f;
-            const float x = xv[b][r];
-            const float ex = e * x;
-            s0 += e;
-            s1 += ex;
-            s2 = __builtin_fmaf(ex, x, s2);
+            if (RAGGED || b >= F_WHOLE) {
+              e[0] = 16 * b + 2 * hp < lim ? e[0] : 0.f;
+              e[1] = 16 * b + 2 * hp + 1 < lim ? e[1] : 0.f;
+            }
+            const f32x2 x = xv[b][hp];
+            const f32x2 ex = e * x;
+            s0v += e;
+            s1v += ex;
+            s2v += ex * x;
           }
+        float s0 = s0v[0] + s0v[1], s1 = s1v[0] + s1v[1], s2 = s2v[0] + s2v[1];
         s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
         s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        WS_ASTAMP(10 + 4 * (it + half));
         if (q4 == 0) {
           const float inv = 1.f / s0;
           const float mean = s1 * inv;
@@ -308,8 +410,11 @@ hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float*
   if ((long long)T * ldh * 4 >= (1ll << 31) || (long long)F_NH * ldw1 * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -324,7 +429,8 @@ hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float*
   }
   (void)cus;
   const int grid = B;
-  hipLaunchKernelGGL(astp_fused_kernel, dim3(grid), dim3(512), F_LDS_BYTES, stream, p);
+  if (lens) hipLaunchKernelGGL(astp_fused_kernel<true>, dim3(grid), dim3(512), F_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(astp_fused_kernel<false>, dim3(grid), dim3(512), F_LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
