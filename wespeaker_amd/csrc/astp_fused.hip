@@ -360,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
             const f32x2 l2 = {lg[b][2 * hp], lg[b][2 * hp + 1]};
             const f32x2 arg = l2 * LOG2E - mlv;
             f32x2 e = {0.f, 0.f};
+            (void)arg;
 #if defined(WS_EXP_NOSOFTMAX)       // timing experiment only (wrong results): how much of phase B is the VALU work?
             e = arg;
 #elif defined(__HIP_DEVICE_COMPILE__)

@@ -154,8 +154,20 @@ struct EcapaModel : ModelBase {
         p0.A16 = col16; p0.lda16 = layer1.ldw; p0.lda = layer1.ldw;
         p0.K = layer1.ldw; p0.Cin = layer1.ldw; p0.kw = 1; p0.pad_w = 0; p0.dil_w = 1;
       }
+      // fp32 back-end, full batches: the same trick in fp32 -- the im2col image (K = taps*F rounded up to 32
+      // columns: 13 K-tiles for 5 x 80) lives in the not-yet-used h buffer and the layer becomes a plain 1x1 GEMM of
+      // the persistent kernel (the implicit-GEMM form stays for ragged and small batches: same k order, same bits)
+      const int kcol = (5 * feat_dim + 31) & ~31;
+      if (gemm_precision == 0 && !no_im2col && !L0 && feat_dim % 4 == 0 && kcol <= layer1.ldw && kcol <= 1536 &&
+          (long long)B * T >= 16384) {
+        WS_LAUNCH(other(4.0 * B * (double)T * (kcol + feat_dim), st, [&] {
+          return launch_im2col_f32(feats, B, T, feat_dim, 5, 2, h, kcol, st);
+        }));
+        p0.A = h; p0.lda = kcol; p0.a_off = 0;
+        p0.K = kcol; p0.Cin = kcol; p0.kw = 1; p0.pad_w = 0; p0.dil_w = 1;
+      }
       p0.row_len = L0;
-      WS_LAUNCH(gemm(p0, st));
+      WS_LAUNCH(gemm(p0, st, 5 * feat_dim));
     }
     for (int L = 0; L < 3; ++L) {
       const int d = L + 2;

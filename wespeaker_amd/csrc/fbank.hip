@@ -368,6 +368,35 @@ hipError_t launch_im2col_f16(const float* feats, int B, int T, int F, int taps, 
   return hipGetLastError();
 }
 
+// fp32 im2col of the same conv (parity-grade back-end): one thread per float4; a float4 never straddles a tap
+// (F % 4 == 0); columns [taps * F, ld) are zeros
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict__ feats, int T, int F, int taps,
+                                                         int pad, float* __restrict__ out, int ld, long long total4) {
+  const int c4n = ld >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long m = i / c4n;
+    const int k = (int)(i - m * c4n) * 4;
+    const int b = (int)(m / T), t = (int)(m - (long long)b * T);
+    const int tap = k / F, f = k - tap * F;
+    const int ts = t + tap - pad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tap < taps && ts >= 0 && ts < T) v = *reinterpret_cast<const float4*>(feats + ((long long)b * T + ts) * F + f);
+    *reinterpret_cast<float4*>(out + m * ld + k) = v;
+  }
+}
+
+hipError_t launch_im2col_f32(const float* feats, int B, int T, int F, int taps, int pad, float* out, int ld,
+                             hipStream_t stream) {
+  if ((F & 3) || (ld & 3) || ld < taps * F) return hipErrorInvalidValue;
+  const long long total4 = (long long)B * T * (ld >> 2);
+  if (total4 <= 0) return hipSuccess;
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feats, T, F, taps, pad, out,
+                     ld, total4);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ chunk-and-average mode
 // SpeakerEngine::ExtractFeature, chunk-by-chunk branch (runtime/core/speaker/speaker_engine.cc:96-131):
 // the utterance's frames [total][F] are cut into consecutive chunks of `cf` frames; a trailing

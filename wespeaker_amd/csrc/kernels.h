@@ -227,6 +227,9 @@ hipError_t launch_resample(const float* x, long long n_in, const float* kern, in
 // into a plain GEMM for the LDS-DMA kernel
 hipError_t launch_im2col_f16(const float* feats, int B, int T, int F, int taps, int pad, uint16_t* out,
                              int ld, hipStream_t stream);
+// the same image in fp32 (columns [taps*F, ld) zero): the k5 layer as a plain GEMM for the persistent fp32 kernel
+hipError_t launch_im2col_f32(const float* feats, int B, int T, int F, int taps, int pad, float* out, int ld,
+                             hipStream_t stream);
 // chunk-and-average mode of the native runtime (speaker_engine.cc:83-159)
 hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int n_full, int n_chunks,
                                float* dst, hipStream_t stream);

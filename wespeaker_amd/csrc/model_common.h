@@ -377,9 +377,10 @@ struct ModelBase : Model {
   }
 
   // ------------------------------------------------------------------------- profiled launches
-  hipError_t gemm(const ConvGemmParams& p, hipStream_t st) {
+  // k_alg: the algorithmic contraction length when p.K carries zero padding (im2col images)
+  hipError_t gemm(const ConvGemmParams& p, hipStream_t st, int k_alg = 0) {
     if (prof.enabled) {
-      const double flops = 2.0 * p.M * (double)p.N * p.K;
+      const double flops = 2.0 * p.M * (double)p.N * (k_alg ? k_alg : p.K);
       // algorithmic bytes: A once, W once, every stored copy of D once (binary16 tensors count 2 B)
       const double a_b = p.prec == 2 && p.A16 ? 2.0 : 4.0 * (p.A2 ? 2 : 1);
       const double w_b = p.prec == 0 ? 4.0 : (p.prec == 1 ? 4.0 : 2.0);

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(512) void res2_chain_kernel(const Res2ChainParams p
 #pragma unroll
     for (int mp = 0; mp < MTW; mp += 2) {
       const bool two = mp + 1 < MTW;
+      // a row tile pair that lies entirely behind the utterance's last frame has nothing to compute (T = 198 in
+      // a 224-row window: the 14th tile -- 1/14 of the MFMAs of every step); wave-uniform
+      if (tbase + (wm * MTW + mp) * 16 >= T) continue;
       f32x4 fa[2][2];
       fa[0][0] = *reinterpret_cast<const f32x4*>(xaddr(mp, 0));
       fa[0][1] = two ? *reinterpret_cast<const f32x4*>(xaddr(mp + 1, 0)) : fa[0][0];
