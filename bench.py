@@ -335,6 +335,9 @@ def parse_args(argv):
     ap.add_argument("--headline-only", action="store_true",
                     help="only the --precision back-end: no other back-ends, no config legs, no PLDA, no CPU "
                          "baseline (for rocprofv3 runs: the kernel statistics then describe one workload)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="batches in flight per GPU (wespeaker_amd.SpeakerModelLanes: one engine + HIP stream per "
+                         "lane, step i runs on lane i %% lanes); 1 = one stream, every launch behind the previous one")
     ap.add_argument("--precision", default="fp32", choices=list(BACKENDS),
                     help="back-end of the headline (`value`): fp32 = the reference's arithmetic (default); "
                          "f16x3 / f16 are the declared fast modes, always reported under `backends`")
@@ -494,7 +497,15 @@ def main(argv=None):
         return
 
     # ======================================================================= default: per-step batches (weak scaling)
-    model = make_model(name, E, chunk, T)
+    n_lanes = 1 if STUB else max(1, args.lanes)
+    lm = None
+    if n_lanes > 1:
+        from wespeaker_amd import SpeakerModelLanes
+        lm = SpeakerModelLanes(name, synth.synth_state_dict(name, 80, E, seed=42), lanes=n_lanes, feat_dim=80,
+                               embed_dim=E, device=device, max_batch=chunk, max_frames=T)
+        model = lm.engines[0]
+    else:
+        model = make_model(name, E, chunk, T)
     if STUB:
         g = torch.Generator().manual_seed(1234 + rank)
         wav = (3000.0 * torch.randn(batch, num_samples, generator=g)).round().to(torch.int16)
@@ -507,7 +518,18 @@ def main(argv=None):
     # before the closing fence of a timed window (`drain`), i.e. all K gathers lie inside the timed region
     in_flight = []
 
+    use_lanes = [lm is not None]                                   # (the single-lane windows switch it off)
+
     def step():
+        if use_lanes[0]:
+            # step i on lane i % lanes: two (three) batches in flight; a result is joined `lanes` steps later
+            res = lm.extract(fe, wav)
+            if world == 1:
+                in_flight.append(res)
+            else:
+                with torch.cuda.stream(lm.streams[res.lane]):     # the gather waits for this lane only
+                    in_flight.append(parallel.gather_rows_async(res.tensor, n_total))
+            return in_flight.pop(0).wait() if len(in_flight) > max(2, n_lanes) else None
         emb = model.extract(fe, wav)                              # (B, E) on this GPU
         if world == 1:
             return emb
@@ -523,7 +545,8 @@ def main(argv=None):
         """EXACTLY `steps` steps between two fences; max over ranks; HIP events bracket only the dominant
         kernel class inside it (events around all ~45 launches per chunk cost ~12 %)."""
         fence()
-        if not STUB:
+        events = not STUB and not use_lanes[0]      # with several batches in flight the kernels of the lanes share
+        if events:                                  # the CUs: a launch's begin -> end is not its own duration
             model.profile(1)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -532,7 +555,7 @@ def main(argv=None):
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = None
-        if not STUB:
+        if events:
             prof = model.profile_read()[DOMINANT]
             model.profile(False)
         return dt, prof, out
@@ -588,7 +611,14 @@ def main(argv=None):
         return roof
 
     def run_backend(prec, steps, warmup, windows):
-        model.set_precision(prec)
+        # several batches in flight: the parity-grade back-end only (SpeakerModelLanes.set_precision: open issue with
+        # binary16 engines on concurrent streams)
+        lanes_here = lm is not None and prec == "fp32"
+        if lanes_here:
+            lm.set_precision(prec)
+        else:
+            model.set_precision(prec)
+        use_lanes[0] = lanes_here
         for _ in range(warmup):
             step()
         drain(None)
@@ -597,15 +627,32 @@ def main(argv=None):
             dt, prof, out = timed_window(steps)
             dts.append(dt)
             profs.append(prof)
-        model.check_range()                                    # binary16 back-ends: loud on overflow
+        (lm if lanes_here else model).check_range()            # binary16 back-ends: loud on overflow
         vals = [n_total * steps / d for d in dts]
         block = {"precision": prec, "dtype": DTYPE_TEXT[prec], "value": vals[0], "unit": "embeddings/s",
                  "ms_per_step": dts[0] / steps * 1e3, "steps": steps, "warmup": warmup,
+                 "batches_in_flight": n_lanes if lanes_here else 1,
                  "windows_embeddings_per_s": [round(v, 1) for v in vals],
                  "median": statistics.median(vals), "min": min(vals), "max": max(vals),
                  "spread_rel": (max(vals) - min(vals)) / statistics.median(vals)}
+        if lanes_here:
+            # the same steps on ONE lane (every launch behind the previous one): the per-kernel durations of the
+            # roofline block come from these windows -- with several batches in flight the lanes' kernels overlap
+            use_lanes[0] = False
+            for _ in range(2):
+                step()
+            drain(None)
+            sdts, profs = [], []
+            for _ in range(max(1, min(windows, 3))):
+                dt, prof, _o = timed_window(steps)
+                sdts.append(dt)
+                profs.append(prof)
+            svals = [n_total * steps / d for d in sdts]
+            block["one_batch_in_flight"] = {"value": svals[0], "ms_per_step": sdts[0] / steps * 1e3,
+                                            "windows_embeddings_per_s": [round(v, 1) for v in svals]}
         if not STUB:
             # untimed pass with every kernel class bracketed, for the per-class breakdown only
+            use_lanes[0] = False
             model.profile(True)
             bsteps = min(steps, 5)
             for _ in range(bsteps):
@@ -615,6 +662,13 @@ def main(argv=None):
             breakdown = model.profile_read()
             model.profile(False)
             block["roofline"] = roofline_block(model, name, prec, steps, dts[0], profs, breakdown, bsteps, batch)
+            if lanes_here:
+                block["roofline"]["note_lanes"] = (
+                    "`achieved` / `frac` / `avg_launch_ms`: HIP events around the class's launches in timed windows "
+                    "of the same run with ONE batch in flight (`one_batch_in_flight`), where a launch's begin -> end "
+                    "is its own duration; `value` and `whole_step_*` are the windows with %d batches in flight "
+                    "(the lanes' kernels share the CUs there)" % n_lanes)
+            use_lanes[0] = lanes_here
         return block, out
 
     # ---- headline back-end first: W warmup steps, then the contract's timed region (window 0)
@@ -639,6 +693,9 @@ def main(argv=None):
         for other in [m for m in BACKENDS if m != args.precision]:
             blocks[other], _ = run_backend(other, max(3, min(args.steps, 10)), 2, max(1, min(args.windows, 3)))
     model.set_precision(args.precision)
+    if lm is not None and args.precision == "fp32":
+        lm.set_precision("fp32")
+    use_lanes[0] = False
 
     # ---- the other BASELINE.json configs, compact: per model one fp32 leg with its dominant-class fraction (HIP
     # events) + the f16 rate; and the two fixed-size sets (configs 2 / 3) at this N
@@ -714,9 +771,25 @@ def main(argv=None):
             bm.profile(False)
             peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS
             batch_sweep[str(b)] = {"value": b * ks / bdt, "unit": "embeddings/s", "ms_per_step": bdt / ks * 1e3,
-                                   "steps": ks, "engine_chunk": b,
+                                   "steps": ks, "engine_chunk": b, "batches_in_flight": 1,
                                    "dominant_frac": (pr["flops"] / (pr["ms"] * 1e-3) / 1e12 / peak) if pr["ms"] else None}
-            del bm, bw
+            del bm
+            if n_lanes > 1 and args.precision == "fp32":
+                # ... and with the headline's number of batches in flight
+                bl = SpeakerModelLanes(name, synth.synth_state_dict(name, 80, E, seed=42), lanes=n_lanes, feat_dim=80,
+                                       embed_dim=E, device=device, max_batch=b, max_frames=T)
+                bl.set_precision(args.precision)
+                for _ in range(2 * n_lanes):
+                    bl.extract(fe, bw)
+                sync()
+                tb = time.perf_counter()
+                for _ in range(ks * n_lanes):
+                    bl.extract(fe, bw)
+                sync()
+                bdt = time.perf_counter() - tb
+                batch_sweep[str(b)]["value_%d_batches_in_flight" % n_lanes] = b * ks * n_lanes / bdt
+                del bl
+            del bw
 
     # ---- PLDA leg (rank 0 scores after the gather; 1 M synthetic trial pairs over 10 k embeddings)
     plda_info = None
@@ -738,12 +811,14 @@ def main(argv=None):
                                    "(wav resident in HBM -> fbank -> CMN -> forward -> all_gather)"
                                    % (name, E, batch, args.seconds),
                        "per_gpu_batch": batch, "global_batch": n_total, "frames": T,
-                       "engine_chunk": chunk, "parallelism": "utterance-sharded x%d" % world},
+                       "engine_chunk": chunk, "parallelism": "utterance-sharded x%d" % world,
+                       "batches_in_flight_per_gpu": head.get("batches_in_flight", 1)},
             "headline_backend": args.precision,
             "headline_is_parity_grade": args.precision == "fp32",
             "headline_note": "value/dtype/roofline describe the %s back-end; fp32 = the arithmetic of the "
                              "reference path (parity-grade); f16x3 and f16 are declared fast modes, see "
                              "`backends`" % args.precision,
+            "value_one_batch_in_flight": (head.get("one_batch_in_flight") or {}).get("value"),
             "value_median_over_windows": head["median"],
             "value_spread_rel": head["spread_rel"],
             "roofline": head.get("roofline"),

@@ -8,7 +8,7 @@ the native library raises if it (or a GPU) is missing -- there is no CPU fallbac
 """
 from .speaker import Speaker, load_model, load_model_pt  # noqa: F401
 from .plda import TwoCovPLDA, score_plda  # noqa: F401
-from .engine import Frontend, NativeSpeakerModel  # noqa: F401
+from .engine import Frontend, NativeSpeakerModel, SpeakerModelLanes  # noqa: F401
 from . import score  # noqa: F401  (bin/score.py + bin/score_norm.py on the GPU)
 
 __version__ = "0.1.0"
