@@ -1367,6 +1367,29 @@ def test_driver_batches_similar_lengths_through_the_ragged_path(tmp_path):
     assert _cos_err(emb, ref).max() < COS_TOL and _rel_err(emb, ref).max() < 5e-4
 
 
+def test_driver_with_two_lanes_equals_one_engine(tmp_path):
+    """GpuExtractor over a SpeakerModelLanes: staging slot i = lane i (own engine + stream), so upload, forward and
+    download of consecutive batches overlap.  Same batches, same kernels: the rows are the one-engine driver's bits,
+    in list order -- uniform files (ws_extract) and all-different lengths (ragged batches)."""
+    from wespeaker_amd import SpeakerModelLanes, extract as wx
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    lines = {"uniform": [], "varied": []}
+    for i in range(45):
+        for tag, n in (("uniform", 32000), ("varied", 24000 + 353 * i)):
+            p = str(tmp_path / ("%s%02d.wav" % (tag[0], i)))
+            synth.write_wav(p, synth.synth_wav(300 + i, n))
+            lines[tag].append("utt%02d %s" % (i, p))
+    fe = Frontend(16000, 80)
+    one = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, max_batch=8, max_frames=250)
+    two = SpeakerModelLanes("ECAPA_TDNN_GLOB_c512", sd, lanes=2, max_batch=8, max_frames=250)
+    for tag in ("uniform", "varied"):
+        k1, e1 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(one, fe), batch_size=1, max_batch=8, num_workers=2)
+        k2, e2 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(two, fe), batch_size=1, max_batch=8, num_workers=2)
+        assert k1 == k2 == ["utt%02d" % i for i in range(45)]
+        assert np.array_equal(e1, e2), tag
+
+
 # ------------------------------------------------------------------------------------------ dispatch tables
 def _dispatch_cases():
     import sys

@@ -46,10 +46,14 @@ def main():
         rec = {"model": args.model, "files": args.n, "decode_threads": args.workers, "max_batch": args.max_batch,
                "loader": "python threads" if args.python_loader else "native (ws_wav_load_rows)",
                "host_cores": os.cpu_count()}
-        for prec in ("fp32", "f16"):
-            model.set_precision(prec)
+        from wespeaker_amd import SpeakerModelLanes
+        lanes2 = SpeakerModelLanes(args.model, synth.synth_state_dict(args.model, 80, E, seed=42), lanes=2, feat_dim=80,
+                                   embed_dim=E, device=dev, max_batch=args.max_batch, max_frames=250)
+        for prec in ("fp32", "fp32_2lanes", "f16"):
+            if prec != "fp32_2lanes":
+                model.set_precision(prec)
             for tag, lines in lists.items():
-                ex = wx.GpuExtractor(model, fe)
+                ex = wx.GpuExtractor(lanes2 if prec == "fp32_2lanes" else model, fe)
                 run = (lambda ls: wx.extract_entries(wx.iter_entries("scp", ls), ex, batch_size=1,
                                                      max_batch=args.max_batch, num_workers=args.workers)) \
                     if args.python_loader else \

@@ -151,9 +151,19 @@ class GpuExtractor:
     staging buffers, a copy stream for H2D and non-blocking D2H: batch i+1 uploads while batch i computes."""
 
     def __init__(self, model, frontend, window_type="hamming", depth=2):
+        """model: a NativeSpeakerModel, or a SpeakerModelLanes -- then staging slot i belongs to lane i (its own
+        engine and HIP stream: upload, forward and download of batch i + 1 are enqueued while batch i computes, and
+        the two forwards share the GPU, engine.SpeakerModelLanes)."""
         self.model, self.frontend, self.window_type = model, frontend, window_type
         self.device = model.device
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        engines = getattr(model, "engines", None)
+        if engines is not None and len(engines) > 1:
+            depth = len(engines)
+            self._engines, self._streams = list(engines), list(model.streams)
+        else:
+            eng = engines[0] if engines else model
+            self._engines, self._streams = [eng] * depth, [None] * depth
         self.depth = depth
         self._slots = [dict(pin=None, dev=None, out=None, handle=None, free=None) for _ in range(depth)]
         self._turn = 0
@@ -169,7 +179,9 @@ class GpuExtractor:
     def submit(self, utts, files=None):
         """Enqueue one batch (a list of 1-D waveforms, or a stacked (B, N) tensor); returns a handle whose
         .result() is the (B, E) numpy array.  Different lengths -> one padded ragged batch."""
-        slot = self._slots[self._turn % self.depth]
+        lane = self._turn % self.depth
+        slot = self._slots[lane]
+        engine = self._engines[lane]
         self._turn += 1
         if files is not None:
             lens = [int(c) for c in files[1]]
@@ -187,7 +199,7 @@ class GpuExtractor:
         nbytes = B * N * (2 if dtype == torch.int16 else 4)   # 8- / 32-bit files arrive as int16-range floats
         if slot["free"] is not None:
             slot["free"].synchronize()                       # the forward that read this slot has finished
-        main = torch.cuda.current_stream(self.device)
+        main = self._streams[lane] or torch.cuda.current_stream(self.device)
         if slot["pin"] is None or slot["pin"].numel() < nbytes:
             slot["pin"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
             # The device staging buffer is written by the COPY stream: it must come from that stream's
@@ -210,12 +222,6 @@ class GpuExtractor:
             uploaded.record(self.copy_stream)
         main.wait_event(uploaded)
         dev.record_stream(main)
-        if ragged:
-            emb = self.model.extract_ragged(self.frontend, dev, lens, window_type=self.window_type)
-        else:
-            emb = self.model.extract(self.frontend, dev, window_type=self.window_type)
-        slot["free"] = torch.cuda.Event()
-        slot["free"].record(main)
         # pinned result buffer of the slot (pin_memory() costs ~10 ms per call: never per batch).  The previous
         # batch of this slot may not have been collected yet: materialise it before its buffer is reused.
         if slot["handle"] is not None:
@@ -223,14 +229,22 @@ class GpuExtractor:
         if slot["out"] is None or slot["out"].shape[0] < B:
             slot["out"] = torch.empty((max(B, 256), self.embed_dim), dtype=torch.float32).pin_memory()
         out = slot["out"][:B]
-        out.copy_(emb, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(main)
+        with torch.cuda.stream(main):
+            if ragged:
+                emb = engine.extract_ragged(self.frontend, dev, lens, window_type=self.window_type)
+            else:
+                emb = engine.extract(self.frontend, dev, window_type=self.window_type)
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(main)
+            out.copy_(emb, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(main)
         slot["handle"] = _Pending(out, done)
         return slot["handle"]
 
     def finish(self):
-        torch.cuda.current_stream(self.device).synchronize()
+        for st in self._streams:
+            (st or torch.cuda.current_stream(self.device)).synchronize()
         self.model.check_range()
 
 
@@ -510,9 +524,10 @@ def chunk_samples(num_frms, resample_rate, frame_shift=10, frame_length=25):
     return ((num_frms - 1) * frame_shift + frame_length) * resample_rate // 1000
 
 
-def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_frames=400, precision="fp32"):
-    """get_speaker_model(...)(**model_args) + load_checkpoint (bin/extract.py:66-77) on the native engine."""
-    from .engine import Frontend, NativeSpeakerModel
+def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_frames=400, precision="fp32", lanes=0):
+    """get_speaker_model(...)(**model_args) + load_checkpoint (bin/extract.py:66-77) on the native engine.
+    lanes: batches in flight on the GPU (engine.SpeakerModelLanes); 0 = two for the fp32 back-end, else one."""
+    from .engine import Frontend, NativeSpeakerModel, SpeakerModelLanes
     from .speaker import _load_state_dict
     fc = check_frontend_config(configs)
     margs = dict(configs.get("model_args") or {})
@@ -520,8 +535,14 @@ def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_fra
     feat_dim = int(margs.pop("feat_dim", fc["num_mel_bins"]))
     embed_dim = margs.pop("embed_dim", None)
     sd = _load_state_dict(model_path)
-    model = NativeSpeakerModel(configs["model"], sd, feat_dim=feat_dim, embed_dim=embed_dim, device=device,
-                               max_batch=max_batch, max_frames=max_frames)
+    if lanes <= 0:
+        lanes = 2 if precision == "fp32" else 1
+    if lanes > 1:
+        model = SpeakerModelLanes(configs["model"], sd, lanes=lanes, feat_dim=feat_dim, embed_dim=embed_dim,
+                                  device=device, max_batch=max_batch, max_frames=max_frames)
+    else:
+        model = NativeSpeakerModel(configs["model"], sd, feat_dim=feat_dim, embed_dim=embed_dim, device=device,
+                                   max_batch=max_batch, max_frames=max_frames)
     model.set_precision(precision)
     fe = Frontend(fc["resample_rate"], feat_dim, device=model.device)
     return GpuExtractor(model, fe), fc
@@ -657,6 +678,8 @@ def main(argv=None):
     ap.add_argument("--nj", type=int, default=0, help="number of sub-lists (default: the number of ranks)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "f16"])
     ap.add_argument("--max_batch", type=int, default=256)
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="batches in flight on the GPU (one engine + stream each); 0 = 2 for fp32, 1 otherwise")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpus", default=None, help="accepted for compatibility; ranks map to LOCAL_RANK")
     ap.add_argument("--gather_npz", default=None,
@@ -673,7 +696,7 @@ def main(argv=None):
 
     def make():
         ex, _ = build_gpu_extractor(configs, args.model_path, device=device, max_batch=args.max_batch,
-                                    precision=args.precision)
+                                    precision=args.precision, lanes=args.lanes)
         return ex
 
     out = run_jobs(read_lists(args.data_list), args.data_type, embed_dir, make, args.nj or world, rank, world,
