@@ -89,7 +89,10 @@ def kernel_text(model_name, prec):
     if prec == "fp32":
         return ("gemm_f32_stream_kernel (persistent: one workgroup of eight 64x64 wavefronts per CU walks whole rounds "
                 "of 256x128 tiles, operands by LDS-DMA into a 3-stage ring of 48-KB K-tiles, v_mfma_f32_32x32x2_f32, "
-                "exact fp32 products: the plain 1x1 layers) + conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> "
+                "exact fp32 products: the plain 1x1 layers, and ECAPA's k5 layer as an im2col GEMM) + "
+                + ("astp_fused_kernel (attention linear1 -> tanh -> linear2 -> softmax pooling, one workgroup per "
+                   "utterance, v_mfma_f32_16x16x4_f32) + " if ecapa else "")
+                + "conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> "
                 "(everything else and the remaining rows): every conv/linear with N > 64")
     if prec == "f16x3":
         return ("conv_gemm_dual_kernel<..,PREC=1> / conv_gemm_kernel<128,128,2,2,..,PREC=1> (3 x "

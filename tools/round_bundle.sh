@@ -22,12 +22,15 @@ done
 python bench.py --workload vox1o --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
 python bench.py --workload vox1o --model ResNet221 --steps 2 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
 python bench.py --workload stream10k --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
+# end to end from wave files in /dev/shm through the batch driver (one engine, two lanes, f16)
+timeout 600 python tools/bench_driver.py 2> /dev/null | tail -1 > "$OUT/${TAG}_driver.jsonl"; cut -c1-300 "$OUT/${TAG}_driver.jsonl"
 cd /tmp && export TMPDIR=/tmp
 # kernel tables: one headline-only run per back-end / family, so every table describes ONE workload
 prof() {  # name, bench args...
   local name=$1; shift
   rm -rf "$OUT/prof_$name"
-  local base="--headline-only --steps 20 --windows 1"
+  # --lanes 1: every launch behind the previous one, so that a kernel's begin -> end in the table is its own duration
+  local base="--headline-only --steps 20 --windows 1 --lanes 1"
   [ "$name" = plda ] && base=""
   rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o p -- python "$REPO/bench.py" $base "$@" > "$OUT/prof_$name.log" 2>&1
   python "$REPO/tools/rocprof_summary.py" "$(ls $OUT/prof_$name/*.db 2>/dev/null | head -1)" > "$OUT/${TAG}_kernel_stats_$name.md" 2>/dev/null
@@ -35,6 +38,7 @@ prof() {  # name, bench args...
   rm -rf "$OUT/prof_$name"            # the .db files are tens of MB: gpurun_out/ only travels back under 64 MiB
 }
 prof fp32 --precision fp32
+prof fp32_2lanes --precision fp32 --lanes 2      # the headline mode: two batches in flight (+ its one-lane windows)
 prof plda --plda-only --no-cpu-baseline
 prof f16 --precision f16
 prof f16x3 --precision f16x3
@@ -50,13 +54,13 @@ pmc() {  # prec, needle, [model]
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     rm -rf "$OUT/pmc_${prec}_$i"
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${prec}_$i" -- python "$REPO/bench.py" --model $model --precision $prec --steps 3 --warmup 1 --windows 1 --headline-only > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${prec}_$i" -- python "$REPO/bench.py" --model $model --precision $prec --steps 3 --warmup 1 --windows 1 --headline-only --lanes 1 > /dev/null 2>&1
   done
   python "$REPO/tools/pmc_traffic.py" $prec "$needle" "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3" > "$OUT/${TAG}_pmc_dominant_kernel_$prec$tag.json"
   grep -E "traffic_bytes_per_launch|mfma_busy|\"traffic_bytes\"" "$OUT/${TAG}_pmc_dominant_kernel_$prec$tag.json"
   rm -rf "$OUT/pmc_${prec}_1" "$OUT/pmc_${prec}_2" "$OUT/pmc_${prec}_3"
 }
-pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
+pmc fp32 "gemm_f32_stream_kernel|astp_fused_kernel|conv_gemm_dual_kernel|conv_gemm_kernel<128, 128, 2, 2|conv_gemm_kernel<64, 64, 2, 2"
 pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64, 64"
 # the 2-D families: whole-forward HBM bytes tell whether their MFMA fraction is the binding limit at all
 pmc f16 "gemm_f16_dma_kernel|gemm_f16_p8_kernel|conv3x3_direct_f16_kernel" ResNet221
