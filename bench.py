@@ -419,13 +419,23 @@ def main(argv=None):
         T = fe.num_frames(num_samples)
 
     # ======================================================================= fixed-size set (strong scaling)
-    def run_set(model_name, embed_dim, n_utts, n_trials, prec, steps, warmup, per_batch, per_chunk, model=None):
+    def run_set(model_name, embed_dim, n_utts, n_trials, prec, steps, warmup, per_batch, per_chunk, model=None,
+                lanes_obj=None):
         """U utterances cut into contiguous shards (parallel.shard_range), every rank walks its shard in batches,
         one all_gather, rank 0 scores `n_trials` (PLDA LLR + cosine).  One step = the whole set."""
         lo, hi = parallel.shard_range(n_utts, rank, world)
         n_local = hi - lo
         m = model or make_model(model_name, embed_dim, min(per_chunk, max(1, n_local)), T)
         m.set_precision(prec)
+        # the batches of a shard alternate between the lanes (fp32 back-end), like the steps of the default mode
+        set_lanes = lanes_obj if (prec == "fp32" and n_local > per_batch) else None
+        if set_lanes is not None:
+            set_lanes.set_precision("fp32")
+        elif not STUB and prec == "fp32" and max(1, args.lanes) > 1 and n_local > per_batch:
+            from wespeaker_amd import SpeakerModelLanes
+            set_lanes = SpeakerModelLanes(model_name, synth.synth_state_dict(model_name, 80, embed_dim, seed=42),
+                                          lanes=args.lanes, feat_dim=80, embed_dim=embed_dim, device=device,
+                                          max_batch=min(per_chunk, max(1, n_local)), max_frames=T)
         if STUB:
             g = torch.Generator().manual_seed(99)
             allw = (3000.0 * torch.randn(n_utts, num_samples, generator=g)).round().to(torch.int16)
@@ -449,7 +459,12 @@ def main(argv=None):
                 return llr, cos
 
         def one_pass():
-            outs = [m.extract(fe, wav[b0:min(n_local, b0 + per_batch)]) for b0 in range(0, n_local, per_batch)]
+            if set_lanes is not None:
+                pend = [set_lanes.extract(fe, wav[b0:min(n_local, b0 + per_batch)])
+                        for b0 in range(0, n_local, per_batch)]
+                outs = [p_.wait() for p_ in pend]
+            else:
+                outs = [m.extract(fe, wav[b0:min(n_local, b0 + per_batch)]) for b0 in range(0, n_local, per_batch)]
             local = torch.cat(outs, 0) if outs else torch.zeros((0, embed_dim), dtype=torch.float32, device=device)
             emb = parallel.gather_rows(local, n_utts)
             sc = scorer(emb) if scorer is not None else None
@@ -468,7 +483,8 @@ def main(argv=None):
                "value": n_utts * steps / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3,
                "steps": steps, "shard": "rank r of %d takes utterances [r*ceil(U/G), (r+1)*ceil(U/G)) "
                                          "(parallel.shard_range = tools/extract_embedding.sh's split rule)" % world,
-               "per_rank_utts": parallel.shard_size(n_utts, world), "batch": per_batch}
+               "per_rank_utts": parallel.shard_size(n_utts, world), "batch": per_batch,
+               "batches_in_flight": set_lanes.lanes if set_lanes is not None else 1}
         if sc is not None:
             res["trials_per_s_inside_the_step"] = n_trials * steps / dt
             res["scores_finite"] = bool(torch.isfinite(sc[0]).all()) and bool(torch.isfinite(sc[1]).all())
@@ -711,7 +727,13 @@ def main(argv=None):
             cfam = cname[:5]
             cE = EMBED_DIM.get(cfam, 256)
             cb, cc = DEFAULT_BATCH.get(cname, DEFAULT_BATCH.get(cfam, (256, 256)))
-            cm = make_model(cname, cE, cc, T)
+            cl = None
+            if n_lanes > 1:
+                cl = SpeakerModelLanes(cname, synth.synth_state_dict(cname, 80, cE, seed=42), lanes=n_lanes,
+                                       feat_dim=80, embed_dim=cE, device=device, max_batch=cc, max_frames=T)
+                cm = cl.engines[0]
+            else:
+                cm = make_model(cname, cE, cc, T)
             cw = wav if cb == batch else device_wavs(cb, num_samples, device, seed_base=77)
             leg = {"model": cname, "batch": cb, "unit": "embeddings/s"}
             for prec in ("fp32", "f16"):
@@ -733,12 +755,30 @@ def main(argv=None):
                 ach = pr["flops"] / (pr["ms"] * 1e-3) / 1e12 if pr["ms"] > 0 else 0.0
                 whole = cm.flops(1, T) * cb * ks / cdt / 1e12
                 leg[prec] = {"value": cb * ks / cdt, "ms_per_step": cdt / ks * 1e3, "steps": ks,
+                             "batches_in_flight": 1,
                              "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                           "frac": ach / peak, "kernel": "dominant class (every conv/linear with "
                                           "N > 64), HIP events inside this window",
                                           "whole_step_frac_of_peak": whole / peak}}
+                if prec == "fp32" and cl is not None:
+                    # the headline's mode: n_lanes batches in flight (the roofline above stays the one-lane window's)
+                    cl.set_precision("fp32")
+                    for _ in range(2 * n_lanes):
+                        cl.extract(fe, cw)
+                    sync()
+                    tb = time.perf_counter()
+                    for _ in range(ks * n_lanes):
+                        cl.extract(fe, cw)
+                    sync()
+                    cdt2 = time.perf_counter() - tb
+                    leg[prec]["value_one_batch_in_flight"] = leg[prec]["value"]
+                    leg[prec]["value"] = cb * ks * n_lanes / cdt2
+                    leg[prec]["ms_per_step"] = cdt2 / (ks * n_lanes) * 1e3
+                    leg[prec]["batches_in_flight"] = n_lanes
+                    leg[prec]["roofline"]["whole_step_frac_of_peak"] = \
+                        cm.flops(1, T) * cb * ks * n_lanes / cdt2 / 1e12 / FP32_MFMA_PEAK_TFLOPS
             configs[cname] = leg
-            keep[cname] = cm
+            keep[cname] = (cm, cl)
         # configs 2 / 3 as fixed-size sets on this one GPU (N > 1: `bench.py --gpus N --workload vox1o|stream10k`)
         sets = {}
         for wl, mname in (("vox1o", "ResNet34"), ("vox1o", "ResNet221"), ("stream10k", "CAMPPlus")):
@@ -746,7 +786,7 @@ def main(argv=None):
             cfam = mname[:5]
             cb, cc = DEFAULT_BATCH.get(mname, DEFAULT_BATCH.get(cfam, (256, 256)))
             r, _ = run_set(mname, EMBED_DIM.get(cfam, 256), u, tr, "fp32", 1 if mname == "ResNet221" else 2, 1,
-                           cb, cc, model=keep[mname])
+                           cb, cc, model=keep[mname][0], lanes_obj=keep[mname][1])
             sets["%s_%s" % (wl, mname)] = r
         configs["fixed_size_sets_n1_fp32"] = sets
         del keep
