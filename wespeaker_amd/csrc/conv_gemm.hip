@@ -1888,8 +1888,22 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
         if (e != hipSuccess || p.m_begin + srows >= p.M) return e;
         ConvGemmParams rest = p;
         rest.m_begin = p.m_begin + srows;
-        return launch_prec<PREC>(rest, stream);
+        rest.colsumsq = nullptr;                  // (the tile kernels leave column sums only)
+        e = launch_prec<PREC>(rest, stream);
+        if (e == hipSuccess && p.colsumsq)
+          e = launch_colsumsq_rows(p.D, p.ldd, p.d_off, rest.m_begin, p.M, p.Hout * p.Wout, p.N, p.colsumsq, stream);
+        return e;
       }
+    }
+    if (p.colsumsq) {
+      // sums of squares of a layer that the persistent kernel does not take: the tile kernels as usual, then one pass
+      // over the stored rows
+      ConvGemmParams q = p;
+      q.colsumsq = nullptr;
+      hipError_t e = launch_prec<PREC>(q, stream);
+      if (e == hipSuccess)
+        e = launch_colsumsq_rows(p.D, p.ldd, p.d_off, p.m_begin, p.M, p.Hout * p.Wout, p.N, p.colsumsq, stream);
+      return e;
     }
   }
   // f16 back-end, plain 1x1 layer: the K-tile-64 kernels (binary16 activations when the producer left
@@ -2067,6 +2081,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     if (direct && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
     return launch_prec<2>(p, stream);
   }
+  if (p.colsumsq && (!p.colsum || !p.D)) return hipErrorInvalidValue;
   return launch_prec<0>(p, stream);
 }
 

@@ -26,7 +26,7 @@ struct EcapaModel : ModelBase {
   size_t se_w1[3], se_b1[3], se_w2[3], se_b2[3];
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
-        *pooled = nullptr, *partial = nullptr, *colsum = nullptr;
+        *pooled = nullptr, *partial = nullptr, *colsum = nullptr, *colsumsq = nullptr;
   uint16_t *h16 = nullptr, *cat16 = nullptr, *out1_16 = nullptr, *att16 = nullptr, *y2_16 = nullptr, *y3_16 = nullptr, *col16 = nullptr;
   static constexpr int kSplitK = 16;
 
@@ -114,13 +114,14 @@ struct EcapaModel : ModelBase {
            o_bias = take((size_t)maxB * 128), o_pool = take((size_t)maxB * 3072),
            o_part = take((size_t)kSplitK * maxB * (embed_dim > 128 ? embed_dim : 128)),
            o_h16 = take((M * (size_t)(1536 + 3 * C + C + 128 + C + C + 512) + 1) / 2),   // binary16 copies (f16 back-end)
-           o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)), o_feats = take(M * feat_dim);
+           o_colsum = take(((M + 63) / 64 + 2) * 2 * (C > 1536 ? C : 1536)),
+           o_colsumsq = take(((M + 63) / 64 + 2) * 2 * 1536), o_feats = take(M * feat_dim);
     if ((err = alloc_workspace(total))) return err;
     float* base = ws.as<float>();
     out1 = base + o_out1; y1 = base + o_y1; y2 = base + o_y2; y3 = base + o_y3; cat = base + o_cat;
     h = base + o_h; att = base + o_att; e = base + o_e; se_s = base + o_s; stats = base + o_stats;
     bias_img = base + o_bias; pooled = base + o_pool; partial = base + o_part;
-    colsum = base + o_colsum; feats_ws = base + o_feats;
+    colsum = base + o_colsum; colsumsq = base + o_colsumsq; feats_ws = base + o_feats;
     h16 = reinterpret_cast<uint16_t*>(base + o_h16);
     cat16 = h16 + M * 1536; out1_16 = cat16 + M * 3 * C; att16 = out1_16 + M * C; y2_16 = att16 + M * 128; y3_16 = y2_16 + M * C; col16 = y3_16 + M * C;
     return 0;
@@ -238,11 +239,16 @@ struct EcapaModel : ModelBase {
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
     // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
     const bool stats_from_colsum = glob && T >= 64;
+    static const bool no_sums = getenv("WS_NO_STD_FROM_SUMS") != nullptr;
+    const bool stats_from_sums = stats_from_colsum && gemm_precision == 0 && !L0 && !no_sums;
     static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
     const bool h_half = allf16 && !no_fuse;
     {
       ConvGemmParams pc = conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU);
       if (stats_from_colsum) pc.colsum = colsum;
+      // fp32, full batches: the epilogue also leaves the column sums of SQUARES, and the context std needs no pass
+      // over h (311 MB at 256 x 2 s) any more
+      if (stats_from_sums) pc.colsumsq = colsumsq;
       if (f16io) { pc.A16 = cat16; pc.lda16 = 3 * C; pc.D16 = h16; pc.ldd16 = 1536; }
       if (h_half) pc.D = nullptr;              // h exists as binary16 only
       pc.row_len = L0;
@@ -257,6 +263,7 @@ struct EcapaModel : ModelBase {
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
         if (stats_from_colsum && h_half)
           return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st, L0);
+        if (stats_from_sums) return launch_astp_std_from_sums(colsum, colsumsq, B, T, 1536, stats, st);
         if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st, L0);
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st, L0);
       }));

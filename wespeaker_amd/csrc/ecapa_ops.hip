@@ -378,6 +378,76 @@ __global__ __launch_bounds__(256) void astp_std_from_colsum_kernel(
   }
 }
 
+// Column sums of squares of rows [m_begin, M) of D, in the layout of ConvGemmParams::colsum ([64-row tile][image
+// part][N]): the rows of a layer that the persistent GEMM did not take (its epilogue sums the squares of its own
+// rows).  One workgroup per (64-row tile, 256 columns); thread = 4 columns x 16 row slots.
+__global__ __launch_bounds__(256) void colsumsq_rows_kernel(const float* __restrict__ D, int ldd, int d_off,
+                                                            int m_begin, int M, int HW, int N,
+                                                            float* __restrict__ colsumsq) {
+  __shared__ f32x4 red[2][4][64];
+  const int t64 = m_begin / 64 + blockIdx.x;
+  const int m0 = t64 * 64;
+  const int lane = threadIdx.x & 63, rs = threadIdx.x >> 6;             // 4 row slots of 16 rows
+  const int n = blockIdx.y * 256 + lane * 4;
+  const int rb = (m0 / HW + 1) * HW - m0;                                // rows of the tile in its first image
+  f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+  if (n < N) {
+#pragma unroll 4
+    for (int r = rs * 16; r < rs * 16 + 16; ++r) {
+      const int m = m0 + r;
+      if (m < M) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(D + (long long)m * ldd + d_off + n);
+        if (r < rb) q0 += v * v; else q1 += v * v;
+      }
+    }
+  }
+  red[0][rs][lane] = q0;
+  red[1][rs][lane] = q1;
+  __syncthreads();
+  if (rs < 2 && n < N) {
+    const f32x4 s = (red[rs][0][lane] + red[rs][1][lane]) + (red[rs][2][lane] + red[rs][3][lane]);
+    *reinterpret_cast<f32x4*>(colsumsq + ((long long)t64 * 2 + rs) * N + n) = s;
+  }
+}
+
+hipError_t launch_colsumsq_rows(const float* D, int ldd, int d_off, int m_begin, int M, int HW, int N,
+                                float* colsumsq, hipStream_t stream) {
+  if (m_begin >= M) return hipSuccess;
+  if ((m_begin & 63) || (N & 3) || (ldd & 3) || (d_off & 3) || HW < 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colsumsq_rows_kernel, dim3((M - m_begin + 63) / 64, (N + 255) / 256), dim3(256), 0, stream, D, ldd,
+                     d_off, m_begin, M, HW, N, colsumsq);
+  return hipGetLastError();
+}
+
+// ASTP global context from the GEMM epilogue's column sums AND sums of squares: mean = S1 / T,
+// std = sqrt((S2 - T mean^2) / (T - 1) + 1e-7) (pooling_layers.py:128-133, unbiased).  No pass over h at all.
+__global__ __launch_bounds__(256) void astp_std_from_sums_kernel(const float* __restrict__ colsum,
+                                                                 const float* __restrict__ colsumsq, int T, int C,
+                                                                 float* __restrict__ stats) {
+  const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)b * T, r1 = r0 + T - 1;
+  const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
+  float s1 = 0.f, s2 = 0.f;
+  for (int tm = t_first; tm <= t_last; ++tm) {
+    const int which = ((int)(((long long)tm * 64) / T) == b) ? 0 : 1;
+    s1 += colsum[((long long)tm * 2 + which) * C + c];
+    s2 += colsumsq[((long long)tm * 2 + which) * C + c];
+  }
+  const float mean = s1 / (float)T;
+  const float var = fmaxf(s2 - (float)T * mean * mean, 0.f) / (float)(T - 1);
+  stats[(long long)b * 2 * C + c] = mean;
+  stats[(long long)b * 2 * C + C + c] = sqrtf(var + 1e-7f);
+}
+
+hipError_t launch_astp_std_from_sums(const float* colsum, const float* colsumsq, int B, int T, int C, float* stats,
+                                     hipStream_t stream) {
+  if (T < 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(astp_std_from_sums_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, colsum, colsumsq, T, C,
+                     stats);
+  return hipGetLastError();
+}
+
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
                                        const float* colsum, float* stats, hipStream_t stream, const int* lens) {
   if ((C & 255) || T < 64) return hipErrorInvalidValue;

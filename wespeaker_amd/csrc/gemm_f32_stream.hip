@@ -94,7 +94,7 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // lives in the stage that the tile's last K-tile has just left, inside the slice that the SAME wavefront's next
 // DMA pieces will overwrite (nobody else touches it in between), and (b) the bias / scale / shift values are not
 // kept for all N columns: every wavefront DMAs the 3 x 64 values of ITS columns at the start of each tile.
-template <int WM, int TN, bool COLSUM>
+template <int WM, int TN, int COLSUM>       // COLSUM: 0 none, 1 column sums, 2 column sums + sums of squares
 __global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
   constexpr int WN = 4 / TN;                 // wavefront columns
@@ -118,7 +118,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // issued behind the pieces this barrier needs (vmcnt retires in order): 4 row stores per 32x32 block (more with
   // D2: then the wait is a little early, never late) and the column sums
   constexpr int WAITN = NP;
-  constexpr int WAITN_FIRST = NP + 3 + 2 * TN * 4 + (COLSUM ? 2 * TN : 0);
+  constexpr int WAITN_FIRST = NP + 3 + 2 * TN * 4 + COLSUM * 2 * TN;
   // DEFER (16-MFMA k-groups only: enough free gaps): the last block of a tile has no MFMAs of its own tile left to
   // hide behind, and the two wavefronts of a SIMD reach that point together -- ~1200 (plain) to ~3500 (column sums)
   // idle cycles per tile.  Its accumulators go through the scratch into registers at once (the scratch is about to
@@ -126,7 +126,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // the NEXT tile's first K-tile.  Those stores are issued behind that K-tile's DMA pieces, so the K-tile after it
   // lets them stay in flight too (WAITN_SECOND).
   constexpr bool DEFER = GM == 16;
-  constexpr int WAITN_SECOND = DEFER ? NP + 4 + (COLSUM ? 2 * TN : 0) : NP;
+  constexpr int WAITN_SECOND = DEFER ? NP + 4 + COLSUM * 2 * TN : NP;
   static_assert(WAITN_FIRST < 64, "vmcnt is six bits");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
@@ -285,8 +285,11 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     t.t64 = mh >> 6;
   };
   f32x4 cs[TN][2];                           // column sums of the stored values: [block column][image part]
+  f32x4 cq[COLSUM == 2 ? TN : 1][2];         // ... and of their squares (the context std of the pooling layer)
 #pragma unroll
   for (int in = 0; in < TN; ++in) cs[in][0] = cs[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
 
   // One block's epilogue in 15 steps (each small enough for the shadow of one MFMA).  im / in: the block,
@@ -330,6 +333,11 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         const float f0 = im * 32 + r8 + 8 * i < t.rb ? 1.f : 0.f, f1 = 1.f - f0;
         cs[in][0] += ev[i] * f0;
         cs[in][1] += ev[i] * f1;
+        if (COLSUM == 2) {
+          const f32x4 sq = ev[i] * ev[i];
+          cq[in][0] += sq * f0;
+          cq[in][1] += sq * f1;
+        }
       }
     }
   };
@@ -347,6 +355,10 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
           for (int e = 0; e < 4; ++e) {
             const float f = cs[in][w][e];
             cs[in][w][e] = f + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, __float_as_int(f)));
+            if (COLSUM == 2) {
+              const float g = cq[in][w][e];
+              cq[in][w][e] = g + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, __float_as_int(g)));
+            }
           }
     } else {
       if (r8 == 0) {
@@ -355,9 +367,18 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
           for (int w = 0; w < 2; ++w)
             *reinterpret_cast<f32x4*>(p.colsum + ((size_t)t.t64 * 2 + w) * p.N + t.ncol + in * 32) = cs[in][w];
+        if (COLSUM == 2) {
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+              *reinterpret_cast<f32x4*>(p.colsumsq + ((size_t)t.t64 * 2 + w) * p.N + t.ncol + in * 32) = cq[in][w];
+        }
       }
 #pragma unroll
       for (int in = 0; in < TN; ++in) cs[in][0] = cs[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
   // the epilogue of a tile's LAST block behind its scratch round trip (ev[] holds its rows): d = 0 channel vectors,
@@ -558,7 +579,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WM, int TN, bool COLSUM>
+template <int WM, int TN, int COLSUM>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
   constexpr int NW = WM * (4 / TN), NP = (8 * WM + 16) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
@@ -669,9 +690,13 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
     snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx128 tile, %d waves> tiles=%d", bm, mode == 1 ? 4 : 8, p.n_big);
     dispatch_log_note(p, k);
   }
-  if (mode == 1) return p.colsum ? launch_stream<2, 2, true>(p, grid, stream) : launch_stream<2, 2, false>(p, grid, stream);
-  if (mode == 2) return p.colsum ? launch_stream<2, 1, true>(p, grid, stream) : launch_stream<2, 1, false>(p, grid, stream);
-  return p.colsum ? launch_stream<4, 2, true>(p, grid, stream) : launch_stream<4, 2, false>(p, grid, stream);
+  const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);
+  if (mode == 1) return cs == 2 ? launch_stream<2, 2, 2>(p, grid, stream)
+                                : cs ? launch_stream<2, 2, 1>(p, grid, stream) : launch_stream<2, 2, 0>(p, grid, stream);
+  if (mode == 2) return cs == 2 ? launch_stream<2, 1, 2>(p, grid, stream)
+                                : cs ? launch_stream<2, 1, 1>(p, grid, stream) : launch_stream<2, 1, 0>(p, grid, stream);
+  return cs == 2 ? launch_stream<4, 2, 2>(p, grid, stream)
+                 : cs ? launch_stream<4, 2, 1>(p, grid, stream) : launch_stream<4, 2, 0>(p, grid, stream);
 }
 
 }  // namespace wsamd

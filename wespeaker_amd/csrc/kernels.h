@@ -72,6 +72,9 @@ struct ConvGemmParams {
   float* colsum;                              // optional [ceil(M/64)][2][N]: column sums of the stored
                                               // values per 64-row tile, split at the image boundary
                                               // inside the tile (needs Hout*Wout >= 64 rows per image)
+  float* colsumsq;                            // optional, only with colsum: column sums of the SQUARES of the
+                                              // stored values, same layout (fp32 back-end; the rows the persistent
+                                              // kernel does not take are summed by colsumsq_rows_kernel)
   const uint16_t* pool_h16;                   // binary16 twin of pool_h (same ldh), used instead when set
   const float* pool_h; int ldh;               // optional fused attentive-statistics pooling: the GEMM
   float* pool_partial;                        // output is the LOGIT tensor e; instead of storing it,
@@ -154,6 +157,12 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
                                        const float* colsum, float* stats, hipStream_t stream,
                                        const int* lens = nullptr);
+// the same statistics from column sums + sums of squares (ConvGemmParams::colsumsq): no pass over h
+hipError_t launch_astp_std_from_sums(const float* colsum, const float* colsumsq, int B, int T, int C, float* stats,
+                                     hipStream_t stream);
+// sums of squares of rows [m_begin, M) of a stored layer output, colsum layout (the rows the persistent GEMM left)
+hipError_t launch_colsumsq_rows(const float* D, int ldd, int d_off, int m_begin, int M, int HW, int N,
+                                float* colsumsq, hipStream_t stream);
 hipError_t launch_astp_std_from_colsum_f16(const uint16_t* h16, int ldh, int B, int T, int C,
                                            const float* colsum, float* stats, hipStream_t stream,
                                            const int* lens = nullptr);
