@@ -809,6 +809,24 @@ def test_lanes_two_batches_in_flight_same_bits():
             assert torch.equal(p.synchronize(), ref[i % 3]), (rep, i)
 
 
+def test_bench_two_ranks_with_lanes_on_one_gpu():
+    """bench.py --gpus 2 (self-launching) with two batches in flight per rank, both ranks on this one GPU
+    (WS_SHARE_GPU=1, gloo): the per-step gathers are issued under the lane's stream and joined two steps later."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WS_SHARE_GPU="1", WS_DIST_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--windows", "1", "--batch", "64", "--headline-only"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128
+    assert line["config"]["batches_in_flight_per_gpu"] == 2 and line["value"] > 0
+    assert line["roofline"]["frac"] > 0
+
+
 def test_full_size_plda_one_million_trials():
     """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""
