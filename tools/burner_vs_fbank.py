@@ -15,7 +15,8 @@ out = torch.zeros(4096 * 256, device=dev)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 for kind, name in ((0, "v_mfma_f32_32x32x2_f32"), (1, "v_mfma_f32_32x32x16_f16"), (2, "v_mfma_f32_16x16x32_f16"),
                    (3, "cvt to f16 denormals"), (4, "cvt to f16 normals"), (5, "16x16x32_f16 on denormals"),
-                   (6, "hi/lo split, denormal lo")):
+                   (6, "hi/lo split, denormal lo"), (7, "v_cvt_f32_f16_sdwa"), (8, "LDS write_b64/read_b128"),
+                   (9, "v_cvt_pk_f16_f32 + packed fp32")):
     for grid in (1024,):
         bad = 0
         for rep in range(30):

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void mfma_burner_kernel(int kind, int iters, f
   // 5: 16x16x32 f16 MFMAs fed with binary16 denormals, 6: the hi / lo split of the f16x3 back-end on values whose lo
   // parts are denormal)
   float acc = 0.f;
-  if (kind >= 3) {
+  if (kind >= 3 && kind <= 6) {
     float v = (kind == 4 ? 1.0f : 3.0e-6f) * (1.0f + threadIdx.x * 1e-3f);
     f16x8 d;
     for (int i = 0; i < 8; ++i) d[i] = (_Float16)(2.0e-7f * (i + 1));          // binary16 denormals
@@ -53,6 +53,43 @@ __global__ __launch_bounds__(256) void mfma_burner_kernel(int kind, int iters, f
         }
       }
     }
+  }
+  // kinds 7..9: 7 = v_cvt_f32_f16_sdwa (sub-dword operand select, as the binary16 kernels unpack high halves),
+  // 8 = LDS traffic of the binary16 kernels' shape (ds_write_b64 / ds_read_b128), 9 = v_cvt_pk_f16_f32 + v_pk ops
+  if (kind == 7) {
+    unsigned u = 0x3c003800u + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float f;
+        asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(u));
+        acc += f;
+        u += 0x00010000u;
+      }
+    }
+  } else if (kind == 8) {
+    __shared__ __attribute__((aligned(16))) unsigned long long buf[2048];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        buf[(threadIdx.x + 64 * r + it) & 2047] = (unsigned long long)it * 0x100010001ull + threadIdx.x;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(&buf[((threadIdx.x * 2 + 128 * r) & 2046)]);
+        acc += q[0] + q[3];
+      }
+    }
+  } else if (kind == 9) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v2 = {1.0f + threadIdx.x * 1e-3f, 0.5f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f16x2 hh = __builtin_convertvector(v2, f16x2);
+        const f32x2 back = __builtin_convertvector(hh, f32x2);
+        v2 = v2 * 0.999f + (v2 - back) * 1.5f;
+      }
+    }
+    acc += v2[0] + v2[1];
   }
   out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[3] + c0[1] + c1[2] + acc;
 }
