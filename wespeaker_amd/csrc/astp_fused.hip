@@ -361,9 +361,7 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
             const f32x2 arg = l2 * LOG2E - mlv;
             f32x2 e = {0.f, 0.f};
             (void)arg;
-#if defined(WS_EXP_NOSOFTMAX)       // timing experiment only (wrong results): how much of phase B is the VALU work?
-            e = arg;
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
             e[0] = __builtin_amdgcn_exp2f(arg[0]);
             e[1] = __builtin_amdgcn_exp2f(arg[1]);
 #endif
