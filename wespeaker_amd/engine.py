@@ -480,7 +480,7 @@ class SpeakerModelLanes:
     def set_precision(self, mode, allow_binary16=False):
         """fp32 (the parity-grade back-end) only, unless allow_binary16.  OPEN ISSUE (round 3): with a split-binary16
         (f16x3 / f16) engine running on another stream, the fbank kernel of ANY engine occasionally returns its last
-        two mel bins of a few frames a little off (tools/bin/lanes_dbg4-style runs: ~1e-3 relative in the log-mel
+        two mel bins of a few frames a little off (tools/lanes_fbank_probe.py: ~1e-3 relative in the log-mel
         value, embeddings then differ by up to 2 %); an fp32 engine next to fp32 engines gives the single engine's
         bits (tests/test_gpu_parity.py::test_lanes_two_batches_in_flight_same_bits).  No LDS or global overrun of the
         binary16 kernels was found (LDS canary next to them: clean); until the cause is known the lanes refuse the
