@@ -19,6 +19,7 @@
 // (144 VGPRs) still live in registers; the two halves read the same activation fragments.
 #include "kernels.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace wsamd {
 
@@ -180,6 +181,171 @@ __global__ __launch_bounds__(C == 32 ? 256 : 512, 2) void conv3x3_direct_f16_ker
     __syncthreads();                             // everyone is done with this stage before it is refilled
     stage ^= 1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same layers on the parity-grade fp32 back-end (round 3): 32 -> 32 channels, fp32 maps, exact fp32 products
+// (v_mfma_f32_32x32x2_f32).  As an implicit GEMM these layers ran at 0.43 of the fp32 MFMA peak (N = 32: a 128 x 32
+// tile re-stages 16 KB of activations for 16 MFMAs per wavefront and K-tile, nine times per input pixel).  Here, as in
+// the binary16 kernel: persistent workgroups over 8 x 16 output patches, the input patch with its halo copied into LDS
+// once by LDS-DMA (two stages), the nine taps formed by shifting the swizzled LDS read address, and ALL 32 x 288 weights
+// in registers -- 144 VGPRs per lane: the weights are the MFMA's A operand, lane (li, lh) holds W[li][32 tap + 8 g +
+// 4 lh + s].  Pixels are 128 B (8 chunks of 16 B, chunk index XOR (pixel >> 1) & 7); one ds_read_b128 of a pixel row
+// feeds four MFMAs (k = 8 g + 4 lh + s: the k order of the GEMM kernels).  144 MFMAs per wavefront and patch.
+// C^T accumulators: a lane owns channels 8 j + 4 lh .. + 3 (j = 0..3) of ONE pixel: four 16-B stores per lane.
+template <int SH, int SW>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGemmParams p, int pyb, int pxb,
+                                                                    int total) {
+  constexpr int C = 32, NWV = 4, PXP = 8;
+  constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
+  constexpr int RP = IH * IW;
+  constexpr int NP = (RP + PXP - 1) / PXP;       // 1-KiB pieces (8 pixels of 128 B)
+  constexpr int PPW = (NP + NWV - 1) / NWV;
+  constexpr int STAGE = NP * 1024;
+  typedef float f32x4d __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char lds_d[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  auto key = [](int q) { return (q >> 1) & 7; };
+
+  // ---- weights: lane (li, lh) keeps W[li][32 tap + 8 g + 4 lh .. + 3] for all 9 taps x 4 k-groups
+  f32x4d wf[36];
+#pragma unroll
+  for (int s = 0; s < 36; ++s)
+    wf[s] = *reinterpret_cast<const f32x4d*>(p.W + (long long)li * p.ldw + 8 * s + 4 * lh);
+
+  int d_ry[PPW], d_rx[PPW], d_c[PPW], d_slot[PPW];
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    int pi = wave * PPW + k;
+    if (pi > NP - 1) pi = NP - 1;                // surplus slots repeat the last piece
+    const int q = pi * PXP + (lane >> 3), pc = lane & 7;
+    d_ry[k] = q < RP ? q / IW : -(1 << 20);      // out of region -> predicate false
+    d_rx[k] = q - (q / IW) * IW;
+    d_c[k] = (pc ^ key(q)) * 4;                  // logical chunk (floats) stored at physical slot pc
+    d_slot[k] = pi * 1024;
+  }
+  auto issue = [&](int patch, int stage) {
+    const int pxi = patch % pxb, t = patch / pxb;
+    const int pyi = t % pyb, img = t / pyb;
+    const int iy0 = pyi * PH * SH - 1, ix0 = pxi * PW * SW - 1;
+    char* base = lds_d + stage * STAGE;
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int iy = iy0 + d_ry[k], ix = ix0 + d_rx[k];
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const float* src = ok ? p.A + (((long long)img * p.Hin + iy) * p.Win + ix) * C + d_c[k] : p.zeros;
+      dma16_direct(src, base + d_slot[k]);
+    }
+  };
+
+  // ---- compute roles: lane li -> patch pixel (row 2 wave + li / 16, col li % 16)
+  const int ppy = 2 * wave + (li >> 4), ppx = li & 15;
+  const int q0 = ppy * SH * IW + ppx * SW;       // region pixel of tap (0, 0)
+
+  int stage = 0;
+  int patch = blockIdx.x;
+  if (patch < total) issue(patch, 0);
+  for (; patch < total; patch += gridDim.x) {
+    // ONE rendezvous per patch: this patch's pieces have landed, and everybody is done with the previous patch -- its
+    // stage is free for the next patch's pieces, which then have a whole patch time to arrive
+    wait_vm_barrier<0>();
+    const int next = patch + gridDim.x;
+    if (next < total) issue(next, stage ^ 1);
+    const char* base = lds_d + stage * STAGE;
+    f32x16d acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int q = q0 + (tap / 3) * IW + (tap % 3);
+      const int kq = key(q);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = g * 2 + lh;
+        const f32x4d a = *reinterpret_cast<const f32x4d*>(base + q * 128 + ((c ^ kq) << 4));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tap * 4 + g][s], a[s], acc, 0, 0, 0);
+      }
+    }
+    // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh
+    const int pxi = patch % pxb, t = patch / pxb;
+    const int pyi = t % pyb, img = t / pyb;
+    const int oy = pyi * PH + ppy, ox = pxi * PW + ppx;
+    if (oy < p.Hout && ox < p.Wout) {
+      const long long m = ((long long)img * p.Hout + oy) * p.Wout + ox;
+      const bool padded = p.row_len && ox >= p.row_len[img];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = 8 * j + 4 * lh;
+        f32x4d v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        if (p.bias) v += *reinterpret_cast<const f32x4d*>(p.bias + ch);
+        if (p.residual) v += *reinterpret_cast<const f32x4d*>(p.residual + m * p.ldr + p.r_off + ch);
+        if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+        }
+        if (padded) v = (f32x4d){0.f, 0.f, 0.f, 0.f};     // ragged batch: columns beyond the utterance stay zero
+        *reinterpret_cast<f32x4d*>(p.D + m * p.ldd + p.d_off + ch) = v;
+      }
+    }
+    stage ^= 1;
+  }
+}
+
+bool conv3x3_direct_f32_supported(const ConvGemmParams& p) {
+  static const int off = [] { const char* e = getenv("WS_DIRECT3X3_F32"); return e && atoi(e) == 0 ? 1 : 0; }();
+  return !off && p.prec == 0 && p.A && p.D && !p.A16 && !p.D16 && !p.A2 && !p.pre_scale && p.Cin == 32 && p.N == 32 &&
+         p.K == 288 && p.kh == 3 && p.kw == 3 && p.dil_h == 1 && p.dil_w == 1 && p.pad_h == 1 && p.pad_w == 1 &&
+         p.lda == 32 && p.a_off == 0 && (p.ldd & 3) == 0 && (p.d_off & 3) == 0 && p.ldw >= p.K &&
+         p.stride_h == 1 && p.stride_w == 1 &&   // (the strided regions need more DMA-role registers than are left
+                                                 // beside the 144 weight registers: they stay on the tile kernels)
+         !p.residual16 && !p.colsum && !p.colsumsq && !p.pool_partial &&
+         !p.seg_scale && !p.post_scale && !p.bias_img && !p.D2 && p.splitk <= 1 && p.m_begin == 0 &&
+         p.act != ACT_TANH && (!p.residual || ((p.ldr & 3) == 0 && (p.r_off & 3) == 0)) &&
+         (long long)p.M * 32 >= (1 << 22);       // small maps stay on the tile kernels (persistent patches need work)
+}
+
+template <int SH, int SW>
+static hipError_t launch_direct_f32(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
+  constexpr int NP = (IH * IW + 7) / 8;
+  constexpr size_t lds = 2 * (size_t)NP * 1024;
+  static_assert(lds <= 160 * 1024, "two stages fit the LDS");
+  auto kern = conv3x3_direct_f32_kernel<SH, SW>;
+  static size_t lds_granted[WS_MAX_DEVICES] = {};
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
+    if (e != hipSuccess) return e;
+  }
+  const int images = p.M / (p.Hout * p.Wout);
+  const int pyb = (p.Hout + PH - 1) / PH, pxb = (p.Wout + PW - 1) / PW;
+  const long long total = (long long)images * pyb * pxb;
+  if (total <= 0) return hipSuccess;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  const size_t by_lds = 160 * 1024 / lds;
+  long long blocks = (long long)cus * (by_lds < 2 ? by_lds : 2);   // 144 weight VGPRs: two workgroups per CU
+  if (blocks > total) blocks = total;
+  if (dispatch_log_enabled()) {
+    char k[64];
+    snprintf(k, sizeof(k), "conv3x3_direct_f32_kernel<%d,%d>", SH, SW);
+    dispatch_log_note(p, k);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p, pyb, pxb, (int)total);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_direct_f32(const ConvGemmParams& p, hipStream_t stream) {
+  if (!conv3x3_direct_f32_supported(p)) return hipErrorInvalidValue;
+  return launch_direct_f32<1, 1>(p, stream);
 }
 
 bool conv3x3_direct_supported(const ConvGemmParams& p) {

@@ -2082,6 +2082,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     return launch_prec<2>(p, stream);
   }
   if (p.colsumsq && (!p.colsum || !p.D)) return hipErrorInvalidValue;
+  if (conv3x3_direct_f32_supported(p)) return launch_conv3x3_direct_f32(p, stream);
   return launch_prec<0>(p, stream);
 }
 

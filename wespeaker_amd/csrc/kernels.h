@@ -277,6 +277,9 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
 // -------- direct 3x3, 32 -> 32 channel convolution on binary16 maps (conv3x3_direct.hip)
 bool conv3x3_direct_supported(const ConvGemmParams& p);
 hipError_t launch_conv3x3_direct(const ConvGemmParams& p, hipStream_t stream);
+// the 32 -> 32 channel layers on the fp32 back-end (exact fp32 MFMA, weights in registers); env WS_DIRECT3X3_F32=0: off
+bool conv3x3_direct_f32_supported(const ConvGemmParams& p);
+hipError_t launch_conv3x3_direct_f32(const ConvGemmParams& p, hipStream_t stream);
 
 // -------- PLDA training statistics (plda_train.hip; two_cov_plda.py:48-66,95-107,261-275)
 int64_t plda_stats_scratch_doubles(int n, int dim);
