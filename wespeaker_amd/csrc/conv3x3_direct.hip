@@ -215,17 +215,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   for (int s = 0; s < 36; ++s)
     wf[s] = *reinterpret_cast<const f32x4d*>(p.W + (long long)li * p.ldw + 8 * s + 4 * lh);
 
-  int d_ry[PPW], d_rx[PPW], d_c[PPW], d_slot[PPW];
-#pragma unroll
-  for (int k = 0; k < PPW; ++k) {
-    int pi = wave * PPW + k;
-    if (pi > NP - 1) pi = NP - 1;                // surplus slots repeat the last piece
-    const int q = pi * PXP + (lane >> 3), pc = lane & 7;
-    d_ry[k] = q < RP ? q / IW : -(1 << 20);      // out of region -> predicate false
-    d_rx[k] = q - (q / IW) * IW;
-    d_c[k] = (pc ^ key(q)) * 4;                  // logical chunk (floats) stored at physical slot pc
-    d_slot[k] = pi * 1024;
-  }
+  // DMA roles: piece pi covers region pixels 8 pi .. 8 pi + 7, lane -> (pixel, physical chunk).  They are recomputed
+  // per patch (a dozen integer operations per piece) instead of being kept: beside 144 weight registers and the
+  // accumulators there is room for EITHER the role registers OR a second set of activation fragments, and the
+  // fragments of tap t + 1 in flight behind the MFMAs of tap t are worth more
   auto issue = [&](int patch, int stage) {
     const int pxi = patch % pxb, t = patch / pxb;
     const int pyi = t % pyb, img = t / pyb;
@@ -233,10 +226,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     char* base = lds_d + stage * STAGE;
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
-      const int iy = iy0 + d_ry[k], ix = ix0 + d_rx[k];
-      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-      const float* src = ok ? p.A + (((long long)img * p.Hin + iy) * p.Win + ix) * C + d_c[k] : p.zeros;
-      dma16_direct(src, base + d_slot[k]);
+      int pi = wave * PPW + k;
+      if (pi > NP - 1) pi = NP - 1;              // surplus slots repeat the last piece
+      const int q = pi * PXP + (lane >> 3), pc = lane & 7;
+      const int ry = q / IW, rx = q - ry * IW;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      const bool ok = q < RP && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const float* src = ok ? p.A + (((long long)img * p.Hin + iy) * p.Win + ix) * C + ((pc ^ key(q)) * 4) : p.zeros;
+      dma16_direct(src, base + pi * 1024);
     }
   };
 
@@ -257,18 +254,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     f32x16d acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // 36 steps of (tap, k-group): one ds_read_b128 = the B operands of four MFMAs; the fragment of step i + 1 is
+    // requested before the MFMAs of step i (four 64-cycle MFMAs cover the LDS round trip)
+    f32x4d fa[2];
+    auto read_step = [&](int i) {
+      const int tap = i >> 2, g = i & 3;
       const int q = q0 + (tap / 3) * IW + (tap % 3);
-      const int kq = key(q);
+      return *reinterpret_cast<const f32x4d*>(base + q * 128 + (((g * 2 + lh) ^ key(q)) << 4));
+    };
+    fa[0] = read_step(0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = g * 2 + lh;
-        const f32x4d a = *reinterpret_cast<const f32x4d*>(base + q * 128 + ((c ^ kq) << 4));
+    for (int i = 0; i < 36; ++i) {
+      if (i + 1 < 36) fa[(i + 1) & 1] = read_step(i + 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tap * 4 + g][s], a[s], acc, 0, 0, 0);
-      }
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][s], fa[i & 1][s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh
     const int pxi = patch % pxb, t = patch / pxb;
