@@ -809,6 +809,52 @@ def test_lanes_two_batches_in_flight_same_bits():
             assert torch.equal(p.synchronize(), ref[i % 3]), (rep, i)
 
 
+def test_attentive_pooling_kernel_forced_on_small_batches(tmp_path):
+    """astp_fused.hip is chosen by a cost model (a full round of one-workgroup-per-utterance work must beat the three
+    tile launches), so small test batches never reach it.  WS_ASTP_FUSED=2 forces it: uniform batches at the edges
+    of its three row-block variants (T = 64 .. 208) and ragged batches, GLOB and plain ECAPA, against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "forced.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fixtures import synth\n"
+        "from wespeaker_amd import NativeSpeakerModel\n"
+        "out = {}\n"
+        "for name in ('ECAPA_TDNN_GLOB_c512', 'ECAPA_TDNN_c512'):\n"
+        "    sd = synth.synth_state_dict(name, 80, 192, seed=42)\n"
+        "    m = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=192, max_batch=8, max_frames=208)\n"
+        "    for T in (64, 100, 112, 113, 160, 161, 198, 208):\n"
+        "        f = np.random.RandomState(T).randn(3, T, 80).astype(np.float32)\n"
+        "        out['%%s/u%%d' %% (name, T)] = m(torch.from_numpy(f))[-1].cpu().numpy()\n"
+        "    for k, lens in enumerate(([198, 150, 57, 208, 5, 203], [160, 113, 129, 75], [112, 64, 100, 97])):\n"
+        "        pad = np.full((len(lens), max(lens), 80), np.nan, dtype=np.float32)\n"
+        "        for i, L in enumerate(lens):\n"
+        "            pad[i, :L] = np.random.RandomState(100 + i).randn(L, 80).astype(np.float32)\n"
+        "        out['%%s/r%%d' %% (name, k)] = m.embed_ragged(torch.from_numpy(pad), lens).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % root)
+    env = dict(os.environ, PYTHONPATH=root, WS_ASTP_FUSED="2", WS_DISPATCH_LOG="0")
+    path = str(tmp_path / "forced.npz")
+    r = subprocess.run([sys.executable, str(script), path], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    got = np.load(path)
+    for name in ("ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512"):
+        sd = synth.synth_state_dict(name, 80, 192, seed=42)
+        for T in (64, 100, 112, 113, 160, 161, 198, 208):
+            f = np.random.RandomState(T).randn(3, T, 80).astype(np.float32)
+            ref = oecapa.ecapa_forward(sd, f).numpy()
+            assert _rel_err(got["%s/u%d" % (name, T)], ref).max() < REL_TOL, (name, T)
+        for k, lens in enumerate(([198, 150, 57, 208, 5, 203], [160, 113, 129, 75], [112, 64, 100, 97])):
+            feats = [np.random.RandomState(100 + i).randn(L, 80).astype(np.float32) for i, L in enumerate(lens)]
+            ref = _oracle_rows(lambda f: oecapa.ecapa_forward(sd, f).numpy(), feats)
+            g = got["%s/r%d" % (name, k)]
+            assert np.isfinite(g).all()
+            assert _cos_err(g, ref).max() < COS_TOL and _rel_err(g, ref).max() < REL_TOL, (name, lens)
+
+
 def test_bench_two_ranks_with_lanes_on_one_gpu():
     """bench.py --gpus 2 (self-launching) with two batches in flight per rank, both ranks on this one GPU
     (WS_SHARE_GPU=1, gloo): the per-step gathers are issued under the lane's stream and joined two steps later."""
@@ -1296,7 +1342,11 @@ RAGGED_CASES = [("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 399, 5, 201]),
                 # 160 < T <= 208: the one-kernel attentive pooling (astp_fused.hip) with per-utterance lengths,
                 # a full 208-frame window, and its shortest window
                 ("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 208, 5, 203]),
-                ("ECAPA_TDNN_c512", 192, [161, 100, 161])]
+                ("ECAPA_TDNN_c512", 192, [161, 100, 161]),
+                # ... and its 10- and 7-row-block variants (T <= 160 / <= 112), incl. the shortest window it takes
+                ("ECAPA_TDNN_GLOB_c512", 192, [160, 113, 129, 75]),
+                ("ECAPA_TDNN_c512", 192, [112, 64, 100, 97]),
+                ("ECAPA_TDNN_GLOB_c512", 192, [64, 64, 5])]
 
 
 @pytest.mark.parametrize("name,E,lens", RAGGED_CASES)

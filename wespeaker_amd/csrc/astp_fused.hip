@@ -37,19 +37,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int F_RB = 13;                       // row blocks of 16 frames
-constexpr int F_ROWS = 16 * F_RB;              // 208
-constexpr int F_WHOLE = 10;                    // T > 160: row blocks 0..9 lie inside every utterance
 constexpr int F_NH = 128;                      // bottleneck width
 constexpr int F_BK = 32;
-constexpr int F_APIECES = F_ROWS / 8;          // 26 pieces of 8 rows x 128 B
-constexpr int F_WPIECES = F_NH / 8;            // 16
-constexpr int F_PIECES = F_APIECES + F_WPIECES;   // 42
-constexpr int F_NP = 6;                        // per wavefront (8 x 6 = 48 slots, the last 6 are copies)
-constexpr int F_STAGE_BYTES = 48 * 1024;
-constexpr int F_W_BYTE0 = F_ROWS * 128;
+constexpr int F_WPIECES = F_NH / 8;            // 16 pieces of 8 rows x 128 B
 constexpr int F_NSTAGE = 3;
-constexpr int F_LDS_BYTES = F_NSTAGE * F_STAGE_BYTES;      // 144 KB; H (208 x 512 B) aliases stages 0..2
+// RB row blocks of 16 frames (13: T <= 208, 10: T <= 160, 7: T <= 112): A pieces, pieces per wavefront, stage bytes
+constexpr int f_np(int rb) { return (2 * rb + F_WPIECES + 7) / 8; }
+constexpr int f_stage_bytes(int rb) { return f_np(rb) * 8 * 1024; }
+constexpr int f_lds_bytes(int rb) { return F_NSTAGE * f_stage_bytes(rb); }   // H (16 RB x 512 B) aliases the ring
 constexpr int F_NC = 1536;                     // pooled channels
 constexpr int F_SLICES = F_NC / 16 / 8;        // 12 per wavefront
 
@@ -102,8 +97,16 @@ struct AstpFusedParams {
   int B, T;
 };
 
-template <bool RAGGED>
+template <bool RAGGED, int F_RB>
 __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParams p) {
+  constexpr int F_ROWS = 16 * F_RB;
+  constexpr int F_WHOLE = F_RB - 3;              // 16 F_WHOLE <= T: these row blocks lie inside every utterance
+  constexpr int F_APIECES = F_ROWS / 8, F_PIECES = F_APIECES + F_WPIECES;
+  constexpr int F_NP = f_np(F_RB);               // per wavefront (8 F_NP slots >= F_PIECES, the surplus are copies)
+  constexpr int F_STAGE_BYTES = f_stage_bytes(F_RB);
+  constexpr int F_W_BYTE0 = F_ROWS * 128;
+  constexpr int F_PAIRS = (F_RB + 1) / 2;        // row blocks are processed two at a time (+ a single one if odd)
+  static_assert(F_NP <= F_PAIRS, "one DMA piece behind each pair of the first half of a K-tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
 #pragma unroll
     for (int i = 0; i < F_NP; ++i) {
       int q = wave * F_NP + i;
-      q = q < F_PIECES ? q : F_PIECES - 1;          // slots 42..47: copies of the last piece (uniform vmcnt)
+      q = q < F_PIECES ? q : F_PIECES - 1;          // surplus slots: copies of the last piece (uniform vmcnt)
       const bool isw = q >= F_APIECES;
       const int row = (isw ? q - F_APIECES : q) * 8 + r8;
       const int c = c8 ^ (row & 7);
@@ -203,15 +206,21 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
               acc[b] = f_mfma(a0[s], w[s], acc[b]);
               acc[b + 1] = f_mfma(a1[s], w[s], acc[b + 1]);
               if (s == 0) {            // behind the first MFMAs of the pair: one DMA piece / the refills
-                const int piece = jj * 7 + b / 2;          // 0..13
+                const int piece = jj * F_PAIRS + b / 2;
                 if (fill && piece < F_NP) dma_piece(kt + 3, stage, piece);
               }
               if (s == 1) fA[jj][b] = *reinterpret_cast<const f32x4*>(nb + b * 2048 + offA[jj]);
               if (s == 2) fA[jj][b + 1] = *reinterpret_cast<const f32x4*>(nb + (b + 1) * 2048 + offA[jj]);
+              // the W1 fragment of this half is free behind the last pair's last MFMAs (even block counts)
+              if (s == 3 && b + 2 >= F_RB) fB[jj] = *reinterpret_cast<const f32x4*>(nb + offW + offA[jj]);
             }
           } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[b] = f_mfma(a0[s], w[s], acc[b]);
+            {
+              const int piece = jj * F_PAIRS + b / 2;     // (7 row blocks: the fourth piece belongs to the single block)
+              if (fill && piece < F_NP) dma_piece(kt + 3, stage, piece);
+            }
             fA[jj][b] = *reinterpret_cast<const f32x4*>(nb + b * 2048 + offA[jj]);
             fB[jj] = *reinterpret_cast<const f32x4*>(nb + offW + offA[jj]);
           }
@@ -302,17 +311,17 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
         // k chunk outermost, row blocks in pairs with alternating MFMAs (see phase A); the fragments of the next
         // pair are read before the MFMAs of this one
         f32x4 fa[2][2];
-        auto read_pair = [&](int idx, f32x4 (&f)[2]) {       // idx = 7 j + pair; the last pair of a chunk is block 12 alone
-          const int j = idx / 7, pr = idx - 7 * j;
+        auto read_pair = [&](int idx, f32x4 (&f)[2]) {       // idx = F_PAIRS j + pair; an odd last block is alone
+          const int j = idx / F_PAIRS, pr = idx - F_PAIRS * j;
           f[0] = *reinterpret_cast<const f32x4*>(ldsb + offH[j & 1] + ((2 * pr) * 8192 + (j >> 1) * 128));
-          if (pr < 6) f[1] = *reinterpret_cast<const f32x4*>(ldsb + offH[j & 1] + ((2 * pr + 1) * 8192 + (j >> 1) * 128));
+          if (2 * pr + 1 < F_RB) f[1] = *reinterpret_cast<const f32x4*>(ldsb + offH[j & 1] + ((2 * pr + 1) * 8192 + (j >> 1) * 128));
         };
         read_pair(0, fa[0]);
 #pragma unroll
-        for (int idx = 0; idx < 56; ++idx) {
-          const int j = idx / 7, pr = idx - 7 * j, b = 2 * pr;
-          if (idx + 1 < 56) read_pair(idx + 1, fa[(idx + 1) & 1]);
-          if (pr < 6) {
+        for (int idx = 0; idx < 8 * F_PAIRS; ++idx) {
+          const int j = idx / F_PAIRS, pr = idx - F_PAIRS * j, b = 2 * pr;
+          if (idx + 1 < 8 * F_PAIRS) read_pair(idx + 1, fa[(idx + 1) & 1]);
+          if (b + 1 < F_RB) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               lg[b] = f_mfma(fa[idx & 1][0][s], fw[half][j][s], lg[b]);
@@ -396,9 +405,48 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
 
 bool astp_fused_supported(int T, int C, int bottleneck) {
   static const int off = [] { const char* e = getenv("WS_ASTP_FUSED"); return e && atoi(e) == 0 ? 1 : 0; }();
-  // all 13 row blocks are computed whatever T is: below ~10 blocks the tile kernels are the faster path
-  return !off && C == F_NC && bottleneck == F_NH && T > 160 && T <= F_ROWS;
+  // 7, 10 or 13 row blocks of 16 frames; shorter utterances stay on the tile kernels, longer ones too (one workgroup
+  // per utterance stops paying when an utterance needs several passes: with a constant rows budget the batch
+  // then holds fewer utterances than there are CUs)
+  return !off && C == F_NC && bottleneck == F_NH && T >= 64 && T <= 208;
 }
+
+// One workgroup per utterance costs a fixed ~25 us per row block and round of workgroups whatever the batch is; the
+// three tile-kernel launches cost ~497 us per 256 x 198 rows in proportion to the rows.  A lone utterance (latency!)
+// or a batch that fills a round badly stays on the tile kernels.
+bool astp_fused_pays(int B, int T) {
+  static const int force = [] { const char* e = getenv("WS_ASTP_FUSED"); return e && atoi(e) == 2 ? 1 : 0; }();
+  if (force) return true;                        // (tests: the kernel on small batches)
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  const int rb = T <= 112 ? 7 : (T <= 160 ? 10 : 13);
+  const double fused = (double)((B + cus - 1) / cus) * (25.5 * rb);
+  const double tiles = 497.0 * ((double)B * T) / (256.0 * 198.0) + 20.0;
+  return fused < tiles;
+}
+
+namespace {
+template <int RB>
+hipError_t launch_astp_rb(const AstpFusedParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<false, RB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, f_lds_bytes(RB));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<true, RB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, f_lds_bytes(RB));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (p.row_len) hipLaunchKernelGGL((astp_fused_kernel<true, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
+  else hipLaunchKernelGGL((astp_fused_kernel<false, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
+  return hipGetLastError();
+}
+}  // namespace
 
 hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float* w1, int ldw1, const float* bias,
                              const float* bias_img, const float* w2, int ldw2, float* pooled, const int* lens,
@@ -407,30 +455,12 @@ hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float*
     return hipErrorInvalidValue;
   // 32-bit byte offsets inside one utterance / the weight matrices
   if ((long long)T * ldh * 4 >= (1ll << 31) || (long long)F_NH * ldw1 * 4 >= (1ll << 31)) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
   AstpFusedParams p;
   p.h = h; p.ldh = ldh; p.w1 = w1; p.ldw1 = ldw1; p.bias = bias; p.bias_img = bias_img;
   p.w2 = w2; p.ldw2 = ldw2; p.pooled = pooled; p.row_len = lens; p.B = B; p.T = T;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
-  (void)cus;
-  const int grid = B;
-  if (lens) hipLaunchKernelGGL(astp_fused_kernel<true>, dim3(grid), dim3(512), F_LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(astp_fused_kernel<false>, dim3(grid), dim3(512), F_LDS_BYTES, stream, p);
-  return hipGetLastError();
+  if (T <= 112) return launch_astp_rb<7>(p, stream);
+  if (T <= 160) return launch_astp_rb<10>(p, stream);
+  return launch_astp_rb<13>(p, stream);
 }
 
 }  // namespace wsamd

@@ -274,7 +274,7 @@ struct EcapaModel : ModelBase {
       a1.bias_img = bias_img;
     }
     a1.row_len = L0;
-    if (gemm_precision == 0 && !no_fuse && astp_fused_supported(T, 1536, 128)) {
+    if (gemm_precision == 0 && !no_fuse && astp_fused_supported(T, 1536, 128) && astp_fused_pays(B, T)) {
       // linear1 -> tanh -> linear2 -> softmax over time -> weighted mean / std: one workgroup per utterance,
       // neither the bottleneck activations nor the logits leave the chip (astp_fused.hip)
       if (prof.enabled) {

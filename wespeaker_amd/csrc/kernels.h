@@ -174,6 +174,7 @@ hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C
 // ASTP linear1 -> tanh -> linear2 -> softmax over time -> weighted mean / std as one kernel, one workgroup per
 // utterance (astp_fused.hip; fp32, 64 <= T <= 208, C = 1536, bottleneck 128).  pooled[b] = [mean(C) | std(C)].
 bool astp_fused_supported(int T, int C, int bottleneck);
+bool astp_fused_pays(int B, int T);          // cost model: one workgroup per utterance vs the three tile launches
 hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float* w1, int ldw1, const float* bias,
                              const float* bias_img, const float* w2, int ldw2, float* pooled, const int* lens,
                              hipStream_t stream);
