@@ -432,16 +432,13 @@ bool astp_fused_pays(int B, int T) {
 namespace {
 template <int RB>
 hipError_t launch_astp_rb(const AstpFusedParams& p, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<false, RB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, f_lds_bytes(RB));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(astp_fused_kernel<true, RB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, f_lds_bytes(RB));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // (per device: several GPUs in one process each need the attribute)
+  static size_t granted0[WS_MAX_DEVICES] = {}, granted1[WS_MAX_DEVICES] = {};
+  hipError_t e = p.row_len ? ensure_dynamic_lds(reinterpret_cast<const void*>(astp_fused_kernel<true, RB>),
+                                                f_lds_bytes(RB), granted1)
+                           : ensure_dynamic_lds(reinterpret_cast<const void*>(astp_fused_kernel<false, RB>),
+                                                f_lds_bytes(RB), granted0);
+  if (e != hipSuccess) return e;
   if (p.row_len) hipLaunchKernelGGL((astp_fused_kernel<true, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
   else hipLaunchKernelGGL((astp_fused_kernel<false, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
   return hipGetLastError();
