@@ -207,6 +207,12 @@ WS_API int ws_engine_check_range(ws_engine* eng, ws_stream stream);
  * tests/golden/dispatch_*.txt pin the tables of the BASELINE models. */
 WS_API int ws_debug_dispatch_log(int mode);
 WS_API long long ws_debug_dispatch_report(char* buf, long long cap);
+/* Reproducer switch of the fbank kernel (process-wide; tests and tools/fbank_race_probe.py only -- DESIGN.md 6.0).
+ * The round-3 build of runtime/core/frontend/fbank.h:138-198's arithmetic used the packed-fp32 instruction forms in
+ * its power-spectrum loop; next to binary16 GEMMs on another stream those returned wrong values in lanes 48..63.
+ * mode 0 = the shipped kernel (no packed-fp32 forms), 1 = the round-3 packed build.  Returns 0, or
+ * WS_ERR_INVALID_ARG for an unknown mode. */
+WS_API int ws_debug_fbank_mode(int mode);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);
 

@@ -34,7 +34,7 @@ def sources():
 
 
 def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "wespeaker_amd.h"))
     return max(os.path.getmtime(h) for h in hs)
 
@@ -91,7 +91,75 @@ def build(force=False, verbose=True):
         rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError("extract_emb_main build failed:\n" + out)
+    if need_link:
+        bad = check_isa(LIB)
+        if bad:
+            raise RuntimeError("forbidden packed-fp32 instruction forms in the library (DESIGN.md 6.0):\n" +
+                               "\n".join("  %s: %d x %s" % b for b in bad))
     return LIB
+
+
+# Kernels that may hold the forbidden form: the reproducer build of the fbank kernel (ws_debug_fbank_mode(1)).
+ISA_CHECK_EXEMPT = ("fbank_kernel_packed",)
+
+
+def gfx950_code_objects(lib_path):
+    """The gfx950 code objects of a hipcc-linked library: every translation unit leaves one clang offload bundle
+    (magic, entry count, then (offset, size, triple) per entry) in .hip_fatbin."""
+    import struct
+    data = open(lib_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos, out = 0, []
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return out
+        cnt, = struct.unpack_from("<Q", data, i + 24)
+        off = i + 32
+        for _ in range(cnt):
+            o, sz, ts = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + ts].decode("ascii", "replace")
+            off += ts
+            if ARCH in triple and sz:
+                out.append(data[i + o:i + o + sz])
+        pos = i + len(magic)
+
+
+def check_isa(lib_path=LIB):
+    """on MI355X a packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) whose op_sel
+    starts [0,1 -- low result from src0's low half and src1's HIGH half -- returns wrong values in lanes 48..63 while
+    binary16 GEMM kernels of another stream share the CU (tools/pk_probe.py: every such form, no other of the 33 forms
+    tried).  hipcc's SLP vectoriser emits it freely, so the linked library is disassembled and searched.  Returns
+    [(kernel, count, mnemonic)] of the offenders outside ISA_CHECK_EXEMPT."""
+    import re
+    import tempfile
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(_hipcc())))
+    objdump = os.path.join(rocm, "lib", "llvm", "bin", "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump") or objdump
+    cos = gfx950_code_objects(lib_path)
+    if not cos:
+        raise RuntimeError("no %s code object found in %s" % (ARCH, lib_path))
+    hits = {}
+    pat = re.compile(r"\b(v_pk_(?:mul|add|fma)_f32)\b.*op_sel:\[0,1")
+    sym = re.compile(r"^[0-9a-f]+ <(.*)>:")
+    for co in cos:
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.run([objdump, "-d", f.name], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 text=True, check=True).stdout
+        cur = "?"
+        for line in txt.splitlines():
+            m = sym.match(line)
+            if m:
+                cur = m.group(1)
+                continue
+            m = pat.search(line)
+            if m and not any(e in cur for e in ISA_CHECK_EXEMPT):
+                hits[(cur, m.group(1))] = hits.get((cur, m.group(1)), 0) + 1
+    return sorted((k, n, op) for (k, op), n in hits.items())
 
 
 if __name__ == "__main__":

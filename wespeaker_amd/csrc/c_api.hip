@@ -566,6 +566,15 @@ int ws_debug_dispatch_log(int mode) {
   return WS_OK;
 }
 
+int ws_debug_fbank_mode(int mode) {
+  if (mode < 0 || mode > 1) {
+    set_error("ws_debug_fbank_mode: mode %d (0 shipped kernel, 1 packed-fp32 reproducer build)", mode);
+    return WS_ERR_INVALID_ARG;
+  }
+  set_fbank_debug_mode(mode);
+  return WS_OK;
+}
+
 long long ws_debug_dispatch_report(char* buf, long long cap) {
   if (cap < 0 || (cap > 0 && !buf)) { set_error("ws_debug_dispatch_report: invalid argument"); return WS_ERR_INVALID_ARG; }
   return (long long)dispatch_log_dump(buf, (size_t)cap);

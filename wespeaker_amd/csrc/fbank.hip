@@ -11,6 +11,7 @@
 //   filters (<= 2 lanes-worth of bins) -> log(max(., eps)) -> one contiguous 80-float row store.
 // HBM-bound by construction (64 KB in, 63 KB out per 2 s utterance); the FFT never leaves LDS.
 #include "kernels.h"
+#include <atomic>
 
 namespace wsamd {
 
@@ -19,177 +20,30 @@ constexpr int CN = FFT_N / 2;         // complex FFT size
 constexpr int FRAMES_PER_BLOCK = 4;
 constexpr int MEL_W_MAX = 1024;       // packed triangular weights (2 per FFT bin at most: 512)
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+// Two builds of one kernel body (fbank_kernel.inc).  DESIGN.md 6.0: the round-3 build let hipcc's SLP vectoriser
+// pair the power-spectrum arithmetic into packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel and an
+// inline constant); next to the binary16 GEMMs of another stream those returned wrong values in lanes 48..63 (the
+// fourth 16-lane pass of the instruction) -- on every MI355X leased, never alone.  The shipped build is compiled
+// without the packed-fp32 instruction forms (same arithmetic, one fp32 operation per instruction); the packed build
+// stays as the reproducer behind ws_debug_fbank_mode(1).
+#define WS_FBANK_FN(name) name
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WS_FBANK_ATTR __attribute__((target("no-packed-fp32-ops")))
+#else
+#define WS_FBANK_ATTR                     // the host pass only needs the kernel's stub
+#endif
+#include "fbank_kernel.inc"
+#undef WS_FBANK_FN
+#undef WS_FBANK_ATTR
+#define WS_FBANK_FN(name) name##_packed
+#define WS_FBANK_ATTR
+#include "fbank_kernel.inc"
+#undef WS_FBANK_FN
+#undef WS_FBANK_ATTR
 
-// Each wavefront owns its frame and its private slice of LDS: only wave-level ordering is needed
-// between the phases (DS operations of one wave execute in order; the fences stop the compiler from
-// moving LDS accesses across the phase boundary).  No workgroup barrier -> the four frames of a
-// block never wait for each other.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// twiddle[m] = exp(-2 pi i m / 512), m = 0..511
-// Persistent workgroups (round 3): the mel tables and the twiddle factors are staged into LDS ONCE per workgroup and
-// every wavefront then walks frames wave, wave + W, ... (before, each workgroup lived for four frames and paid the
-// ~5.5-KB table staging + a barrier in front of them; the FFT stages read their twiddles through dependent global
-// loads).  The mel phase requests all taps of a pass before the first multiply (trip count = the longest filter of
-// the pass, uniform across the wavefront) instead of one exposed LDS round trip per tap: ~10 -> 1 per pass.
-// Same arithmetic in the same order: the outputs are bit-identical to the previous kernel.
-__global__ __launch_bounds__(64 * FRAMES_PER_BLOCK, 6) void fbank_kernel(      // six workgroups per CU: <= 80 VGPRs
-    const FbankTables tb, const void* __restrict__ wav, int wav_dtype, int N, long long wav_stride,
-    float scale, const float* __restrict__ window, int T, long long total_frames,
-    float* __restrict__ feats, const int* __restrict__ frames) {
-  __shared__ __attribute__((aligned(16))) float2 bufA[FRAMES_PER_BLOCK][CN];
-  __shared__ __attribute__((aligned(16))) float2 bufB[FRAMES_PER_BLOCK][CN + 4];
-  __shared__ float mel_w_s[MEL_W_MAX];
-  __shared__ int mel_start_s[128], mel_len_s[128], mel_off_s[128], pass_max_s[8];
-  __shared__ __attribute__((aligned(16))) float2 tw_s[FFT_N];
-  for (int i = threadIdx.x; i < tb.mel_w_total; i += 64 * FRAMES_PER_BLOCK) mel_w_s[i] = tb.mel_w[i];
-  for (int i = threadIdx.x; i < 128; i += 64 * FRAMES_PER_BLOCK) {
-    const bool has = i < tb.num_bins;
-    mel_start_s[i] = has ? tb.mel_start[i] : 0; mel_len_s[i] = has ? tb.mel_len[i] : 0; mel_off_s[i] = has ? tb.mel_off[i] : 0;
-  }
-  for (int i = threadIdx.x; i < FFT_N; i += 64 * FRAMES_PER_BLOCK) {
-    tw_s[i] = reinterpret_cast<const float2*>(tb.twiddle)[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 8) {                        // longest filter of each 16-bin pass
-    int mx = 0;
-    for (int q = 0; q < 16; ++q) { const int l = mel_len_s[threadIdx.x * 16 + q]; mx = l > mx ? l : mx; }
-    pass_max_s[threadIdx.x] = mx;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int L = tb.frame_len;                   // 400
-  float* xs = reinterpret_cast<float*>(bufB[wave]);   // raw samples (<= 512 floats)
-  float* zr = reinterpret_cast<float*>(bufA[wave]);   // windowed, zero padded = complex input
-  const float2* tw = tw_s;
-
-  for (long long frame = (long long)blockIdx.x * FRAMES_PER_BLOCK + wave; frame < total_frames;
-       frame += (long long)gridDim.x * FRAMES_PER_BLOCK) {
-    const int b = (int)(frame / T), f = (int)(frame - (long long)b * T);
-    // ragged batch: utterance b has frames[b] <= T frames; the rows beyond are written as zeros (they are
-    // the zero padding the first convolution sees).  Only wave-level synchronisation is used in this loop.
-    if (frames && f >= frames[b]) {
-      for (int i = lane; i < tb.num_bins; i += 64) feats[frame * tb.num_bins + i] = 0.f;
-      continue;
-    }
-    const long long s0 = (long long)b * wav_stride + (long long)f * tb.frame_shift;
-
-    // 1. load + DC offset
-    float part = 0.f;
-    for (int j = lane; j < L; j += 64) {
-      float v;
-      if (wav_dtype == 0) v = (float)reinterpret_cast<const short*>(wav)[s0 + j];
-      else v = reinterpret_cast<const float*>(wav)[s0 + j];
-      v *= scale;
-      xs[j] = v;
-      part += v;
-    }
-    const float mean = wave_sum_f(part) / (float)L;
-    wave_sync();
-    // 2. pre-emphasis (replicate-pad first sample) + window, zero pad to 512
-    for (int j = lane; j < FFT_N; j += 64) {
-      float y = 0.f;
-      if (j < L) {
-        const float cur = xs[j] - mean;
-        const float prev = xs[j > 0 ? j - 1 : 0] - mean;
-        y = (cur - 0.97f * prev) * window[j];
-      }
-      zr[j] = y;
-    }
-    wave_sync();
-
-    // 3. 256-point complex FFT, Stockham radix-4: A -> B -> A -> B -> A
-    float2* src = bufA[wave];
-    float2* dst = bufB[wave];
-#pragma unroll
-    for (int stage = 0; stage < 4; ++stage) {
-      const int Ns = 1 << (2 * stage);              // 1, 4, 16, 64
-      const int k = lane & (Ns - 1);
-      float2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
-      if (stage > 0) {
-        const int step = (FFT_N / (Ns * 4)) * k;     // index into the 512-th roots table
-        v1 = cmul(v1, tw[step]);
-        v2 = cmul(v2, tw[2 * step]);
-        v3 = cmul(v3, tw[3 * step]);
-      }
-      // DFT-4 (forward: multiply by -i = (y, -x))
-      const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-      const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-      const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i * (v1 - v3)
-      const int d0 = ((lane - k) << 2) + k;          // (lane / Ns) * Ns * 4 + k
-      dst[d0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-      dst[d0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
-      dst[d0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-      dst[d0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
-      wave_sync();
-      float2* t = src; src = dst; dst = t;
-    }
-    // result Z[0..255] in src (= bufA)
-
-    // 4. unpack to the real-input spectrum and take the power: P[k], k = 0..256 -> floats in dst
-    float* P = reinterpret_cast<float*>(dst);
-    for (int k = lane; k <= CN; k += 64) {
-      const float2 zk = src[k & (CN - 1)];
-      const float2 zc = src[(CN - k) & (CN - 1)];
-      // E = (Z[k] + conj(Z[N-k])) / 2 ; O = (Z[k] - conj(Z[N-k])) / (2i)
-      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
-      const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
-      const float2 w = tw[k & (FFT_N - 1)];          // exp(-2 pi i k / 512); k = 256 -> (-1, 0)
-      const float xr = er + (orr * w.x - oi * w.y);
-      const float xi = ei + (orr * w.y + oi * w.x);
-      P[k] = xr * xr + xi * xi;
-    }
-    wave_sync();
-
-    // 5. mel filterbank + log.  Four lanes per mel bin (16 bins per pass), taps i = sub, sub + 4, ...: every tap of
-    // the pass is requested before the first multiply (masked taps read P[st] with weight 0: acc + 0 * P is acc)
-    for (int b0 = 0; b0 < tb.num_bins; b0 += 16) {
-      const int bin = b0 + (lane >> 2), sub = lane & 3;
-      const bool has = bin < tb.num_bins;
-      const int st = mel_start_s[bin], len = mel_len_s[bin];
-      const float* w = mel_w_s + mel_off_s[bin];
-      const int its = (pass_max_s[b0 >> 4] + 3) >> 2;                   // wave-uniform
-      float acc = 0.f;
-#pragma unroll
-      for (int h0 = 0; h0 < 12; h0 += 6) {          // six taps in flight at a time (registers: six workgroups per CU)
-        if (h0 < its) {
-          float wv[6], pv[6];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            if (h0 + q < its) {
-              const int i = sub + 4 * (h0 + q);
-              const bool ok = i < len;
-              wv[q] = ok ? w[i] : 0.f;
-              pv[q] = P[st + (ok ? i : 0)];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            if (h0 + q < its) acc += wv[q] * pv[q];
-        }
-      }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
-      if (has && sub == 0) feats[frame * tb.num_bins + bin] = v;
-    }
-    wave_sync();                                  // the next frame reuses bufA / bufB
-  }
-}
+// ws_debug_fbank_mode: 0 shipped kernel, 1 the packed-fp32 build (tests and tools/fbank_race_probe.py only)
+static std::atomic<int> g_fbank_mode{0};
+void set_fbank_debug_mode(int mode) { g_fbank_mode.store(mode, std::memory_order_relaxed); }
 
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
@@ -209,8 +63,12 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
   const long long resident = (long long)cus * 6;         // ~26 KB of LDS per workgroup: six per CU
   if (blocks > resident) blocks = resident;
   const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
-  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
-                     wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
+  if (g_fbank_mode.load(std::memory_order_relaxed) == 1)
+    hipLaunchKernelGGL(fbank_kernel_packed, dim3((unsigned)blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
+                       wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
+  else
+    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
+                       wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
   return hipGetLastError();
 }
 

@@ -225,6 +225,7 @@ struct FbankTables {
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream, const int* frames = nullptr);
+void set_fbank_debug_mode(int mode);   // ws_debug_fbank_mode (0 shipped kernel, 1 packed-fp32 reproducer)
 // lens (optional, [B]): valid frames per utterance of a ragged batch -- fbank writes zero rows beyond
 // them, CMN averages over / subtracts from the valid rows only
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr);

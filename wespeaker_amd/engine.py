@@ -438,7 +438,8 @@ class SpeakerModelLanes:
     results are the same bits (same kernels, same launch parameters per batch).
 
     extract() / embed() return a LaneResult immediately; call .wait() (stream-side) or .synchronize() (host-side)
-    before the embeddings are consumed.  Inputs must stay alive and unmodified until then."""
+    before the embeddings are consumed.  Inputs must stay unmodified until then (they may be dropped: the lane's stream
+    is recorded on them)."""
 
     def __init__(self, model_name, state_dict, lanes=2, **kwargs):
         if lanes < 1:
@@ -453,11 +454,14 @@ class SpeakerModelLanes:
     def lanes(self):
         return len(self.engines)
 
-    def _run(self, fn):
+    def _run(self, fn, *inputs):
         lane = self._next
         self._next = (lane + 1) % len(self.engines)
         stream = self.streams[lane]
         stream.wait_stream(torch.cuda.current_stream(self.device))      # the inputs are ready
+        for t in inputs:                      # the caller may drop / rebind them as soon as we return: keep the
+            if isinstance(t, torch.Tensor) and t.is_cuda:       # caching allocator from reusing the block before the
+                t.record_stream(stream)                          # lane's kernels have read it
         with torch.cuda.stream(stream):
             out = fn(self.engines[lane])
             ev = torch.cuda.Event()
@@ -465,30 +469,23 @@ class SpeakerModelLanes:
         return LaneResult(out, ev, lane)
 
     def extract(self, frontend, wav, window_type="hamming", scale=1.0):
-        return self._run(lambda e: e.extract(frontend, wav, window_type=window_type, scale=scale))
+        return self._run(lambda e: e.extract(frontend, wav, window_type=window_type, scale=scale), wav)
 
     def extract_ragged(self, frontend, wav, num_samples, **kw):
-        return self._run(lambda e: e.extract_ragged(frontend, wav, num_samples, **kw))
+        return self._run(lambda e: e.extract_ragged(frontend, wav, num_samples, **kw), wav)
 
     def embed(self, feats):
-        return self._run(lambda e: e.embed(feats))
+        return self._run(lambda e: e.embed(feats), feats)
 
     def synchronize(self):
         for s in self.streams:
             s.synchronize()
 
-    def set_precision(self, mode, allow_binary16=False):
-        """fp32 (the parity-grade back-end) only, unless allow_binary16.  OPEN ISSUE (round 3): with a split-binary16
-        (f16x3 / f16) engine running on another stream, the fbank kernel of ANY engine occasionally returns its last
-        two mel bins of a few frames a little off (tools/lanes_fbank_probe.py: ~1e-3 relative in the log-mel
-        value, embeddings then differ by up to 2 %); an fp32 engine next to fp32 engines gives the single engine's
-        bits (tests/test_gpu_parity.py::test_lanes_two_batches_in_flight_same_bits).  No LDS or global overrun of the
-        binary16 kernels was found (LDS canary next to them: clean); until the cause is known the lanes refuse the
-        binary16 back-ends by default."""
-        name = mode if isinstance(mode, str) else {0: "fp32", 1: "f16x3", 2: "f16"}[int(mode)]
-        if name != "fp32" and len(self.engines) > 1 and not allow_binary16:
-            raise _lib.NativeError("SpeakerModelLanes: %s engines on concurrent streams are not bit-stable yet (see "
-                                   "set_precision.__doc__); use one lane or allow_binary16=True" % name)
+    def set_precision(self, mode):
+        """Every lane gets the back-end.  (Round 3 refused the binary16 back-ends here: next to their kernels the
+        fbank kernel of any engine returned a few mel bins wrong.  Root cause and fix: DESIGN.md 6.0 -- a packed-fp32
+        instruction form of fbank's power-spectrum loop; the shipped kernel has none, and the library is checked for
+        that form at build time.)"""
         for e in self.engines:
             e.set_precision(mode)
         return self
