@@ -386,10 +386,11 @@ def main(argv=None):
         if not STUB:
             torch.cuda.synchronize(device)
 
-    nccl = world > 1 and dist.get_backend() == "nccl"
+    active = parallel.collectives_active()            # several ranks (or WS_DIST_FORCE_GROUP=1: a lone rank on RCCL)
+    nccl = active and dist.get_backend() == "nccl"
 
     def fence():
-        if world > 1:
+        if active:
             if nccl:
                 dist.barrier(device_ids=[device.index])
             else:
@@ -397,7 +398,7 @@ def main(argv=None):
         sync()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not active:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=device if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -427,15 +428,21 @@ def main(argv=None):
         n_local = hi - lo
         m = model or make_model(model_name, embed_dim, min(per_chunk, max(1, n_local)), T)
         m.set_precision(prec)
-        # the batches of a shard alternate between the lanes (fp32 back-end), like the steps of the default mode
-        set_lanes = lanes_obj if (prec == "fp32" and n_local > per_batch) else None
+        # equal batches (VoxCeleb1-O over 8 ranks: 610 utterances = 2 x 305, not 512 + 98), alternating between the
+        # lanes like the steps of the default mode
+        n_b = max(1, -(-n_local // per_batch))
+        if not STUB and max(1, args.lanes) > 1 and n_b < args.lanes and n_local >= 128 * args.lanes:
+            n_b = args.lanes
+        cuts = [(n_local * i) // n_b for i in range(n_b + 1)]
+        set_lanes = lanes_obj if n_b > 1 else None
         if set_lanes is not None:
-            set_lanes.set_precision("fp32")
-        elif not STUB and prec == "fp32" and max(1, args.lanes) > 1 and n_local > per_batch:
+            set_lanes.set_precision(prec)
+        elif not STUB and max(1, args.lanes) > 1 and n_b > 1:
             from wespeaker_amd import SpeakerModelLanes
             set_lanes = SpeakerModelLanes(model_name, synth.synth_state_dict(model_name, 80, embed_dim, seed=42),
                                           lanes=args.lanes, feat_dim=80, embed_dim=embed_dim, device=device,
                                           max_batch=min(per_chunk, max(1, n_local)), max_frames=T)
+            set_lanes.set_precision(prec)
         if STUB:
             g = torch.Generator().manual_seed(99)
             allw = (3000.0 * torch.randn(n_utts, num_samples, generator=g)).round().to(torch.int16)
@@ -460,11 +467,10 @@ def main(argv=None):
 
         def one_pass():
             if set_lanes is not None:
-                pend = [set_lanes.extract(fe, wav[b0:min(n_local, b0 + per_batch)])
-                        for b0 in range(0, n_local, per_batch)]
+                pend = [set_lanes.extract(fe, wav[cuts[i]:cuts[i + 1]]) for i in range(n_b) if cuts[i + 1] > cuts[i]]
                 outs = [p_.wait() for p_ in pend]
             else:
-                outs = [m.extract(fe, wav[b0:min(n_local, b0 + per_batch)]) for b0 in range(0, n_local, per_batch)]
+                outs = [m.extract(fe, wav[cuts[i]:cuts[i + 1]]) for i in range(n_b) if cuts[i + 1] > cuts[i]]
             local = torch.cat(outs, 0) if outs else torch.zeros((0, embed_dim), dtype=torch.float32, device=device)
             emb = parallel.gather_rows(local, n_utts)
             sc = scorer(emb) if scorer is not None else None
@@ -484,6 +490,7 @@ def main(argv=None):
                "steps": steps, "shard": "rank r of %d takes utterances [r*ceil(U/G), (r+1)*ceil(U/G)) "
                                          "(parallel.shard_range = tools/extract_embedding.sh's split rule)" % world,
                "per_rank_utts": parallel.shard_size(n_utts, world), "batch": per_batch,
+               "batches_per_rank": [cuts[i + 1] - cuts[i] for i in range(n_b)],
                "batches_in_flight": set_lanes.lanes if set_lanes is not None else 1}
         if sc is not None:
             res["trials_per_s_inside_the_step"] = n_trials * steps / dt
@@ -510,7 +517,7 @@ def main(argv=None):
                 "set": res,
             }
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if active:
             fence()
             dist.destroy_process_group()
         return
@@ -543,14 +550,14 @@ def main(argv=None):
         if use_lanes[0]:
             # step i on lane i % lanes: two (three) batches in flight; a result is joined `lanes` steps later
             res = lm.extract(fe, wav)
-            if world == 1:
+            if not active:
                 in_flight.append(res)
             else:
                 with torch.cuda.stream(lm.streams[res.lane]):     # the gather waits for this lane only
                     in_flight.append(parallel.gather_rows_async(res.tensor, n_total))
             return in_flight.pop(0).wait() if len(in_flight) > max(2, n_lanes) else None
         emb = model.extract(fe, wav)                              # (B, E) on this GPU
-        if world == 1:
+        if not active:
             return emb
         in_flight.append(parallel.gather_rows_async(emb, n_total))
         return in_flight.pop(0).wait() if len(in_flight) > 2 else None
@@ -630,9 +637,9 @@ def main(argv=None):
         return roof
 
     def run_backend(prec, steps, warmup, windows):
-        # several batches in flight: the parity-grade back-end only (SpeakerModelLanes.set_precision: open issue with
-        # binary16 engines on concurrent streams)
-        lanes_here = lm is not None and prec == "fp32"
+        # several batches in flight on every back-end (round 3 had to keep the binary16 ones on one stream:
+        # DESIGN.md 6.0, closed in round 4)
+        lanes_here = lm is not None
         if lanes_here:
             lm.set_precision(prec)
         else:
@@ -877,14 +884,14 @@ def main(argv=None):
             line["configs"] = configs
         if batch_sweep:
             line["throughput_vs_per_gpu_batch"] = batch_sweep
-        if STUB:
-            line["embedding_checksum"] = float(all_emb.double().abs().sum().item())
+        line["embedding_checksum"] = float(all_emb.double().abs().sum().item())
+        line["collective_backend"] = dist.get_backend() if active else None
         if world == 1 and not args.no_cpu_baseline and not args.headline_only and not STUB:
             heavy = name.startswith("ResNet") and name not in ("ResNet18", "ResNet34")
             line["cpu_baseline"] = cpu_baseline(name, E, args.cpu_utts, budget_s=6.0 if heavy else 8.0)
         assert all_emb.shape == (n_total, E) and bool(torch.isfinite(all_emb).all())
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if active:
         fence()
         dist.destroy_process_group()
 

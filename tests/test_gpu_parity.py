@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): embeddings within 1e-4 cosine of the reference 
 LLRs within 1e-3.  The tests additionally hold tighter bounds (relative L2 error) so that a
 wrong-but-correlated embedding cannot pass."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -969,6 +970,80 @@ def test_bench_two_ranks_with_lanes_on_one_gpu():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128
     assert line["config"]["batches_in_flight_per_gpu"] == 2 and line["value"] > 0
     assert line["roofline"]["frac"] > 0
+
+
+def _rccl_env(root, port, log_path):
+    """A lone rank on a REAL RCCL process group: WS_DIST_FORCE_GROUP=1 makes init_distributed build the group and
+    every collective run at world size 1 (parallel.collectives_active); NCCL_DEBUG=INFO (into a file: RCCL writes it
+    through its own buffer, in the middle of other stdout lines) proves it was RCCL."""
+    return dict(os.environ, PYTHONPATH=root, WS_DIST_FORCE_GROUP="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=str(log_path),
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+def _assert_rccl_ran(log_path):
+    log = open(log_path).read()
+    assert "NCCL INFO" in log, log[-1500:]
+    assert re.search(r"nranks 1\b", log) or re.search(r"nRanks 1\b", log), log[-1500:]
+    assert "Init COMPLETE" in log or "init complete" in log.lower(), log[-1500:]
+
+
+def test_rccl_group_of_one_runs_bench_default_and_set_modes(tmp_path):
+    """The nccl (= RCCL) branches of bench.py and parallel.py executed for real on the one GPU there is:
+    init_process_group("nccl", device_id), the device barrier of fence(), the device-side max_over_ranks all_reduce,
+    gather_rows_async's all_gather_into_tensor(async_op=True) under a lane's stream (default mode) and gather_rows'
+    blocking all_gather_into_tensor (set mode); the gathered embeddings equal the un-gathered run's checksum."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"]
+    for extra in (["--windows", "1", "--batch", "64", "--headline-only"],
+                  ["--workload", "stream10k", "--total-utts", "700", "--batch", "256"]):
+        lines = {}
+        for forced in (True, False):
+            log = tmp_path / ("rccl_%d.log" % len(extra))
+            env = _rccl_env(root, 29873, log) if forced else dict(os.environ, PYTHONPATH=root)
+            r = subprocess.run(base + extra, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            lines[forced] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            if forced:
+                _assert_rccl_ran(log)
+                assert lines[forced].get("collective_backend", "nccl") == "nccl"
+        a, b = lines[True], lines[False]
+        assert a["n_gpus"] == 1 and a["value"] > 0
+        ka = a.get("set", a)
+        kb = b.get("set", b)
+        assert ka["embedding_checksum"] == kb["embedding_checksum"], (extra, ka["embedding_checksum"], kb["embedding_checksum"])
+
+
+def test_rccl_group_of_one_runs_the_extract_driver(tmp_path):
+    """python -m wespeaker_amd.extract --gather_npz on an RCCL group of one: the barrier, the all_reduce of the
+    embedding width / the per-job counts on device tensors, gather_rows and all_gather_object (extract.py run_jobs)
+    execute under nccl; arks and gathered rows equal the plain single-process run bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir = str(tmp_path / "exp")
+    synth.write_model_dir(mdir, "ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    n = len(_driver_corpus(tmp_path))
+    base = [sys.executable, "-m", "wespeaker_amd.extract", "--exp_dir", mdir, "--model_path",
+            os.path.join(mdir, "avg_model.pt"), "--data_type", "raw", "--data_list", str(tmp_path / "raw.list"),
+            "--wavs_num", str(n), "--nj", "3", "--batch_size", "1"]
+    outs = {}
+    for tag, env in (("plain", dict(os.environ, PYTHONPATH=root)),
+                     ("rccl", _rccl_env(root, 29874, tmp_path / "rccl.log"))):
+        r = subprocess.run(base + ["--store_dir", tag, "--gather_npz", str(tmp_path / (tag + ".npz"))], env=env, cwd=root,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        outs[tag] = r.stdout
+    _assert_rccl_ran(tmp_path / "rccl.log")
+    g0, g1 = np.load(str(tmp_path / "plain.npz")), np.load(str(tmp_path / "rccl.npz"))
+    assert list(g0["keys"]) == list(g1["keys"]) and np.array_equal(g0["emb"], g1["emb"])
+    for j in range(3):
+        assert open(os.path.join(mdir, "embeddings", "plain", "xvector_%03d.ark" % j), "rb").read() == \
+               open(os.path.join(mdir, "embeddings", "rccl", "xvector_%03d.ark" % j), "rb").read()
 
 
 def test_full_size_plda_one_million_trials():

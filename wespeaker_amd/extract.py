@@ -605,9 +605,12 @@ def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, b
         write_ark_scp(keys, emb, os.path.join(embed_dir, "xvector_%03d.ark" % j))
         my_keys.append((j, keys))
         my_emb.append((j, emb))
-    multi = world > 1 and dist.is_initialized()
+    multi = parallel.collectives_active()          # several ranks, or a forced one-rank group (WS_DIST_FORCE_GROUP)
     if multi:
-        dist.barrier()
+        if dist.get_backend() == "nccl":           # RCCL's barrier is a device collective: name the device
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
     result = None
     if rank == 0:
         merged = os.path.join(embed_dir, "xvector.scp")
@@ -707,9 +710,12 @@ def main(argv=None):
     if args.gather_npz and rank == 0:
         keys, emb = out
         np.savez(args.gather_npz, keys=np.asarray(keys), emb=emb)
-    if world > 1:
+    if parallel.collectives_active():
         import torch.distributed as dist
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -26,6 +26,18 @@ def shard_size(n_total: int, world_size: int) -> int:
     return (n_total + world_size - 1) // world_size
 
 
+def force_group() -> bool:
+    """WS_DIST_FORCE_GROUP=1: build the process group and issue every collective also at world size 1.  A lone rank
+    needs neither; the switch exists so that a one-GPU box executes the RCCL code paths for real (init with a device id,
+    all_gather_into_tensor, device-side all_reduce, the device barrier) -- tests/test_gpu_parity.py::test_rccl_*."""
+    return os.environ.get("WS_DIST_FORCE_GROUP") == "1"
+
+
+def collectives_active(group=None) -> bool:
+    """True when the data path has to go through torch.distributed: several ranks, or a forced one-rank group."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or force_group())
+
+
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).
@@ -33,7 +45,7 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("WS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -50,7 +62,7 @@ def init_distributed(backend=None):
 def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Every rank passes its (n_local, E) shard (n_local = len of shard_range); every rank gets the
     full (n_total, E) tensor in list order."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return local[:n_total]
     world = dist.get_world_size(group)
     per = shard_size(n_total, world)
@@ -92,8 +104,7 @@ def gather_rows_async(local: torch.Tensor, n_total: int, group=None) -> PendingG
     a streaming server -- then overlaps the (latency-bound, few hundred KB) gather of batch k with the forward of
     batch k + 1, and a slow rank delays its peers by at most the batches they keep in flight instead of at every
     step.  (gloo with CUDA tensors -- the one-GPU debug path -- completes the gather before returning.)"""
-    if (not dist.is_initialized() or dist.get_world_size(group) == 1
-            or (dist.get_backend(group) == "gloo" and local.is_cuda)):
+    if not collectives_active(group) or (dist.get_backend(group) == "gloo" and local.is_cuda):
         return PendingGather(gather_rows(local, n_total, group), n_total)
     world = dist.get_world_size(group)
     per = shard_size(n_total, world)
