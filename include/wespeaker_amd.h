@@ -144,7 +144,12 @@ WS_API int ws_extract(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_
  * enters a convolution tap (it is the conv's zero padding), CMN / SE means / attentive and statistics pooling
  * / CAM++ context segments run over the utterance's own frames (pooling_layers.py:78-85,119-144;
  * campplus.py:108-135; ecapa_tdnn.py:120-126).  The length arrays are HOST pointers (read before the call
- * returns). */
+ * returns).
+ * Streams: a ws_frontend may be shared by calls on DIFFERENT streams as long as the calls themselves come from one
+ * host thread at a time (no handle is thread-safe).  ws_fbank / ws_extract* only read the frontend's constant tables.
+ * ws_fbank_ragged also uploads a per-call frame-count table; those tables live in a ring of 4 slots, a slot is reused
+ * only after the kernels that read it have finished (the call then waits on the host for that earlier call), so up to
+ * 4 ragged calls may be in flight on any mix of streams. */
 WS_API int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, const int32_t* num_samples,
                     int max_samples, int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
                     ws_stream stream);   /* feats (batch, ws_num_frames(max_samples), bins); rows beyond an utterance's frames = 0 */

@@ -53,6 +53,19 @@ def test_fbank_matches_oracle(frontend, window):
     assert np.abs(got_c - ref_c).max() < 2e-3
 
 
+@pytest.mark.parametrize("bins", [23, 24, 40, 64, 128])
+def test_fbank_other_mel_bin_counts(bins):
+    """Kaldi's own default (23) and the common 40 / 64: triangular filters longer than the mel phase's 48 register taps
+    take its tail loop (round 3 rejected such frontends: ADVICE r3)."""
+    from wespeaker_amd.engine import Frontend
+    fe = Frontend(16000, bins)
+    wav = synth.synth_wav_batch(3, 3)
+    got = fe.fbank(torch.from_numpy(wav), cmn=False).cpu().numpy()
+    ref = np.stack([ofbank.kaldi_fbank(w.astype(np.float32), num_mel_bins=bins, window_type="hamming") for w in wav])
+    assert got.shape == ref.shape == (3, 198, bins)
+    assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 2e-5
+
+
 def test_fbank_matches_reference_native_golden(frontend, golden_dir):
     g = np.load(os.path.join(golden_dir, "fbank_ref_native.npz"))
     wav = np.stack([synth.synth_wav(int(i)) for i in g["utt_idx"]])
@@ -771,6 +784,53 @@ def test_persistent_fp32_gemm_against_the_tile_kernels(tmp_path):
                 assert np.array_equal(res["0"][k], res[mode][k]), (mode, k, np.abs(res["0"][k] - res[mode][k]).max())
             else:
                 assert _rel_err(res[mode][k], res["0"][k]).max() < 1e-6, (mode, k)
+
+
+@pytest.mark.parametrize("switch", ["WS_DIRECT3X3_F32=0", "WS_NO_STD_FROM_SUMS=1", "WS_NO_IM2COL=1", "WS_ASTP_FUSED=0",
+                                    "WS_NO_POOL_FUSE=1"])
+def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
+    """Every environment A/B switch of DESIGN.md 7.1 that selects another kernel for the same arithmetic: the models
+    it touches, full-size batches (so that the shipped side does take the kernel in question), switched against shipped.
+    Different summation orders only: embeddings agree to 1e-5 relative."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    models = {"WS_DIRECT3X3_F32=0": "(('ResNet34', 256, 64, 'fp32'), ('CAMPPlus', 512, 64, 'fp32'))",
+              "WS_NO_STD_FROM_SUMS=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'),)",
+              "WS_NO_IM2COL=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'), ('ECAPA_TDNN_c1024', 192, 128, 'fp32'))",
+              "WS_ASTP_FUSED=0": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'), ('ECAPA_TDNN_c512', 192, 256, 'fp32'))",
+              "WS_NO_POOL_FUSE=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'f16'),)"}[switch]
+    script = tmp_path / "ab.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fixtures import synth\n"
+        "from bench import device_wavs\n"
+        "from wespeaker_amd import Frontend, NativeSpeakerModel\n"
+        "dev = torch.device('cuda:0'); fe = Frontend(16000, 80, device=dev); out = {}\n"
+        "for name, E, B, prec in %s:\n"
+        "    sd = synth.synth_state_dict(name, 80, E, seed=5)\n"
+        "    m = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=E, device=dev, max_batch=B, max_frames=198)\n"
+        "    m.set_precision(prec)\n"
+        "    out[name] = m.extract(fe, device_wavs(B, 32000, dev, 17)).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % (root, models))
+    res = {}
+    for tag in ("shipped", "switched"):
+        env = dict(os.environ, PYTHONPATH=root)
+        for k in ("WS_DIRECT3X3_F32", "WS_NO_STD_FROM_SUMS", "WS_NO_IM2COL", "WS_ASTP_FUSED", "WS_NO_POOL_FUSE"):
+            env.pop(k, None)
+        if tag == "switched":
+            k, v = switch.split("=")
+            env[k] = v
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(script), path], env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        res[tag] = np.load(path)
+    tol = 2e-3 if "POOL_FUSE" in switch else 1e-5      # (binary16 h: another rounding point, not just another order)
+    for k in res["shipped"].files:
+        assert np.isfinite(res["switched"][k]).all()
+        assert _rel_err(res["switched"][k], res["shipped"][k]).max() < tol, (switch, k)
 
 
 def test_lanes_two_batches_in_flight_same_bits():

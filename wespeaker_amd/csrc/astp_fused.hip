@@ -417,12 +417,7 @@ bool astp_fused_supported(int T, int C, int bottleneck) {
 bool astp_fused_pays(int B, int T) {
   static const int force = [] { const char* e = getenv("WS_ASTP_FUSED"); return e && atoi(e) == 2 ? 1 : 0; }();
   if (force) return true;                        // (tests: the kernel on small batches)
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
+  const int cus = current_device_cus();
   const int rb = T <= 112 ? 7 : (T <= 160 ? 10 : 13);
   const double fused = (double)((B + cus - 1) / cus) * (25.5 * rb);
   const double tiles = 497.0 * ((double)B * T) / (256.0 * 198.0) + 20.0;

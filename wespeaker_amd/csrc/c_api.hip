@@ -28,14 +28,24 @@ struct ws_frontend {
   int frame_len = 400, frame_shift = 160, fft_n = 512;
   DevBuf window_h, window_p, twiddle, mel_start, mel_len, mel_off, mel_w;
   FbankTables tables;
-  // ws_fbank_ragged: per-utterance frame counts (device) + their pinned staging
-  DevBuf frames_dev;
-  int* frames_pinned = nullptr;
-  size_t frames_cap = 0;
-  hipEvent_t frames_copied = nullptr;
+  // ws_fbank_ragged: per-utterance frame counts (device) + their pinned staging, in a ring of slots.  A slot's `done`
+  // event is recorded BEHIND the kernels that read its table, on the stream of that call, and waited for (host side)
+  // before the slot is written again -- so consecutive calls may use different streams (a table that a kernel of
+  // another stream still reads is never overwritten), and up to FRAME_SLOTS calls are in flight without a host wait.
+  static constexpr int FRAME_SLOTS = 4;
+  struct FrameSlot {
+    DevBuf dev;
+    int* pinned = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool used = false;
+  } slots[FRAME_SLOTS];
+  int next_slot = 0;
   ~ws_frontend() {
-    if (frames_pinned) (void)hipHostFree(frames_pinned);
-    if (frames_copied) (void)hipEventDestroy(frames_copied);
+    for (auto& sl : slots) {
+      if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+      if (sl.pinned) (void)hipHostFree(sl.pinned);
+    }
   }
 };
 
@@ -120,13 +130,6 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
     st[b] = first; ln[b] = last - first + 1; off[b] = (int)wts.size();
     for (int i = first; i <= last; ++i) wts.push_back(row[i]);
   }
-  // fbank_kernel's mel phase holds at most 12 x 4 taps of a filter in registers (80 bins at 16 kHz: <= 37)
-  for (int b = 0; b < num_mel_bins; ++b)
-    if (ln[b] > 48) {
-      delete fe;
-      set_error("ws_frontend_create: mel filter %d spans %d FFT bins (> 48): too few mel bins for this kernel", b, ln[b]);
-      return WS_ERR_INVALID_ARG;
-    }
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.alloc(bytes);
     if (e != hipSuccess) return e;
@@ -189,31 +192,31 @@ int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, 
   if (T == 0 || batch == 0) return WS_OK;
   hipStream_t st = (hipStream_t)stream;
   WS_HIP_CHECK(hipSetDevice(fe->device));
-  if ((size_t)batch > fe->frames_cap) {
-    WS_HIP_CHECK(hipStreamSynchronize(st));
-    if (fe->frames_pinned) (void)hipHostFree(fe->frames_pinned);
-    fe->frames_pinned = nullptr;
+  ws_frontend::FrameSlot& sl = fe->slots[fe->next_slot];
+  fe->next_slot = (fe->next_slot + 1) % ws_frontend::FRAME_SLOTS;
+  if (!sl.done) WS_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (sl.used) WS_HIP_CHECK(hipEventSynchronize(sl.done));     // the kernels that read this slot's table have finished
+  if ((size_t)batch > sl.cap) {
+    if (sl.pinned) (void)hipHostFree(sl.pinned);
+    sl.pinned = nullptr; sl.cap = 0;
     const size_t cap = (size_t)batch + batch / 2 + 64;
-    WS_HIP_CHECK(fe->frames_dev.alloc(cap * sizeof(int)));
-    WS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->frames_pinned), cap * sizeof(int), 0));
-    fe->frames_cap = cap;
-    if (!fe->frames_copied) WS_HIP_CHECK(hipEventCreateWithFlags(&fe->frames_copied, hipEventDisableTiming));
-  } else {
-    WS_HIP_CHECK(hipEventSynchronize(fe->frames_copied));
+    WS_HIP_CHECK(sl.dev.alloc(cap * sizeof(int)));
+    WS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), cap * sizeof(int), 0));
+    sl.cap = cap;
   }
   for (int b = 0; b < batch; ++b) {
     if (num_samples[b] < 0 || num_samples[b] > max_samples) {
       set_error("ws_fbank_ragged: utterance %d has %d samples, max_samples is %d", b, num_samples[b], max_samples);
       return WS_ERR_INVALID_ARG;
     }
-    fe->frames_pinned[b] = ws_num_frames(num_samples[b], fe->sample_rate);
+    sl.pinned[b] = ws_num_frames(num_samples[b], fe->sample_rate);
   }
-  WS_HIP_CHECK(hipMemcpyAsync(fe->frames_dev.ptr, fe->frames_pinned, (size_t)batch * sizeof(int),
-                              hipMemcpyHostToDevice, st));
-  WS_HIP_CHECK(hipEventRecord(fe->frames_copied, st));
+  WS_HIP_CHECK(hipMemcpyAsync(sl.dev.ptr, sl.pinned, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, st));
   WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, max_samples, wav_stride, scale, window_type, T,
-                            feats, st, fe->frames_dev.as<int>()));
-  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st, fe->frames_dev.as<int>()));
+                            feats, st, sl.dev.as<int>()));
+  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st, sl.dev.as<int>()));
+  WS_HIP_CHECK(hipEventRecord(sl.done, st));
+  sl.used = true;
   return WS_OK;
 }
 

@@ -324,13 +324,7 @@ static hipError_t launch_direct_f32(const ConvGemmParams& p, hipStream_t stream)
   const int pyb = (p.Hout + PH - 1) / PH, pxb = (p.Wout + PW - 1) / PW;
   const long long total = (long long)images * pyb * pxb;
   if (total <= 0) return hipSuccess;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess)
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
+  const int cus = current_device_cus();
   const size_t by_lds = 160 * 1024 / lds;
   long long blocks = (long long)cus * (by_lds < 2 ? by_lds : 2);   // 144 weight VGPRs: two workgroups per CU
   if (blocks > total) blocks = total;
@@ -376,13 +370,7 @@ static hipError_t launch_direct(const ConvGemmParams& p, hipStream_t stream) {
   const int pyb = (p.Hout + PH - 1) / PH, pxb = (p.Wout + PW - 1) / PW;
   const long long total = (long long)images * pyb * pxb;
   if (total <= 0) return hipSuccess;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess)
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
+  const int cus = current_device_cus();
   // resident workgroups per CU: the VGPR budget allows 8 wavefronts (2 x 4 waves for C = 32, 1 x 8 for 64)
   const size_t by_lds = 160 * 1024 / lds;
   const size_t by_regs = C == 32 ? 2 : 1;

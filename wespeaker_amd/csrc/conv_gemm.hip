@@ -1871,13 +1871,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   const bool simple_geom = p.kh == 1 && p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 &&
                            p.pad_w == 0 && p.K % BK == 0 && p.K == p.Cin;
   const int mode = p.A2 ? 1 : (p.pre_scale ? (simple_geom ? 4 : 2) : (simple ? 3 : 0));
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess)
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = 2 * cus;
-  }
+  const int slots = 2 * current_device_cus();
   // fp32 back-end, plain 1x1 layer with a bias / ReLU / BN epilogue: whole rounds of 128x128 tiles go to the
   // persistent kernel (gemm_f32_stream.hip), the remaining rows re-enter below with m_begin set
   if constexpr (PREC == 0) {

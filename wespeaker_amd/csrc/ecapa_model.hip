@@ -263,7 +263,7 @@ struct EcapaModel : ModelBase {
       WS_LAUNCH(other(4.0 * B * (double)T * 1536, st, [&] {
         if (stats_from_colsum && h_half)
           return launch_astp_std_from_colsum_f16(h16, 1536, B, T, 1536, colsum, stats, st, L0);
-        if (stats_from_sums) return launch_astp_std_from_sums(colsum, colsumsq, B, T, 1536, stats, st);
+        if (stats_from_sums) return launch_astp_std_from_sums(colsum, colsumsq, B, T, 1536, stats, st, h, 1536);
         if (stats_from_colsum) return launch_astp_std_from_colsum(h, 1536, B, T, 1536, colsum, stats, st, L0);
         return launch_astp_stats(h, 1536, B, T, 1536, stats, st, L0);
       }));

@@ -420,10 +420,14 @@ hipError_t launch_colsumsq_rows(const float* D, int ldd, int d_off, int m_begin,
 }
 
 // ASTP global context from the GEMM epilogue's column sums AND sums of squares: mean = S1 / T,
-// std = sqrt((S2 - T mean^2) / (T - 1) + 1e-7) (pooling_layers.py:128-133, unbiased).  No pass over h at all.
+// std = sqrt((S2 - T mean^2) / (T - 1) + 1e-7) (pooling_layers.py:128-133, unbiased).  No pass over h -- unless the
+// single-pass form has cancelled: the fp32 sums carry ~1e-6 of S2 as error, so when S2 - T mean^2 < 1e-3 S2 (a channel
+// whose std is below ~3 % of its mean: rare behind a ReLU, but torch.var is two-pass and would get it right) the
+// variance of that one (utterance, channel) is recomputed from its T values of h around the mean.
 __global__ __launch_bounds__(256) void astp_std_from_sums_kernel(const float* __restrict__ colsum,
                                                                  const float* __restrict__ colsumsq, int T, int C,
-                                                                 float* __restrict__ stats) {
+                                                                 float* __restrict__ stats,
+                                                                 const float* __restrict__ h, int ldh) {
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
@@ -435,16 +439,28 @@ __global__ __launch_bounds__(256) void astp_std_from_sums_kernel(const float* __
     s2 += colsumsq[((long long)tm * 2 + which) * C + c];
   }
   const float mean = s1 / (float)T;
-  const float var = fmaxf(s2 - (float)T * mean * mean, 0.f) / (float)(T - 1);
+  float ss = s2 - (float)T * mean * mean;
+  if (h && ss < 1e-3f * s2) {                      // cancelled: two-pass on this column
+    const float* col = h + r0 * ldh + c;
+    float a0 = 0.f, a1 = 0.f;
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      const float d0 = col[(long long)t * ldh] - mean, d1 = col[(long long)(t + 1) * ldh] - mean;
+      a0 += d0 * d0; a1 += d1 * d1;
+    }
+    if (t < T) { const float d0 = col[(long long)t * ldh] - mean; a0 += d0 * d0; }
+    ss = a0 + a1;
+  }
+  const float var = fmaxf(ss, 0.f) / (float)(T - 1);
   stats[(long long)b * 2 * C + c] = mean;
   stats[(long long)b * 2 * C + C + c] = sqrtf(var + 1e-7f);
 }
 
 hipError_t launch_astp_std_from_sums(const float* colsum, const float* colsumsq, int B, int T, int C, float* stats,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const float* h, int ldh) {
   if (T < 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(astp_std_from_sums_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, stream, colsum, colsumsq, T, C,
-                     stats);
+                     stats, h, ldh);
   return hipGetLastError();
 }
 

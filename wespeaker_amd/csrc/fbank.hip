@@ -51,14 +51,8 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
   if (T <= 0 || B <= 0) return hipSuccess;
   if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128)
     return hipErrorInvalidValue;
-  // the longest triangular filter must fit the mel phase's 12 x 4 taps
   const long long total = (long long)B * T;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
+  const int cus = current_device_cus();
   long long blocks = (total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const long long resident = (long long)cus * 6;         // ~26 KB of LDS per workgroup: six per CU
   if (blocks > resident) blocks = resident;

@@ -55,9 +55,7 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 #if defined(__HIP_DEVICE_COMPILE__)
   // this wavefront's fragment reads of the stage are complete, its DMA pieces of the next stage have landed
   // (all but the N newest VMEM operations), then the workgroup barrier
-#ifdef WS_EXPERIMENT_NOBARRIER      // timing experiment only (results are wrong): what does the rendezvous cost?
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-#elif defined(WS_TRACE)             // the wait and the rendezvous stamped separately (slot 176: after the wait)
+#if defined(WS_TRACE)               // the wait and the rendezvous stamped separately (slot 176: after the wait)
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
   if (g_trace_split && blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 256))
     g_stream_trace[176 + threadIdx.x] = __builtin_readcyclecounter();
@@ -174,7 +172,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       const int row = q * 8 + r8;
       const int c = c8 ^ ((row >> 1) & 7);
       const int ld = isw ? p.ldw : p.lda, off = isw ? 0 : p.a_off, row0 = isw ? n0 : m0;
-      voff[i] = (unsigned)(((row0 + row) * ld + off) * 4 + c * 16);
+      voff[i] = (unsigned)(((unsigned long long)(row0 + row) * ld + off) * 4ull + c * 16);   // (< 2^32: the guard)
     }
   };
   int pf_seq = 0, pf_kt = 0, pf_stage = 0;
@@ -279,8 +277,8 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     t.vec = reinterpret_cast<const float*>(vec_w + (seq & 1) * (3 * 64 * 4));
     t.nblk = n0 + wn * 32 * TN;
     t.ncol = t.nblk + c8 * 4;
-    t.dvoff = (unsigned)(((mh + r8) * p.ldd + p.d_off + t.ncol) * 4);
-    t.d2voff = p.D2 ? (unsigned)(((mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4) : 0u;
+    t.dvoff = (unsigned)(((unsigned long long)(mh + r8) * p.ldd + p.d_off + t.ncol) * 4ull);
+    t.d2voff = p.D2 ? (unsigned)(((unsigned long long)(mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4ull) : 0u;
     t.rb = COLSUM ? (mh / HW + 1) * HW - mh : 64;
     t.t64 = mh >> 6;
   };

@@ -7,6 +7,21 @@
 
 namespace wsamd {
 
+// Compute units of the CURRENT device, cached per device id (grids and cost models are sized by it; a process may
+// drive several GPUs with different counts).
+inline int current_device_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cache[dev]) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cache[dev] = cus > 0 ? cus : 256;
+  }
+  return cache[dev];
+}
+
+
 // Opt-in to more than 64 KB of dynamic LDS: hipFuncSetAttribute acts on the CURRENT device's copy of the kernel, so
 // "done" is remembered per (kernel, device) -- a per-kernel `static bool` let the second GPU of a process launch
 // without the attribute (one process per GPU is how this library is deployed, but the C-ABI takes a device index).
@@ -159,7 +174,7 @@ hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, in
                                        const int* lens = nullptr);
 // the same statistics from column sums + sums of squares (ConvGemmParams::colsumsq): no pass over h
 hipError_t launch_astp_std_from_sums(const float* colsum, const float* colsumsq, int B, int T, int C, float* stats,
-                                     hipStream_t stream);
+                                     hipStream_t stream, const float* h = nullptr, int ldh = 0);
 // sums of squares of rows [m_begin, M) of a stored layer output, colsum layout (the rows the persistent GEMM left)
 hipError_t launch_colsumsq_rows(const float* D, int ldd, int d_off, int m_begin, int M, int HW, int N,
                                 float* colsumsq, hipStream_t stream);

@@ -389,15 +389,7 @@ static constexpr int chain_cap(int W, int MTW) { return (8 / (W / 16)) * MTW * 1
 // would leave most CUs idle -- a chain is 7 serial steps of ~10 us whatever the batch, so a lone utterance is
 // spread over three or four workgroups instead of one
 static int chain_mtw(int W, bool small) { return W == 64 ? (small ? 4 : 7) : (small ? 7 : 13); }
-static int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
-  return cus;
-}
+static int device_cus() { return current_device_cus(); }
 // tiles per utterance / owned rows per tile for frames T (whole utterance in one workgroup when it fits)
 static void chain_tiling_for(int cap, int T, int dil, int* tiles, int* tile_rows) {
   if (T <= cap) { *tiles = 1; *tile_rows = cap; return; }
