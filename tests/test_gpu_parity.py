@@ -787,7 +787,7 @@ def test_persistent_fp32_gemm_against_the_tile_kernels(tmp_path):
 
 
 @pytest.mark.parametrize("switch", ["WS_DIRECT3X3_F32=0", "WS_NO_STD_FROM_SUMS=1", "WS_NO_IM2COL=1", "WS_ASTP_FUSED=0",
-                                    "WS_NO_POOL_FUSE=1"])
+                                    "WS_NO_POOL_FUSE=1", "WS_CAM_FUSED=0"])
 def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
     """Every environment A/B switch of DESIGN.md 7.1 that selects another kernel for the same arithmetic: the models
     it touches, full-size batches (so that the shipped side does take the kernel in question), switched against shipped.
@@ -799,7 +799,8 @@ def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
               "WS_NO_STD_FROM_SUMS=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'),)",
               "WS_NO_IM2COL=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'), ('ECAPA_TDNN_c1024', 192, 128, 'fp32'))",
               "WS_ASTP_FUSED=0": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'), ('ECAPA_TDNN_c512', 192, 256, 'fp32'))",
-              "WS_NO_POOL_FUSE=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'f16'),)"}[switch]
+              "WS_NO_POOL_FUSE=1": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'f16'),)",
+              "WS_CAM_FUSED=0": "(('CAMPPlus', 512, 96, 'fp32'),)"}[switch]
     script = tmp_path / "ab.py"
     script.write_text(
         "import sys, numpy as np, torch\n"
@@ -817,7 +818,8 @@ def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
     res = {}
     for tag in ("shipped", "switched"):
         env = dict(os.environ, PYTHONPATH=root)
-        for k in ("WS_DIRECT3X3_F32", "WS_NO_STD_FROM_SUMS", "WS_NO_IM2COL", "WS_ASTP_FUSED", "WS_NO_POOL_FUSE"):
+        for k in ("WS_DIRECT3X3_F32", "WS_NO_STD_FROM_SUMS", "WS_NO_IM2COL", "WS_ASTP_FUSED", "WS_NO_POOL_FUSE",
+                  "WS_CAM_FUSED"):
             env.pop(k, None)
         if tag == "switched":
             k, v = switch.split("=")
@@ -1572,6 +1574,10 @@ RAGGED_CASES = [("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 399, 5, 201]),
                 ("ECAPA_TDNN_c1024", 192, [600, 450]),
                 ("ResNet34", 256, [1001, 640, 431]),
                 ("CAMPPlus", 512, [1500, 1001, 777]),
+                # <= 256 frames = <= 128 trunk frames: the one-kernel dense layer (cam_dense.hip) with per-utterance
+                # lengths, one and two context segments (trunk lengths 125, 99, 66, 29, 4, 102), and a full 128
+                ("CAMPPlus", 512, [250, 198, 131, 57, 7, 203]),
+                ("CAMPPlus", 512, [256, 255, 201, 200]),
                 # 160 < T <= 208: the one-kernel attentive pooling (astp_fused.hip) with per-utterance lengths,
                 # a full 208-frame window, and its shortest window
                 ("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 208, 5, 203]),

@@ -1,0 +1,297 @@
+// One CAM++ dense layer as ONE kernel (fp32 back-end, utterances of <= 128 trunk frames).
+//
+// Replaces the four launches per layer of CAMDenseTDNNLayer.forward (wespeaker/models/campplus.py:138-170) /
+// CAMLayer.forward (:86-135):
+//     x -> BN-ReLU -> Conv1d(C_i -> 128, k1) -> BN-ReLU = h
+//     m = sigmoid(W2 relu(W1 (mean_T(h) + segmean_100(h)) + b1) + b2)            (per utterance and 100-frame segment)
+//     y = Conv1d(128 -> 32, k3, dilation d)(h) * m ;  x = cat(x, y)
+// Round 3 ran them as GEMM (C_i -> 128, 128 x 128 tiles over the batch) -> context kernel -> GEMM (k3, N = 32 tiles)
+// with h making a round trip through HBM: 52 layers x 3 launches of 7 - 100 us, the k3 GEMM at 0.14 of the MFMA peak
+// (N = 32: 396 tiles of a few us) and 728 context launches of 7 us -- a dispatcher-bound 0.5 of the fp32 MFMA peak
+// for the whole model.
+//
+// Here a workgroup owns one UTTERANCE (T' <= 128 rows = one 128-row tile; two workgroups share a CU):
+//   1. h = the 128 x 128 tile of the 1x1 convolution: K loop over C_i in 32-wide K-tiles, A (with the pre-activation
+//      BN-ReLU applied while staging) and W1 through a double-buffered LDS stage, v_mfma_f32_32x32x2_f32, one
+//      32-row block x four 32-column blocks per wavefront;
+//   2. bias + ReLU, rows beyond the utterance's frames zeroed, h parked in LDS (over the stages) with two zero halo
+//      rows on either side; column means per segment -> the two context FCs -> the mask, all in LDS;
+//   3. the dilated k3 convolution straight from the LDS copy of h (the taps are row shifts), weights prefetched from
+//      L2 through a register ring, times the mask, 32 channels appended to x at the layer's channel offset.
+// h never leaves the CU; 52 launches instead of 208.
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace wsamd {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CD_BK = 32;                  // K-tile
+constexpr int CD_S = CD_BK + 4;            // stage row stride (floats): conflict-free 16-B fragment reads
+constexpr int CD_HS = 132;                 // row stride of the LDS copy of h
+constexpr int CD_HALO = 2;                 // zero rows before / behind h (dilation <= 2)
+constexpr int CD_STAGE_FLOATS = 2 * 128 * CD_S;                    // A rows + W rows of one stage
+constexpr int CD_MAIN_FLOATS = 2 * CD_STAGE_FLOATS;                // two stages; h (132 x 132) lives over them
+constexpr int CD_SMALL_FLOATS = 2 * 2 * 128 + 2 * 128 + 2 * 64 + 2 * 32;   // partial sums, ctx, hidden, mask
+static_assert((128 + 2 * CD_HALO) * CD_HS <= CD_MAIN_FLOATS, "h fits over the stages");
+constexpr size_t CD_LDS_BYTES = (size_t)(CD_MAIN_FLOATS + CD_SMALL_FLOATS) * 4;
+
+__global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const small = lds + CD_MAIN_FLOATS;
+  float* const part = small;                       // [2 row parities][2 segments][128]
+  float* const ctx = part + 2 * 2 * 128;           // [2 segments][128]
+  float* const hid = ctx + 2 * 128;                // [2][64]
+  float* const maskv = hid + 2 * 64;               // [2][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x;
+  const int Tp = p.Tp;
+  const int len = p.lens ? p.lens[b] : Tp;         // this utterance's frames (<= Tp <= 128)
+  const long long row0 = (long long)b * Tp;
+  const int nk = p.cin / CD_BK;
+
+  // ------------------------------------------------------------------ 1. h = relu(W1 . relu(bn(x)) + b1)
+  const int kc = tid & 7, r0 = tid >> 3;           // this thread's 16-B chunk column and first row of a stage
+  const float* a_ptr[4];
+  const float* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = r0 + 32 * i;
+    row = row < Tp ? row : Tp - 1;                 // (rows beyond the utterance are zeroed in h: any finite value)
+    a_ptr[i] = p.X + (row0 + row) * p.ldx + kc * 4;
+    w_ptr[i] = p.W1 + (long long)(r0 + 32 * i) * p.ldw1 + kc * 4;
+  }
+  const float* ps_ptr = p.pre_s + kc * 4;
+  const float* pb_ptr = p.pre_b + kc * 4;
+  // two sets of staging registers: K-tile kt + 2 is requested at the top of K-tile kt and staged into LDS during
+  // K-tile kt + 1 (one K-tile of lead -- ~1.7 us with two workgroups per CU -- did not cover the HBM round trip)
+  f32x4 ra[2][4], rw[2][4], s4[2], b4[2];
+  auto load_tile = [&](int set) {
+    s4[set] = *reinterpret_cast<const f32x4*>(ps_ptr);
+    b4[set] = *reinterpret_cast<const f32x4*>(pb_ptr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[set][i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
+      rw[set][i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
+      a_ptr[i] += CD_BK; w_ptr[i] += CD_BK;
+    }
+    ps_ptr += CD_BK; pb_ptr += CD_BK;
+  };
+  // staging piece j of the K-tile in register set `set`: 0..3 = pre-activation of A chunk j, 4..7 = its LDS store,
+  // 8..11 = the W chunks (each small enough for the shadow of one MFMA)
+  auto store_piece = [&](int buf, int set, int j) {
+    float* As = lds + buf * CD_STAGE_FLOATS;
+    float* Ws = As + 128 * CD_S;
+    if (j < 4) {
+      f32x4 v = ra[set][j] * s4[set] + b4[set];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+      ra[set][j] = v;
+    } else if (j < 8) {
+      *reinterpret_cast<f32x4*>(&As[(r0 + 32 * (j - 4)) * CD_S + kc * 4]) = ra[set][j - 4];
+    } else if (j < 12) {
+      *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * (j - 8)) * CD_S + kc * 4]) = rw[set][j - 8];
+    }
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int in = 0; in < 4; ++in)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[in][r] = 0.f;
+  // fragments of one k-group (8 k): the wavefront's 32 rows of A, all 128 rows of W; two register slots
+  f32x4 fa[2], fw[2][4];
+  auto frag_read = [&](int buf, int g, int slot, int j) {        // j = 0: A, 1..4: W block j - 1
+    const float* As = lds + buf * CD_STAGE_FLOATS + (32 * wave + li) * CD_S + lh * 4 + g * 8;
+    const float* Ws = lds + buf * CD_STAGE_FLOATS + 128 * CD_S + li * CD_S + lh * 4 + g * 8;
+    if (j == 0) fa[slot] = *reinterpret_cast<const f32x4*>(As);
+    else fw[slot][j - 1] = *reinterpret_cast<const f32x4*>(&Ws[(j - 1) * 32 * CD_S]);
+  };
+  // the 16 MFMAs of the k-group in `slot`; filler(i) is issued behind MFMA i (an fp32 32x32x2 MFMA holds the matrix
+  // pipe for 64 cycles: LDS reads / stores and the pre-activation maths of the next K-tile ride in its shadow --
+  // left to itself hipcc puts them between the K-tiles, where the two workgroups of a CU, running in lock step,
+  // both idle the pipe: 0.66 of the MFMA rate inside the loop)
+  auto mma = [&](int slot, auto&& filler) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int in = 0; in < 4; ++in) {
+        acc[in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][in][s], fa[slot][s], acc[in], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        filler(s * 4 + in);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  load_tile(0);
+  if (nk > 1) load_tile(1);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) store_piece(0, 0, j);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 5; ++j) frag_read(0, 0, 0, j);
+  int buf = 0;
+  // K-tile kt: its MFMAs; K-tile kt + 1 (register set (kt + 1) & 1) goes to LDS stage buf ^ 1 behind them; K-tile
+  // kt + 2 is requested into the set K-tile kt came from
+  auto ktile = [&](int kt, auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;  // kt & 1
+    const bool more = kt + 1 < nk;                 // (uniform)
+    if (kt + 2 < nk) load_tile(PAR);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, [&](int i) { if (i >= 8 && i < 13) frag_read(buf, 1, 1, i - 8); });
+    mma(1, [&](int i) { if (i >= 8 && i < 13) frag_read(buf, 2, 0, i - 8); });
+    mma(0, [&](int i) {                            // g2: fragments of g3 + the staging of K-tile kt + 1
+      if (i < 5) frag_read(buf, 3, 1, i);
+      else if (more) store_piece(buf ^ 1, PAR ^ 1, i - 5);             // pieces 0 .. 10
+    });
+    if (more) store_piece(buf ^ 1, PAR ^ 1, 11);
+    // stage buf^1 complete; nobody reads stage buf any more (g3 is in registers).  NOT __syncthreads(): its fence
+    // waits for vmcnt(0), i.e. for the global loads of K-tile kt + 2 that were just sent ahead
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+    mma(1, [&](int i) { if (more && i < 5) frag_read(buf, 0, 0, i); });
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
+  }
+  __syncthreads();                                 // every wavefront has left the stages: h goes over them
+
+  // ------------------------------------------------------------------ 2. h -> LDS, context mask
+  float* const Hs = lds;                           // [(128 + 2 halo)][CD_HS], row t at index t + CD_HALO
+  {
+    const int t = 32 * wave + li;
+    const bool valid = t < len;
+#pragma unroll
+    for (int in = 0; in < 4; ++in)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = 32 * in + 8 * g + 4 * lh;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + n0);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(acc[in][4 * g + r] + bias[r]) : 0.f;
+        *reinterpret_cast<f32x4*>(&Hs[(t + CD_HALO) * CD_HS + n0]) = v;
+      }
+    // halo rows: 0, 1 and 130, 131 (4 rows x 128 floats)
+    for (int i = tid; i < 4 * 128; i += 256) {
+      const int hr = i >> 7, c = i & 127;
+      Hs[(hr < 2 ? hr : 128 + hr) * CD_HS + c] = 0.f;
+    }
+  }
+  // the first weight fragments of the k3 convolution: in flight while the mask is computed
+  constexpr int RING = 8;
+  f32x4 wl[RING];
+  const float* wl_ptr = p.Wl + (long long)li * p.ldwl + lh * 4;      // row o = li, K offset 8 j + 4 lh
+#pragma unroll
+  for (int j = 0; j < RING; ++j) wl[j] = *reinterpret_cast<const f32x4*>(wl_ptr + 8 * j);
+  __syncthreads();
+  const int nseg = len > 100 ? 2 : 1;              // (T' <= 128: at most two 100-frame segments)
+  {
+    const int c = tid & 127, par = tid >> 7;
+    float s0 = 0.f, s1 = 0.f;
+    const int e0 = len < 100 ? len : 100;
+    for (int t = par; t < e0; t += 2) s0 += Hs[(t + CD_HALO) * CD_HS + c];
+    for (int t = 100 + par; t < len; t += 2) s1 += Hs[(t + CD_HALO) * CD_HS + c];
+    part[(par * 2 + 0) * 128 + c] = s0;
+    part[(par * 2 + 1) * 128 + c] = s1;
+  }
+  __syncthreads();
+  {
+    const int c = tid & 127, s = tid >> 7;         // ctx[s][c] = mean over the utterance + mean over segment s
+    const float a0 = part[c] + part[2 * 128 + c], a1 = part[128 + c] + part[3 * 128 + c];
+    const int n_s = s == 0 ? (len < 100 ? len : 100) : len - 100;
+    ctx[s * 128 + c] = n_s > 0 ? (a0 + a1) / (float)len + (s == 0 ? a0 : a1) / (float)n_s : 0.f;
+  }
+  __syncthreads();
+  for (int s = 0; s < nseg; ++s) {                 // hid[s][j] = relu(cw1[j] . ctx[s] + cb1[j]): 4 lanes per j
+    const int j = tid >> 2, q = tid & 3;
+    const float* wr = p.cw1 + j * 128 + q * 32;
+    const float* cx = ctx + s * 128 + q * 32;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k);
+      v += w4[0] * cx[k] + w4[1] * cx[k + 1] + w4[2] * cx[k + 2] + w4[3] * cx[k + 3];
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if (q == 0) hid[s * 64 + j] = relu_f(v + p.cb1[j]);
+  }
+  __syncthreads();
+  if (tid < 64) {                                  // mask[s][o] = sigmoid(cw2[o] . hid[s] + cb2[o])
+    const int s = tid >> 5, o = tid & 31;
+    float m = 0.f;
+    if (s < nseg) {
+      const float* wr = p.cw2 + o * 64;
+      float v = p.cb2[o];
+      for (int k = 0; k < 64; ++k) v += wr[k] * hid[s * 64 + k];
+      m = 1.f / (1.f + expf(-v));
+    }
+    maskv[s * 32 + o] = m;
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ 3. y = conv_k3(h) * mask, appended to x
+  f32x16 y;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) y[r] = 0.f;
+  {
+    const int t = 32 * wave + li;
+    const float* hrow = Hs + (t + CD_HALO) * CD_HS + lh * 4;
+#pragma unroll
+    for (int j = 0; j < 48; ++j) {                 // K = 3 taps x 128 channels in steps of 8
+      const int tap = j >> 4, g = j & 15;
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(hrow + (tap - 1) * p.dil * CD_HS + g * 8);
+      const f32x4 fw = wl[j % RING];
+      if (j + RING < 48) wl[j % RING] = *reinterpret_cast<const f32x4*>(wl_ptr + 8 * (j + RING));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[s], fa[s], y, 0, 0, 0);
+    }
+    if (t < Tp) {
+      const float* mrow = maskv + (t >= 100 ? 32 : 0);
+      float* orow = p.Xout + (row0 + t) * p.ldx + p.c_off;
+      const bool valid = t < len;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int o0 = 8 * g + 4 * lh;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = valid ? y[4 * g + r] * mrow[o0 + r] : 0.f;
+        *reinterpret_cast<f32x4*>(orow + o0) = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool cam_dense_fused_applies(int Tp, int cin, int dil) {
+  static const int off = [] { const char* e = getenv("WS_CAM_FUSED"); return e && atoi(e) == 0 ? 1 : 0; }();
+  return !off && Tp >= 1 && Tp <= 128 && cin >= CD_BK && cin % CD_BK == 0 && dil >= 1 && dil <= CD_HALO;
+}
+
+hipError_t launch_cam_dense_layer(const CamDenseParams& p, int B, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  if (!cam_dense_fused_applies(p.Tp, p.cin, p.dil) || (p.ldx & 3) || (p.c_off & 3) || (p.ldw1 & 3) || (p.ldwl & 3) ||
+      p.ldwl < 3 * 128)
+    return hipErrorInvalidValue;
+  if (dispatch_log_enabled()) {
+    char key[200];
+    snprintf(key, sizeof(key), "CAM dense layer: utterances=%d T'=%d Cin=%d dil=%d prec=0%s -> cam_dense_layer_kernel", B, p.Tp,
+             p.cin, p.dil, p.lens ? " +mask" : "");
+    dispatch_log_note_text(key);
+  }
+  static size_t granted[WS_MAX_DEVICES] = {};
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cam_dense_layer_kernel), CD_LDS_BYTES, granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cam_dense_layer_kernel, dim3(B), dim3(256), CD_LDS_BYTES, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace wsamd

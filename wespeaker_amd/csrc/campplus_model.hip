@@ -237,6 +237,23 @@ struct CamppModel : ModelBase {
     for (int k = 0; k < 3; ++k) {
       for (size_t j = 0; j < layers[k].size(); ++j) {
         const DenseLayerW& L = layers[k][j];
+        // fp32, utterances of <= 128 trunk frames: the whole layer is one kernel, one workgroup per utterance
+        if (gemm_precision == 0 && cam_dense_fused_applies(Tp, L.cin, kDil[k])) {
+          CamDenseParams cp = {};
+          cp.X = X; cp.Xout = X; cp.ldx = ldx; cp.cin = L.cin; cp.c_off = L.cin; cp.Tp = Tp; cp.lens = L1;
+          cp.pre_s = arena.at(L.pre_s); cp.pre_b = arena.at(L.pre_b);
+          cp.W1 = arena.at(L.lin1.w); cp.b1 = arena.at(L.lin1.b); cp.ldw1 = L.lin1.ldw;
+          cp.Wl = arena.at(L.local.w); cp.ldwl = L.local.ldw;
+          cp.cw1 = arena.at(L.cw1); cp.cb1 = arena.at(L.cb1); cp.cw2 = arena.at(L.cw2); cp.cb2 = arena.at(L.cb2);
+          cp.dil = kDil[k];
+          if (prof.enabled)
+            prof.begin(0, 2.0 * B * (double)Tp * (128.0 * L.cin + 3.0 * 128 * 32),
+                       4.0 * (B * (double)Tp * (L.cin + 32) + 128.0 * L.cin + 3.0 * 128 * 32), st);
+          hipError_t ce = launch_cam_dense_layer(cp, B, st);
+          prof.end(st);
+          WS_LAUNCH(ce);
+          continue;
+        }
         // BN-ReLU -> 1x1 (Cin -> 128) -> BN -> ReLU
         ConvGemmParams p1 = conv1d(L.lin1, X, ldx, 0, hbuf, 128, 0, B, Tp, 1, ACT_RELU);
         p1.pre_scale = arena.at(L.pre_s); p1.pre_shift = arena.at(L.pre_b);

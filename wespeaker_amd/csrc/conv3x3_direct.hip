@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   constexpr int NP = (RP + PXP - 1) / PXP;       // 1-KiB pieces (8 pixels of 128 B)
   constexpr int PPW = (NP + NWV - 1) / NWV;
   constexpr int STAGE = NP * 1024;
+  constexpr int ISSUE_UNROLL = PPW <= 6 ? PPW : 2;   // (the strided region has 10 pieces per wavefront: unrolled, their
+                                                       // address arithmetic spills beside the 144 weight registers)
   typedef float f32x4d __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char lds_d[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     const int pyi = t % pyb, img = t / pyb;
     const int iy0 = pyi * PH * SH - 1, ix0 = pxi * PW * SW - 1;
     char* base = lds_d + stage * STAGE;
-#pragma unroll
+#pragma unroll ISSUE_UNROLL
     for (int k = 0; k < PPW; ++k) {
       int pi = wave * PPW + k;
       if (pi > NP - 1) pi = NP - 1;              // surplus slots repeat the last piece
@@ -240,17 +242,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   // ---- compute roles: lane li -> patch pixel (row 2 wave + li / 16, col li % 16)
   const int ppy = 2 * wave + (li >> 4), ppx = li & 15;
   const int q0 = ppy * SH * IW + ppx * SW;       // region pixel of tap (0, 0)
+  // the bias lives in LDS behind the two stages (no registers to spare beside the 144 weight registers; a global
+  // load per patch, as in round 3, is a ~500-cycle round trip in the exposed epilogue)
+  float* const bias_s = reinterpret_cast<float*>(lds_d + 2 * STAGE);
+  if (tid < 32) bias_s[tid] = p.bias ? p.bias[tid] : 0.f;
+  __syncthreads();
 
   int stage = 0;
   int patch = blockIdx.x;
   if (patch < total) issue(patch, 0);
+  bool stores_pending = false;                   // (wave-uniform) the previous patch's four row stores were issued
   for (; patch < total; patch += gridDim.x) {
     // ONE rendezvous per patch: this patch's pieces have landed, and everybody is done with the previous patch -- its
-    // stage is free for the next patch's pieces, which then have a whole patch time to arrive
-    wait_vm_barrier<0>();
+    // stage is free for the next patch's pieces, which then have a whole patch time to arrive.  The previous patch's
+    // output stores were issued BEHIND those pieces (VMEM operations retire in order), so they may stay in flight:
+    // round 3 waited for them too (vmcnt(0)) and paid a store round trip per patch.
+    if (stores_pending) wait_vm_barrier<4>();
+    else wait_vm_barrier<0>();
     const int next = patch + gridDim.x;
     if (next < total) issue(next, stage ^ 1);
     const char* base = lds_d + stage * STAGE;
+    const int pxi = patch % pxb, t = patch / pxb;
+    const int pyi = t % pyb, img = t / pyb;
+    const int oy = pyi * PH + ppy, ox = pxi * PW + ppx;
+    const bool inside = oy < p.Hout && ox < p.Wout;
+    const long long m = ((long long)img * p.Hout + (inside ? oy : 0)) * p.Wout + (inside ? ox : 0);
     f32x16d acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -271,26 +287,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
       __builtin_amdgcn_sched_barrier(0);
     }
     // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh
-    const int pxi = patch % pxb, t = patch / pxb;
-    const int pyi = t % pyb, img = t / pyb;
-    const int oy = pyi * PH + ppy, ox = pxi * PW + ppx;
-    if (oy < p.Hout && ox < p.Wout) {
-      const long long m = ((long long)img * p.Hout + oy) * p.Wout + ox;
-      const bool padded = p.row_len && ox >= p.row_len[img];
+    const bool padded = p.row_len && ox >= p.row_len[img];
+    float* const drow = p.D + m * p.ldd + p.d_off + 4 * lh;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ch = 8 * j + 4 * lh;
-        f32x4d v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
-        if (p.bias) v += *reinterpret_cast<const f32x4d*>(p.bias + ch);
-        if (p.residual) v += *reinterpret_cast<const f32x4d*>(p.residual + m * p.ldr + p.r_off + ch);
-        if (p.act == ACT_RELU) {
+    for (int j = 0; j < 4; ++j) {
+      f32x4d v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+      v += *reinterpret_cast<const f32x4d*>(bias_s + 8 * j + 4 * lh);
+      if (p.residual) v += *reinterpret_cast<const f32x4d*>(p.residual + m * p.ldr + p.r_off + 8 * j + 4 * lh);
+      if (p.act == ACT_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-        }
-        if (padded) v = (f32x4d){0.f, 0.f, 0.f, 0.f};     // ragged batch: columns beyond the utterance stay zero
-        *reinterpret_cast<f32x4d*>(p.D + m * p.ldd + p.d_off + ch) = v;
+        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
       }
+      if (padded) v = (f32x4d){0.f, 0.f, 0.f, 0.f};     // ragged batch: columns beyond the utterance stay zero
+      if (inside) *reinterpret_cast<f32x4d*>(drow + 8 * j) = v;
     }
+    // (vmcnt counts wave instructions: the four stores were issued unless no lane of the wavefront was inside)
+    stores_pending = __builtin_amdgcn_ballot_w64(inside) != 0;
     stage ^= 1;
   }
 }
@@ -300,8 +312,9 @@ bool conv3x3_direct_f32_supported(const ConvGemmParams& p) {
   return !off && p.prec == 0 && p.A && p.D && !p.A16 && !p.D16 && !p.A2 && !p.pre_scale && p.Cin == 32 && p.N == 32 &&
          p.K == 288 && p.kh == 3 && p.kw == 3 && p.dil_h == 1 && p.dil_w == 1 && p.pad_h == 1 && p.pad_w == 1 &&
          p.lda == 32 && p.a_off == 0 && (p.ldd & 3) == 0 && (p.d_off & 3) == 0 && p.ldw >= p.K &&
-         p.stride_h == 1 && p.stride_w == 1 &&   // (the strided regions need more DMA-role registers than are left
-                                                 // beside the 144 weight registers: they stay on the tile kernels)
+         // stride (1,1), and CAM++'s frequency-only stride (2,1) (campplus.py:245-330: three FCM convolutions; the
+         // DMA roles are recomputed per patch, so the larger region costs LDS -- 2 x 39 KB -- not registers)
+         p.stride_w == 1 && (p.stride_h == 1 || p.stride_h == 2) &&
          !p.residual16 && !p.colsum && !p.colsumsq && !p.pool_partial &&
          !p.seg_scale && !p.post_scale && !p.bias_img && !p.D2 && p.splitk <= 1 && p.m_begin == 0 &&
          p.act != ACT_TANH && (!p.residual || ((p.ldr & 3) == 0 && (p.r_off & 3) == 0)) &&
@@ -312,7 +325,7 @@ template <int SH, int SW>
 static hipError_t launch_direct_f32(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
   constexpr int NP = (IH * IW + 7) / 8;
-  constexpr size_t lds = 2 * (size_t)NP * 1024;
+  constexpr size_t lds = 2 * (size_t)NP * 1024 + 128;        // two stages + the bias
   static_assert(lds <= 160 * 1024, "two stages fit the LDS");
   auto kern = conv3x3_direct_f32_kernel<SH, SW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
@@ -339,6 +352,7 @@ static hipError_t launch_direct_f32(const ConvGemmParams& p, hipStream_t stream)
 
 hipError_t launch_conv3x3_direct_f32(const ConvGemmParams& p, hipStream_t stream) {
   if (!conv3x3_direct_f32_supported(p)) return hipErrorInvalidValue;
+  if (p.stride_h == 2) return launch_direct_f32<2, 1>(p, stream);
   return launch_direct_f32<1, 1>(p, stream);
 }
 

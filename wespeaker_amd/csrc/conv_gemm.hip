@@ -82,6 +82,10 @@ void dispatch_log_note(const ConvGemmParams& p, const char* kernel) {
   std::lock_guard<std::mutex> lk(g_dlog_mu);
   ++g_dlog[key];
 }
+void dispatch_log_note_text(const char* key) {      // kernels outside the conv-GEMM dispatcher (cam_dense.hip)
+  std::lock_guard<std::mutex> lk(g_dlog_mu);
+  ++g_dlog[key];
+}
 size_t dispatch_log_dump(char* buf, size_t cap) {
   std::lock_guard<std::mutex> lk(g_dlog_mu);
   size_t need = 0;

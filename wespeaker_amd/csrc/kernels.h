@@ -112,6 +112,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 void dispatch_log_enable(bool on);
 bool dispatch_log_enabled();
 void dispatch_log_note(const ConvGemmParams& p, const char* kernel);
+void dispatch_log_note_text(const char* key);
 size_t dispatch_log_dump(char* buf, size_t cap);      // text lines; returns the bytes the full report needs
 void dispatch_log_clear();
 
@@ -224,6 +225,19 @@ hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int 
                               const float* w1, const float* b1, int hidden, const float* w2,
                               const float* b2, int Cout, float* mask, hipStream_t stream,
                               const int* lens = nullptr);
+
+// One CAM++ dense layer as one kernel (cam_dense.hip): x[:, 0:cin) -> 32 channels appended at c_off of the same buffer.
+struct CamDenseParams {
+  const float* X; float* Xout; int ldx, cin, c_off;      // [B*Tp][ldx]
+  int Tp; const int* lens;                                // trunk frames per utterance (<= 128); valid frames or null
+  const float *pre_s, *pre_b;                             // nonlinear1 BN on the layer input [cin]
+  const float *W1, *b1; int ldw1;                         // linear1 with nonlinear2's BN folded: [128][ldw1], [128]
+  const float* Wl; int ldwl;                              // cam_layer.linear_local: [32][tap * 128 + c]
+  const float *cw1, *cb1, *cw2, *cb2;                     // cam_layer.linear1 [64][128], linear2 [32][64]
+  int dil;
+};
+bool cam_dense_fused_applies(int Tp, int cin, int dil);  // (WS_CAM_FUSED=0 switches it off)
+hipError_t launch_cam_dense_layer(const CamDenseParams& p, int B, hipStream_t stream);
 
 // ---- frontend
 struct FbankTables {
