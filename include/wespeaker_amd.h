@@ -212,6 +212,11 @@ WS_API int ws_engine_check_range(ws_engine* eng, ws_stream stream);
  * tests/golden/dispatch_*.txt pin the tables of the BASELINE models. */
 WS_API int ws_debug_dispatch_log(int mode);
 WS_API long long ws_debug_dispatch_report(char* buf, long long cap);
+/* Gather yardstick of bench.py's PLDA roofline (no reference counterpart): out[p] = sum of the row_len doubles of row
+ * idx[p] of `table` -- the row-gather path of ws_plda_llr_pairs (tables resident in L2 / Infinity Cache) with no second
+ * operand.  Device pointers; row_len even. */
+WS_API int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, int64_t n, double* out,
+                               ws_stream stream);
 /* Reproducer switch of the fbank kernel (process-wide; tests and tools/fbank_race_probe.py only -- DESIGN.md 6.0).
  * The round-3 build of runtime/core/frontend/fbank.h:138-198's arithmetic used the packed-fp32 instruction forms in
  * its power-spectrum loop; next to binary16 GEMMs on another stream those returned wrong values in lanes 48..63.

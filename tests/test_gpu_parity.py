@@ -448,6 +448,31 @@ def test_plda_large_tables_take_the_gemm_paths(normalize_length):
         assert np.abs(pr - ref[ie, it]).max() < 1e-8
 
 
+def test_score_plda_orders_long_lists_by_enrollment_model():
+    """score_plda scores a long list ordered by enrollment model (the pair kernel then reads the enrollment row of
+    consecutive trials from L1) and returns the scores in the CALLER's order: a shuffled 20 k-trial list equals the
+    same list scored trial by trial through the oracle, position by position."""
+    from wespeaker_amd import TwoCovPLDA, score_plda
+    p = synth.synth_plda(64, seed=3)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False)
+    emb, _ = synth.synth_embeddings(260, 64, seed=9)
+    enroll = {"m%03d" % i: [emb[i]] for i in range(60)}
+    test = {"t%03d" % i: emb[60 + i] for i in range(200)}
+    rs = np.random.RandomState(4)
+    trials = [("m%03d" % rs.randint(60), "t%03d" % rs.randint(200)) for _ in range(20000)]
+    got = score_plda(plda, enroll, test, trials)
+    e_t = {k: oplda.prepare_enroll(p, v, None, True)[0] for k, v in enroll.items()}
+    t_t = {k: oplda.prepare_test(p, v, None) for k, v in test.items()}
+    for i in range(0, 20000, 97):
+        m, t = trials[i]
+        assert abs(got[i] - oplda.log_likelihood_ratio(p, e_t[m], t_t[t], 1)) < 1e-8, i
+    again = score_plda(plda, enroll, test, sorted(trials))
+    lookup = {}
+    for (m, t), v in zip(sorted(trials), again):
+        lookup[(m, t)] = v
+    assert all(got[i] == lookup[trials[i]] for i in range(0, 20000, 13))       # same kernel, same bits per trial
+
+
 @pytest.mark.parametrize("normalize_length,multisession_avg", [(False, True), (True, False)])
 def test_score_plda_and_eval_sv_files(tmp_path, normalize_length, multisession_avg):
     from wespeaker_amd import TwoCovPLDA, kaldi_io, score_plda

@@ -569,6 +569,15 @@ int ws_debug_dispatch_log(int mode) {
   return WS_OK;
 }
 
+int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, int64_t n, double* out, ws_stream stream) {
+  if (!table || !idx || !out || row_len <= 0 || (row_len & 1) || n < 0) {
+    set_error("ws_debug_row_gather: invalid argument (row_len must be even)");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_row_gather_probe(table, row_len, idx, n, out, (hipStream_t)stream));
+  return WS_OK;
+}
+
 int ws_debug_fbank_mode(int mode) {
   if (mode < 0 || mode > 1) {
     set_error("ws_debug_fbank_mode: mode %d (0 shipped kernel, 1 packed-fp32 reproducer build)", mode);

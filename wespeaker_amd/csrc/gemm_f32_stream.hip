@@ -92,7 +92,12 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // lives in the stage that the tile's last K-tile has just left, inside the slice that the SAME wavefront's next
 // DMA pieces will overwrite (nobody else touches it in between), and (b) the bias / scale / shift values are not
 // kept for all N columns: every wavefront DMAs the 3 x 64 values of ITS columns at the start of each tile.
-template <int WM, int TN, int COLSUM>       // COLSUM: 0 none, 1 column sums, 2 column sums + sums of squares
+// RES (round 4): the residual of a ResNet Bottleneck's third convolution (wespeaker/models/resnet.py:72-107:
+// out = relu(bn3(conv3(.)) + shortcut(x))) is added in the epilogue, (acc + bias) + residual -> ReLU like the tile
+// kernels (same bits).  Its rows -- the same 128-B row segments the block's stores write -- are requested into
+// registers one K-tile ahead of the tile's last K-tile (16 or 8 raw buffer loads per wavefront in the free MFMA gaps
+// of k-groups 1 and 2) and consumed in epilogue steps 5..8.
+template <int WM, int TN, int COLSUM, bool RES = false>       // COLSUM: 0 none, 1 column sums, 2 column sums + sums of squares
 __global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
   constexpr int WN = 4 / TN;                 // wavefront columns
@@ -126,6 +131,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   constexpr bool DEFER = GM == 16;
   constexpr int WAITN_SECOND = DEFER ? NP + 4 + COLSUM * 2 * TN : NP;
   static_assert(WAITN_FIRST < 64, "vmcnt is six bits");
+  static_assert(!RES || (2 * TN * 4 <= GM && NP + 2 * TN * 4 < 64), "the residual loads fit the free gaps of g1 / g2");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
 
@@ -254,6 +260,8 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.D, 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t d2_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.D2 ? p.D2 : p.D, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      RES ? const_cast<float*>(p.residual) : p.D, 0, 0xffffffff, 0x00020000);
   // ReLU as ONE integer max per value: the int image of a float is >= 0 exactly for +0, positive values, +inf and
   // positive NaNs, so max(bits, 0) maps every negative value (and -0) to +0 and keeps NaN a NaN like relu_f
   // does; without an activation the bound is INT_MIN (identity)
@@ -262,6 +270,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   struct TileOut {
     unsigned dvoff;        // byte offset of D[m0 + wm*64 + r8][d_off + n0 + wn*32*TN + 4 c8]
     unsigned d2voff;       // the same for D2 (columns n - d2_col0)
+    unsigned rvoff;        // the same for the residual
     const float* vec;      // this wavefront's [bias | scale | shift][64] slots of the tile
     int ncol;              // n0 + wn*32*TN + 4 c8: first of this lane's 4 columns in block 0
     int nblk;              // n0 + wn*32*TN (wave-uniform)
@@ -279,6 +288,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     t.ncol = t.nblk + c8 * 4;
     t.dvoff = (unsigned)(((unsigned long long)(mh + r8) * p.ldd + p.d_off + t.ncol) * 4ull);
     t.d2voff = p.D2 ? (unsigned)(((unsigned long long)(mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4ull) : 0u;
+    t.rvoff = RES ? (unsigned)(((unsigned long long)(mh + r8) * p.ldr + p.r_off + t.ncol) * 4ull) : 0u;
     t.rb = COLSUM ? (mh / HW + 1) * HW - mh : 64;
     t.t64 = mh >> 6;
   };
@@ -289,6 +299,16 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
   for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
+  f32x4 rres[RES ? 2 * TN : 1][4];           // RES: the residual rows of all blocks of the tile ([im * TN + in][i])
+  constexpr int NRES = RES ? 2 * TN * 4 : 0;
+  auto res_load = [&](int j, const TileOut& t) {           // j = (im * TN + in) * 4 + i
+    if (!RES || j >= NRES) return;
+    const int blk = j >> 2, i = j & 3, im = blk / TN, in = blk - im * TN;
+    const int srow = im * 32 + 8 * i;
+    typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+    const u32x4r raw = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, t.rvoff, (srow * p.ldr + in * 32) * 4, 0);
+    rres[RES ? blk : 0][i] = __builtin_bit_cast(f32x4, raw);
+  };
 
   // One block's epilogue in 15 steps (each small enough for the shadow of one MFMA).  im / in: the block,
   // t: its tile; steps 0-1 take the accumulator quads `q` (C^T block: lane (li, lh) holds channels
@@ -311,6 +331,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     } else if (step >= 5 && step <= 8) {
       const int i = step - 5;
       f32x4 v = ev[i] + vb;
+      if (RES) v += rres[RES ? im * TN + in : 0][i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // (a scalar copy first: __builtin_bit_cast on a vector ELEMENT reads element 0 whatever the index)
@@ -419,7 +440,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   };
 
   // One K-tile, MFMAs round-robin over the accumulator blocks.  FIRST: first K-tile of a tile (fresh accumulators).
-  auto ktile = [&](auto kind_tag) {
+  auto ktile = [&](auto kind_tag, bool load_res) {
     constexpr int KIND = decltype(kind_tag)::value;        // 0 regular, 1 first K-tile of a tile, 2 the one after it
     constexpr bool FIRST = KIND == 1;
     // DEFER: deferred step d of the previous tile sits in the d-th gap of k-groups 0..2 that carries neither a DMA
@@ -454,17 +475,20 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     WS_FSTAMP(trace_now, fs + 2)
     mma_group(1, false, [&](int i) {                       // g1: fragments of g2
       if (i >= GM / 2 && i < GM / 2 + NF) frag_read(0, 2, i - GM / 2);
+      if (RES && KIND == 0 && load_res && i < GM / 2) res_load(i, cur);
       deferred_at(1, i);
     });
     WS_FSTAMP(trace_now, fs + 3)
     mma_group(0, false, [&](int i) {                       // g2: fragments of g3
       if (i >= GM / 2 && i < GM / 2 + NF) frag_read(1, 3, i - GM / 2);
+      if (RES && KIND == 0 && load_res && i < GM / 2) res_load(GM / 2 + i, cur);
       deferred_at(2, i);
     });
     WS_FSTAMP(trace_now, fs + 4)
     if (FIRST && cur_seq > 0) s_wait_lds_vm_barrier<WAITN_FIRST>();
     else if (FIRST) s_wait_lds_vm_barrier<NP + 3>();       // (the very first tile: no epilogue stores in flight)
     else if (KIND == 2 && cur_seq > 0) s_wait_lds_vm_barrier<WAITN_SECOND>();
+    else if (RES && KIND == 0 && load_res) s_wait_lds_vm_barrier<WAITN + NRES>();   // (the residual rows stay in flight)
     else s_wait_lds_vm_barrier<WAITN>();
     WS_FSTAMP(trace_now, fs + 5)
 #ifdef WS_TRACE
@@ -553,15 +577,15 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     set_tile_out(seq, cur);
     WS_SSTAMP(stamp++)
     trace_now = seq == 1;
-    ktile(std::integral_constant<int, 1>{});
+    ktile(std::integral_constant<int, 1>{}, false);
     pending = false;
     WS_SSTAMP(stamp++)
     trace_now = false;
-    ktile(std::integral_constant<int, 2>{});
+    ktile(std::integral_constant<int, 2>{}, false);
     for (int kt = 2; kt + 1 < nk; ++kt) {
       WS_SSTAMP(stamp++)
       trace_now = seq == 1 && kt == 5;
-      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 0>{}, kt + 2 == nk);       // (RES: the last regular K-tile requests the residual)
     }
     WS_SSTAMP(stamp++)
     trace_now = seq == 1;
@@ -577,7 +601,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WM, int TN, int COLSUM>
+template <int WM, int TN, int COLSUM, bool RES = false>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
   constexpr int NW = WM * (4 / TN), NP = (8 * WM + 16) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
@@ -585,7 +609,7 @@ hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) 
                                (size_t)NW * 2 * 3 * 64 * 4;
   static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
-  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM>;
+  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES>;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
@@ -661,13 +685,18 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   if (g_ws_stream <= 0) return 0;
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
-                     !p.bias_img && !p.residual && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
+                     !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
                      p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
   if (!plain) return 0;
   if (p.N % S_BN != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
   if (p.colsum && p.Hout * p.Wout < 64) return 0;
   if ((p.m_begin & 63) || ((p.lda | p.a_off | p.ldd | p.d_off) & 3)) return 0;
   if (p.D2 && (((p.ldd2 | p.d2_off) & 3) || (p.d2_col0 & 31))) return 0;
+  // a residual: the eight-wavefront forms only (no registers for it beside the 4-wave form's 64 accumulators), no
+  // column sums / second output with it (no caller has both)
+  if (p.residual && (g_ws_stream == 1 || p.colsum || p.D2 || ((p.ldr | p.r_off) & 3) ||
+                     (long long)p.M * p.ldr * 4 >= (1LL << 32)))
+    return 0;
   // 32-bit byte offsets
   if ((long long)p.M * p.lda * 4 >= (1LL << 32) || (long long)p.M * p.ldd * 4 >= (1LL << 32) ||
       (long long)p.N * p.ldw * 4 >= (1LL << 32) || (p.D2 && (long long)p.M * p.ldd2 * 4 >= (1LL << 32)))
@@ -689,6 +718,11 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
     dispatch_log_note(p, k);
   }
   const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);
+  if (p.residual) {
+    if (mode == 2) return launch_stream<2, 1, 0, true>(p, grid, stream);
+    if (mode == 3) return launch_stream<4, 2, 0, true>(p, grid, stream);
+    return hipErrorInvalidValue;
+  }
   if (mode == 1) return cs == 2 ? launch_stream<2, 2, 2>(p, grid, stream)
                                 : cs ? launch_stream<2, 2, 1>(p, grid, stream) : launch_stream<2, 2, 0>(p, grid, stream);
   if (mode == 2) return cs == 2 ? launch_stream<2, 1, 2>(p, grid, stream)

@@ -304,6 +304,11 @@ hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, const doub
 hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* colc,
                                  const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
                                  int64_t num_trials, double* out, hipStream_t stream);
+hipError_t launch_row_gather_probe(const double* T, int K, const int32_t* idx, int64_t n, double* out,
+                                   hipStream_t stream);   // ws_debug_row_gather (bench yardstick)
+hipError_t launch_plda_llr_pairs_auto(const double* EA, const double* rowc, const double* colc, const double* TT, int K,
+                                      const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
+                                      unsigned long long* breaks, hipStream_t stream);
 
 // -------- direct 3x3, 32 -> 32 channel convolution on binary16 maps (conv3x3_direct.hip)
 bool conv3x3_direct_supported(const ConvGemmParams& p);

@@ -9,6 +9,8 @@
 // stays valid when n differs per enrollment model.  The GEMM runs on v_mfma_f64_16x16x4_f64.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace wsamd {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -385,6 +387,43 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(plda_llr_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, EA, rowc,
                      colc, TT, K, idx_e, idx_t, (long long)num_trials, out);
+  return hipGetLastError();
+}
+
+// (Round 4 measured two ways of halving the gather bytes of a list that is grouped by enrollment model -- as trial
+// files are: a kernel that keeps the [g * e] row in LDS per run of equal idx_e, and bucketing an ungrouped list on the
+// device first (histogram / scan / scatter).  Neither survived: on a grouped list the plain kernel above already
+// reads the enrollment row from L1 (16 consecutive trials per workgroup share it): 1 M grouped trials in 203 us
+// against 388 us in random order, and the LDS form took 232 us + its switch; bucketing by global atomics costs 135 us
+// per million trials, most of what it saves.  So: one kernel; callers that build the list themselves -- eval_sv,
+// wespeaker_amd/plda.py -- order it by enrollment row on the host.)
+
+// Gather yardstick (bench.py's PLDA roofline): 16 lanes read one K-double row per index and reduce it to its sum --
+// the row-gather path of the scoring kernels (L2 / Infinity Cache -> CU) with no second operand and 8 B out per row.
+__global__ __launch_bounds__(256) void row_gather_probe_kernel(const double* __restrict__ T, int K,
+                                                               const int32_t* __restrict__ idx, long long n,
+                                                               double* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4; p < n; p += ((long long)gridDim.x * 256) >> 4) {
+    const double* r = T + (long long)idx[p] * K;
+    double s = 0.0;
+    for (int k = sub * 2; k < K; k += 32) {
+      const double2 a = *reinterpret_cast<const double2*>(r + k);
+      s += a.x + a.y;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) out[p] = s;
+  }
+}
+
+hipError_t launch_row_gather_probe(const double* T, int K, const int32_t* idx, int64_t n, double* out,
+                                   hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (K & 1) return hipErrorInvalidValue;
+  long long blocks = (n * 16 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(row_gather_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, K, idx, (long long)n, out);
   return hipGetLastError();
 }
 

@@ -330,7 +330,19 @@ def score_plda(plda: TwoCovPLDA, enroll_embeddings, test_embeddings, trials,
     enroll_t = plda.prepare_enroll(np.vstack(rows), offs, indomain_mean)
     test_t = plda.prepare_test(np.vstack([np.asarray(test_embeddings[k], dtype=np.float32)
                                           for k in t_names]), indomain_mean)
+    # the pair kernel reads the enrollment row of consecutive trials from L1 when they share it (1 M trials: 203 us
+    # grouped, 388 us in random order): score the list ordered by enrollment model -- trial files mostly are already,
+    # then the sort is skipped -- and put the scores back in the caller's order
+    order = None
+    if len(idx_e) > 4096 and np.any(idx_e[1:] < idx_e[:-1]):
+        order = np.argsort(idx_e, kind="stable")
+        idx_e, idx_t = idx_e[order], idx_t[order]
     out = plda.llr_pairs(enroll_t, np.asarray(counts, dtype=np.int32), test_t, idx_e, idx_t)
+    if order is not None:
+        inv = torch.from_numpy(order).to(out.device)
+        back = torch.empty_like(out)
+        back[inv] = out
+        out = back
     return out if return_tensor else out.cpu().numpy()
 
 
