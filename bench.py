@@ -807,9 +807,9 @@ def main(argv=None):
                                           "frac": ach / peak, "kernel": "dominant class (every conv/linear with "
                                           "N > 64), HIP events inside this window",
                                           "whole_step_frac_of_peak": whole / peak}}
-                if prec == "fp32" and cl is not None:
+                if cl is not None:
                     # the headline's mode: n_lanes batches in flight (the roofline above stays the one-lane window's)
-                    cl.set_precision("fp32")
+                    cl.set_precision(prec)
                     for _ in range(2 * n_lanes):
                         cl.extract(fe, cw)
                     sync()
@@ -823,7 +823,7 @@ def main(argv=None):
                     leg[prec]["ms_per_step"] = cdt2 / (ks * n_lanes) * 1e3
                     leg[prec]["batches_in_flight"] = n_lanes
                     leg[prec]["roofline"]["whole_step_frac_of_peak"] = \
-                        cm.flops(1, T) * cb * ks * n_lanes / cdt2 / 1e12 / FP32_MFMA_PEAK_TFLOPS
+                        cm.flops(1, T) * cb * ks * n_lanes / cdt2 / 1e12 / peak
             configs[cname] = leg
             keep[cname] = (cm, cl)
         # configs 2 / 3 as fixed-size sets on this one GPU (N > 1: `bench.py --gpus N --workload vox1o|stream10k`)

@@ -578,6 +578,13 @@ def test_campplus_forward_matches_oracle_and_golden(golden_dir):
         f = np.random.RandomState(T).randn(2, T, 80).astype(np.float32)
         e = model(torch.from_numpy(f)).cpu().numpy()
         assert _rel_err(e, ocam.campplus_forward(sd, f).numpy()).max() < REL_TOL
+    # the row-block variants of the one-kernel dense layer (cam_dense.hip): T' = 32 q + r trunk frames run q blocks of
+    # 32 rows + a 4-row tail on 4x4x1 MFMAs when r <= 4: T' = 32, 33, 35, 64, 65, 68, 69, 75, 96, 99 (the 2-s
+    # utterance), 100 (last frame of segment 0 in the tail), 101 (a one-frame second segment), 128
+    for T in (64, 66, 70, 128, 130, 136, 138, 150, 192, 198, 200, 202, 256):
+        f = np.random.RandomState(T).randn(3, T, 80).astype(np.float32)
+        e = model(torch.from_numpy(f)).cpu().numpy()
+        assert _rel_err(e, ocam.campplus_forward(sd, f).numpy()).max() < REL_TOL, T
 
 
 def test_speaker_api_precision_switch(tmp_path):
@@ -1603,6 +1610,11 @@ RAGGED_CASES = [("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 399, 5, 201]),
                 # lengths, one and two context segments (trunk lengths 125, 99, 66, 29, 4, 102), and a full 128
                 ("CAMPPlus", 512, [250, 198, 131, 57, 7, 203]),
                 ("CAMPPlus", 512, [256, 255, 201, 200]),
+                # ... with the 4-row tail on 4x4x1 MFMAs: T' max = 99 (3 blocks + 3 rows; utterances ending inside a
+                # block, inside the tail and before it), 100 (a 4-row tail), 35 (one block + 3)
+                ("CAMPPlus", 512, [198, 197, 195, 193, 192, 150, 9]),
+                ("CAMPPlus", 512, [200, 199, 131]),
+                ("CAMPPlus", 512, [70, 69, 64, 33]),
                 # 160 < T <= 208: the one-kernel attentive pooling (astp_fused.hip) with per-utterance lengths,
                 # a full 208-frame window, and its shortest window
                 ("ECAPA_TDNN_GLOB_c512", 192, [198, 150, 57, 208, 5, 203]),
@@ -1715,11 +1727,14 @@ def test_driver_with_two_lanes_equals_one_engine(tmp_path):
     fe = Frontend(16000, 80)
     one = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, max_batch=8, max_frames=250)
     two = SpeakerModelLanes("ECAPA_TDNN_GLOB_c512", sd, lanes=2, max_batch=8, max_frames=250)
-    for tag in ("uniform", "varied"):
-        k1, e1 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(one, fe), batch_size=1, max_batch=8, num_workers=2)
-        k2, e2 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(two, fe), batch_size=1, max_batch=8, num_workers=2)
-        assert k1 == k2 == ["utt%02d" % i for i in range(45)]
-        assert np.array_equal(e1, e2), tag
+    for prec in ("fp32", "f16"):                # (the driver's default is two lanes for every back-end since round 4)
+        one.set_precision(prec)
+        two.set_precision(prec)
+        for tag in ("uniform", "varied"):
+            k1, e1 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(one, fe), batch_size=1, max_batch=8, num_workers=2)
+            k2, e2 = wx.extract_list("scp", lines[tag], wx.GpuExtractor(two, fe), batch_size=1, max_batch=8, num_workers=2)
+            assert k1 == k2 == ["utt%02d" % i for i in range(45)]
+            assert np.array_equal(e1, e2), (prec, tag)
 
 
 # ------------------------------------------------------------------------------------------ dispatch tables

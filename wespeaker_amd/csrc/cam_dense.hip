@@ -42,18 +42,30 @@ constexpr int CD_SMALL_FLOATS = 2 * 2 * 128 + 2 * 128 + 2 * 64 + 2 * 32;   // pa
 static_assert((128 + 2 * CD_HALO) * CD_HS <= CD_MAIN_FLOATS, "h fits over the stages");
 constexpr size_t CD_LDS_BYTES = (size_t)(CD_MAIN_FLOATS + CD_SMALL_FLOATS) * 4;
 
+// NB: 32-row blocks of the utterance that run on v_mfma_f32_32x32x2_f32; TAIL: the last 1..4 rows (T' = 32 NB + 1..4,
+// e.g. the 99 trunk frames of a 2-s utterance = 3 x 32 + 3) run on v_mfma_f32_4x4x1_16B_f32 instead of a fourth, 29/32
+// empty block: the instruction multiplies 16 independent 4 x 4 blocks, here 16 groups of four channels x the four
+// tail rows, one k per instruction -- the same 64 FLOP per cycle, 3 % of the rows instead of 25 % of the work.
+// Wavefront w owns the 32 channels 32 w .. 32 w + 31 of h for all NB row blocks (one W fragment, NB A fragments and
+// 4 NB MFMAs per 8 k); wavefronts 0 / 1 also the tail rows of channels 0..63 / 64..127.
+template <int NB, bool TAIL>
 __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ROWS = 32 * NB + (TAIL ? 4 : 0);   // rows of h that are computed (>= T')
+  constexpr int GM = 4 * NB;                       // 32x32x2 MFMAs per k-group and wavefront
+  constexpr int NFR = 1 + NB;                      // fragment reads per k-group
+  constexpr int NFRT = NFR + (TAIL ? 4 : 0);       // ... incl. the tail's
   float* const small = lds + CD_MAIN_FLOATS;
   float* const part = small;                       // [2 row parities][2 segments][128]
   float* const ctx = part + 2 * 2 * 128;           // [2 segments][128]
   float* const hid = ctx + 2 * 128;                // [2][64]
   float* const maskv = hid + 2 * 64;               // [2][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x;
   const int Tp = p.Tp;
-  const int len = p.lens ? p.lens[b] : Tp;         // this utterance's frames (<= Tp <= 128)
+  const int len = p.lens ? p.lens[b] : Tp;         // this utterance's frames (<= Tp <= ROWS)
   const long long row0 = (long long)b * Tp;
   const int nk = p.cin / CD_BK;
 
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
   const float* ps_ptr = p.pre_s + kc * 4;
   const float* pb_ptr = p.pre_b + kc * 4;
   // two sets of staging registers: K-tile kt + 2 is requested at the top of K-tile kt and staged into LDS during
-  // K-tile kt + 1 (one K-tile of lead -- ~1.7 us with two workgroups per CU -- did not cover the HBM round trip)
+  // K-tile kt + 1
   f32x4 ra[2][4], rw[2][4], s4[2], b4[2];
   auto load_tile = [&](int set) {
     s4[set] = *reinterpret_cast<const f32x4*>(ps_ptr);
@@ -100,41 +112,61 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
       *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * (j - 8)) * CD_S + kc * 4]) = rw[set][j - 8];
     }
   };
-  f32x16 acc[4];
+  f32x16 acc[NB];
 #pragma unroll
-  for (int in = 0; in < 4; ++in)
+  for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[in][r] = 0.f;
-  // fragments of one k-group (8 k): the wavefront's 32 rows of A, all 128 rows of W; two register slots
-  f32x4 fa[2], fw[2][4];
-  auto frag_read = [&](int buf, int g, int slot, int j) {        // j = 0: A, 1..4: W block j - 1
-    const float* As = lds + buf * CD_STAGE_FLOATS + (32 * wave + li) * CD_S + lh * 4 + g * 8;
-    const float* Ws = lds + buf * CD_STAGE_FLOATS + 128 * CD_S + li * CD_S + lh * 4 + g * 8;
-    if (j == 0) fa[slot] = *reinterpret_cast<const f32x4*>(As);
-    else fw[slot][j - 1] = *reinterpret_cast<const f32x4*>(&Ws[(j - 1) * 32 * CD_S]);
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  f32x4 tacc = {0.f, 0.f, 0.f, 0.f};               // TAIL (wavefronts 0, 1): channels 64 wave + 4 (lane >> 2) .. + 3 of
+                                                   // tail row (lane & 3)
+  const bool tail_wave = TAIL && wave < 2;         // (uniform)
+  // fragments of one k-group (8 k): this wavefront's 32 rows of W, the NB row blocks of A; two register slots
+  f32x4 fw[2], fa[2][NB];
+  f32x4 tw[2][2], tx[2][2];                        // TAIL: W row 64 wave + lane and A row 32 NB + (lane & 3), 8 k each
+  auto frag_read = [&](int buf, int g, int slot, int j) {        // j = 0: W, 1..NB: A block j - 1, then the tail's four
+    const float* st = lds + buf * CD_STAGE_FLOATS;
+    if (j == 0) fw[slot] = *reinterpret_cast<const f32x4*>(st + 128 * CD_S + (32 * wave + li) * CD_S + lh * 4 + g * 8);
+    else if (j <= NB) fa[slot][j - 1] = *reinterpret_cast<const f32x4*>(st + (32 * (j - 1) + li) * CD_S + lh * 4 + g * 8);
+    else if (TAIL && tail_wave) {
+      const int q = j - NB - 1;                    // 0, 1: W halves; 2, 3: A halves
+      if (q < 2) tw[slot][q] = *reinterpret_cast<const f32x4*>(st + 128 * CD_S + (64 * wave + lane) * CD_S + g * 8 + 4 * q);
+      else tx[slot][q - 2] = *reinterpret_cast<const f32x4*>(st + (32 * NB + (lane & 3)) * CD_S + g * 8 + 4 * (q - 2));
+    }
   };
-  // the 16 MFMAs of the k-group in `slot`; filler(i) is issued behind MFMA i (an fp32 32x32x2 MFMA holds the matrix
-  // pipe for 64 cycles: LDS reads / stores and the pre-activation maths of the next K-tile ride in its shadow --
-  // left to itself hipcc puts them between the K-tiles, where the two workgroups of a CU, running in lock step,
-  // both idle the pipe: 0.66 of the MFMA rate inside the loop)
+  // the MFMAs of the k-group in `slot`; filler(i) is issued behind MFMA i (an fp32 32x32x2 MFMA holds the matrix pipe
+  // for 64 cycles: LDS reads / stores and the pre-activation maths of the next K-tile ride in its shadow -- left to
+  // itself hipcc puts them between the K-tiles, where the two workgroups of a CU, running in lock step, both idle
+  // the pipe)
   auto mma = [&](int slot, auto&& filler) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int in = 0; in < 4; ++in) {
-        acc[in] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][in][s], fa[slot][s], acc[in], 0, 0, 0);
+      for (int mb = 0; mb < NB; ++mb) {
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[slot][s], fa[slot][mb][s], acc[mb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        filler(s * 4 + in);
+        filler(s * NB + mb);
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+    for (int i = GM; i < NFRT; ++i) filler(i);     // (one row block + tail: more fragment reads than MFMA gaps)
+    if (TAIL && tail_wave) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          tacc = __builtin_amdgcn_mfma_f32_4x4x1f32(tw[slot][q][s], tx[slot][q][s], tacc, 0, 0, 0);
+    }
   };
+  // the 12 staging pieces go into the gaps of k-groups 1 and 2 that carry no fragment read (NB >= 3: all of them;
+  // smaller utterances finish the rest in front of the barrier)
+  constexpr int GAP = GM > NFRT ? GM - NFRT : 0;   // free gaps per k-group
   load_tile(0);
   if (nk > 1) load_tile(1);
 #pragma unroll
   for (int j = 0; j < 12; ++j) store_piece(0, 0, j);
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 5; ++j) frag_read(0, 0, 0, j);
+  for (int j = 0; j < NFRT; ++j) frag_read(0, 0, 0, j);
   int buf = 0;
   // K-tile kt: its MFMAs; K-tile kt + 1 (register set (kt + 1) & 1) goes to LDS stage buf ^ 1 behind them; K-tile
   // kt + 2 is requested into the set K-tile kt came from
@@ -143,18 +175,24 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
     const bool more = kt + 1 < nk;                 // (uniform)
     if (kt + 2 < nk) load_tile(PAR);
     __builtin_amdgcn_sched_barrier(0);
-    mma(0, [&](int i) { if (i >= 8 && i < 13) frag_read(buf, 1, 1, i - 8); });
-    mma(1, [&](int i) { if (i >= 8 && i < 13) frag_read(buf, 2, 0, i - 8); });
-    mma(0, [&](int i) {                            // g2: fragments of g3 + the staging of K-tile kt + 1
-      if (i < 5) frag_read(buf, 3, 1, i);
-      else if (more) store_piece(buf ^ 1, PAR ^ 1, i - 5);             // pieces 0 .. 10
+    mma(0, [&](int i) { if (i < NFRT) frag_read(buf, 1, 1, i); });
+    mma(1, [&](int i) {                            // g1: fragments of g2, then staging pieces 0 .. GAP - 1
+      if (i < NFRT) frag_read(buf, 2, 0, i);
+      else if (more) store_piece(buf ^ 1, PAR ^ 1, i - NFRT);
     });
-    if (more) store_piece(buf ^ 1, PAR ^ 1, 11);
+    mma(0, [&](int i) {                            // g2: fragments of g3, then staging pieces GAP .. 2 GAP - 1
+      if (i < NFRT) frag_read(buf, 3, 1, i);
+      else if (more) store_piece(buf ^ 1, PAR ^ 1, GAP + i - NFRT);
+    });
+    if (more) {
+#pragma unroll
+      for (int j = 2 * GAP; j < 12; ++j) store_piece(buf ^ 1, PAR ^ 1, j);
+    }
     // stage buf^1 complete; nobody reads stage buf any more (g3 is in registers).  NOT __syncthreads(): its fence
     // waits for vmcnt(0), i.e. for the global loads of K-tile kt + 2 that were just sent ahead
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     buf ^= 1;
-    mma(1, [&](int i) { if (more && i < 5) frag_read(buf, 0, 0, i); });
+    mma(1, [&](int i) { if (more && i < NFRT) frag_read(buf, 0, 0, i); });
   };
   for (int kt = 0; kt < nk; kt += 2) {
     ktile(kt, std::integral_constant<int, 0>{});
@@ -163,33 +201,46 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
   __syncthreads();                                 // every wavefront has left the stages: h goes over them
 
   // ------------------------------------------------------------------ 2. h -> LDS, context mask
-  float* const Hs = lds;                           // [(128 + 2 halo)][CD_HS], row t at index t + CD_HALO
+  float* const Hs = lds;                           // [ROWS + 2 halo][CD_HS], row t at index t + CD_HALO
   {
-    const int t = 32 * wave + li;
-    const bool valid = t < len;
 #pragma unroll
-    for (int in = 0; in < 4; ++in)
+    for (int mb = 0; mb < NB; ++mb) {
+      const int t = 32 * mb + li;
+      const bool valid = t < len;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n0 = 32 * in + 8 * g + 4 * lh;
+        const int n0 = 32 * wave + 8 * g + 4 * lh;
         const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + n0);
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(acc[in][4 * g + r] + bias[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(acc[mb][4 * g + r] + bias[r]) : 0.f;
         *reinterpret_cast<f32x4*>(&Hs[(t + CD_HALO) * CD_HS + n0]) = v;
       }
-    // halo rows: 0, 1 and 130, 131 (4 rows x 128 floats)
+    }
+    if (TAIL && tail_wave) {
+      const int t = 32 * NB + (lane & 3), n0 = 64 * wave + 4 * (lane >> 2);
+      const bool valid = t < len;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + n0);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(tacc[r] + bias[r]) : 0.f;
+      *reinterpret_cast<f32x4*>(&Hs[(t + CD_HALO) * CD_HS + n0]) = v;
+    }
+    // halo rows: 0, 1 and ROWS + 2, ROWS + 3 (4 rows x 128 floats)
     for (int i = tid; i < 4 * 128; i += 256) {
       const int hr = i >> 7, c = i & 127;
-      Hs[(hr < 2 ? hr : 128 + hr) * CD_HS + c] = 0.f;
+      Hs[(hr < 2 ? hr : ROWS + hr) * CD_HS + c] = 0.f;
     }
   }
   // the first weight fragments of the k3 convolution: in flight while the mask is computed
   constexpr int RING = 8;
   f32x4 wl[RING];
-  const float* wl_ptr = p.Wl + (long long)li * p.ldwl + lh * 4;      // row o = li, K offset 8 j + 4 lh
+  const bool tail3 = TAIL && wave == NB;           // (uniform) the wavefront that convolves the tail rows
+  // main: row o = li, K offset 8 j + 4 lh; tail: row o = lane & 31, K offset 4 j
+  const float* wl_ptr = tail3 ? p.Wl + (long long)(lane & 31) * p.ldwl : p.Wl + (long long)li * p.ldwl + lh * 4;
+  const int wl_step = tail3 ? 4 : 8;
 #pragma unroll
-  for (int j = 0; j < RING; ++j) wl[j] = *reinterpret_cast<const f32x4*>(wl_ptr + 8 * j);
+  for (int j = 0; j < RING; ++j) wl[j] = *reinterpret_cast<const f32x4*>(wl_ptr + wl_step * j);
   __syncthreads();
   const int nseg = len > 100 ? 2 : 1;              // (T' <= 128: at most two 100-frame segments)
   {
@@ -238,20 +289,20 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
   __syncthreads();
 
   // ------------------------------------------------------------------ 3. y = conv_k3(h) * mask, appended to x
-  f32x16 y;
+  if (wave < NB) {                                 // row block `wave`: 32 rows x 32 output channels, K = 3 x 128
+    f32x16 y;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) y[r] = 0.f;
-  {
+    for (int r = 0; r < 16; ++r) y[r] = 0.f;
     const int t = 32 * wave + li;
     const float* hrow = Hs + (t + CD_HALO) * CD_HS + lh * 4;
 #pragma unroll
-    for (int j = 0; j < 48; ++j) {                 // K = 3 taps x 128 channels in steps of 8
+    for (int j = 0; j < 48; ++j) {                 // K in steps of 8
       const int tap = j >> 4, g = j & 15;
-      const f32x4 fa = *reinterpret_cast<const f32x4*>(hrow + (tap - 1) * p.dil * CD_HS + g * 8);
-      const f32x4 fw = wl[j % RING];
+      const f32x4 fa3 = *reinterpret_cast<const f32x4*>(hrow + (tap - 1) * p.dil * CD_HS + g * 8);
+      const f32x4 fw3 = wl[j % RING];
       if (j + RING < 48) wl[j % RING] = *reinterpret_cast<const f32x4*>(wl_ptr + 8 * (j + RING));
 #pragma unroll
-      for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[s], fa[s], y, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_32x32x2f32(fw3[s], fa3[s], y, 0, 0, 0);
     }
     if (t < Tp) {
       const float* mrow = maskv + (t >= 100 ? 32 : 0);
@@ -266,7 +317,53 @@ __global__ __launch_bounds__(256, 2) void cam_dense_layer_kernel(const CamDenseP
         *reinterpret_cast<f32x4*>(orow + o0) = v;
       }
     }
+  } else if (TAIL && tail3) {                      // the tail rows: 4x4x1 blocks = (4 output channels) x (4 rows), one k each;
+    f32x4 y4 = {0.f, 0.f, 0.f, 0.f};               // lanes 32..63 repeat lanes 0..31 (16 blocks, 8 channel groups)
+    const int t = 32 * NB + (lane & 3);
+    const float* hrow = Hs + (t + CD_HALO) * CD_HS;
+#pragma unroll
+    for (int j = 0; j < 96; ++j) {                 // K in steps of 4
+      const int tap = j >> 5, c4 = j & 31;
+      const f32x4 fa3 = *reinterpret_cast<const f32x4*>(hrow + (tap - 1) * p.dil * CD_HS + c4 * 4);
+      const f32x4 fw3 = wl[j % RING];
+      if (j + RING < 96) wl[j % RING] = *reinterpret_cast<const f32x4*>(wl_ptr + 4 * (j + RING));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y4 = __builtin_amdgcn_mfma_f32_4x4x1f32(fw3[s], fa3[s], y4, 0, 0, 0);
+    }
+    if (t < Tp && lane < 32) {
+      const float* mrow = maskv + (t >= 100 ? 32 : 0);
+      const int o0 = 4 * (lane >> 2);
+      const bool valid = t < len;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = valid ? y4[r] * mrow[o0 + r] : 0.f;
+      *reinterpret_cast<f32x4*>(p.Xout + (row0 + t) * p.ldx + p.c_off + o0) = v;
+    }
   }
+}
+
+template <int NB, bool TAIL>
+hipError_t launch_cam(const CamDenseParams& p, int B, hipStream_t stream) {
+  static size_t granted[WS_MAX_DEVICES] = {};
+  auto kern = cam_dense_layer_kernel<NB, TAIL>;
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), CD_LDS_BYTES, granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), CD_LDS_BYTES, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_cam_variant(int nb, bool tail, const CamDenseParams& p, int B, hipStream_t stream) {
+  if (tail) {
+    if (nb == 1) return launch_cam<1, true>(p, B, stream);
+    if (nb == 2) return launch_cam<2, true>(p, B, stream);
+    if (nb == 3) return launch_cam<3, true>(p, B, stream);
+    return hipErrorInvalidValue;
+  }
+  if (nb == 1) return launch_cam<1, false>(p, B, stream);
+  if (nb == 2) return launch_cam<2, false>(p, B, stream);
+  if (nb == 3) return launch_cam<3, false>(p, B, stream);
+  if (nb == 4) return launch_cam<4, false>(p, B, stream);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -287,11 +384,11 @@ hipError_t launch_cam_dense_layer(const CamDenseParams& p, int B, hipStream_t st
              p.cin, p.dil, p.lens ? " +mask" : "");
     dispatch_log_note_text(key);
   }
-  static size_t granted[WS_MAX_DEVICES] = {};
-  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cam_dense_layer_kernel), CD_LDS_BYTES, granted);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cam_dense_layer_kernel, dim3(B), dim3(256), CD_LDS_BYTES, stream, p);
-  return hipGetLastError();
+  // row blocks: T' = 32 q + r; r in 1..4 -> q blocks + the 4x4x1 tail, else ceil(T' / 32) blocks
+  const int q = p.Tp / 32, r = p.Tp % 32;
+  const bool tail = r >= 1 && r <= 4 && q >= 1;
+  const int nb = tail || r == 0 ? q : q + 1;
+  return launch_cam_variant(nb, tail, p, B, stream);
 }
 
 }  // namespace wsamd

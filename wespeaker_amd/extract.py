@@ -526,7 +526,8 @@ def chunk_samples(num_frms, resample_rate, frame_shift=10, frame_length=25):
 
 def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_frames=400, precision="fp32", lanes=0):
     """get_speaker_model(...)(**model_args) + load_checkpoint (bin/extract.py:66-77) on the native engine.
-    lanes: batches in flight on the GPU (engine.SpeakerModelLanes); 0 = two for the fp32 back-end, else one."""
+    lanes: batches in flight on the GPU (engine.SpeakerModelLanes); 0 = two (every back-end: the fbank defect that kept
+    the binary16 ones on one stream in round 3 is closed)."""
     from .engine import Frontend, NativeSpeakerModel, SpeakerModelLanes
     from .speaker import _load_state_dict
     fc = check_frontend_config(configs)
@@ -536,7 +537,7 @@ def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_fra
     embed_dim = margs.pop("embed_dim", None)
     sd = _load_state_dict(model_path)
     if lanes <= 0:
-        lanes = 2 if precision == "fp32" else 1
+        lanes = 2
     if lanes > 1:
         model = SpeakerModelLanes(configs["model"], sd, lanes=lanes, feat_dim=feat_dim, embed_dim=embed_dim,
                                   device=device, max_batch=max_batch, max_frames=max_frames)
@@ -682,7 +683,7 @@ def main(argv=None):
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "f16"])
     ap.add_argument("--max_batch", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0,
-                    help="batches in flight on the GPU (one engine + stream each); 0 = 2 for fp32, 1 otherwise")
+                    help="batches in flight on the GPU (one engine + stream each); 0 = 2")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpus", default=None, help="accepted for compatibility; ranks map to LOCAL_RANK")
     ap.add_argument("--gather_npz", default=None,
