@@ -307,6 +307,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   }
 }
 
+// (Round 4 looked for what keeps this kernel at ~0.7 of the fp32 MFMA rate on ResNet34's first stage -- PMC: the matrix
+// pipe busy 0.715 of the kernel's cycles at 2.34 GHz, full occupancy -- and ruled out, one rocprofv3 run each: the
+// workgroup barrier per patch (a barrier-free form with one 2 x 16 patch and private LDS stages per wavefront: 1432 vs
+// 1443 us), the dependent accumulation chain (two chains per wavefront: same), lock step of the two wavefronts of a SIMD
+// (unequal s_setprio: same), the epilogue's store round trip (counted vmcnt: -4 %, kept) and its bias loads (LDS:
+// kept).  Without any LDS-DMA the same loop takes 1153 - 1296 us, without stores 1369, without residual loads 1373: no
+// single phase is the missing 30 %.  Open.)
+
 bool conv3x3_direct_f32_supported(const ConvGemmParams& p) {
   static const int off = [] { const char* e = getenv("WS_DIRECT3X3_F32"); return e && atoi(e) == 0 ? 1 : 0; }();
   return !off && p.prec == 0 && p.A && p.D && !p.A16 && !p.D16 && !p.A2 && !p.pre_scale && p.Cin == 32 && p.N == 32 &&

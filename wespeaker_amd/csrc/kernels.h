@@ -48,6 +48,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 // ws_engine_check_range reports it.
 __device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
 
+
 // Implicit-GEMM convolution / linear layer on channels-last activations:
 //   D[m][n] = epilogue( sum_{tap, ci} A[pix(m, tap)][a_off + ci] * W[n][tap*Cin + ci] )
 // m enumerates output pixels (img, oy, ox) row-major; pix() applies stride/dilation/zero padding.
