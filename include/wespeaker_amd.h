@@ -62,7 +62,7 @@ typedef void* ws_stream;                /* hipStream_t */
 /* Bumped whenever an exported signature changes (101: ws_plda_stats takes `emb_is_f64` and a void* table since
  * round 2 -- a caller built against 100 would pass shifted arguments).  ws_version() returns the library's value:
  * compare it with the header's before calling anything else. */
-#define WS_VERSION 101
+#define WS_VERSION 102
 WS_API int ws_version(void);
 WS_API const char* ws_last_error(void);
 /* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-end verification + measurement bundle for ONE gpurun call (run from the repo root on the GPU box):
-#   gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r04'
 # Everything lands in gpurun_out/<tag>_*; tools/collect_profiles.sh <tag> copies the judged artefacts to profiles/.
 # An optional second argument selects parts (default: all): "tests bench models prof pmc" -- several short gpurun
 # calls lose less than one long one when a box is lost.
-TAG=${1:-r03}
+TAG=${1:-r04}
 PARTS=${2:-tests bench models prof pmc}
 want() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -54,6 +54,7 @@ prof f16x3 --precision f16x3
 prof ResNet34_f16 --model ResNet34 --precision f16 --steps 5
 prof ResNet34_fp32 --model ResNet34 --precision fp32 --steps 5
 prof ResNet221_f16 --model ResNet221 --precision f16 --steps 5
+prof ResNet221_fp32 --model ResNet221 --precision fp32 --steps 4
 prof CAMPPlus_f16 --model CAMPPlus --precision f16 --steps 5
 prof CAMPPlus_fp32 --model CAMPPlus --precision fp32 --steps 5
 fi
@@ -76,7 +77,7 @@ pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64,
 # the 2-D families: whole-forward HBM bytes tell whether their MFMA fraction is the binding limit at all
 pmc f16 "gemm_f16_dma_kernel|gemm_f16_p8_kernel|conv3x3_direct_f16_kernel" ResNet221
 pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel" ResNet34
-pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel" CAMPPlus
+pmc fp32 "cam_dense_layer_kernel|gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel|conv3x3_direct_f32_kernel" CAMPPlus
 fi
 cd "$REPO"
 ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwespeaker_amd.so")
 
 _lib = None
 
-ABI_VERSION = 101      # = WS_VERSION of include/wespeaker_amd.h
+ABI_VERSION = 102      # = WS_VERSION of include/wespeaker_amd.h
 
 # name -> (restype, argtypes); also used by the ABI test to check every header symbol is exported
 SIGNATURES = {

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  auto key = [](int q) { return (q >> 1) & 7; };
+  // chunk swizzle: eight consecutive pixels (= eight consecutive lanes of a fragment read) use eight different 16-B
+  // slots of their 128-B rows, i.e. all 32 banks once (round 3's (q >> 1) & 7 gave every read a 2-way conflict)
+  auto key = [](int q) { return q & 7; };
 
   // ---- weights: lane (li, lh) keeps W[li][32 tap + 8 g + 4 lh .. + 3] for all 9 taps x 4 k-groups
   f32x4d wf[36];
@@ -272,18 +274,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // 36 steps of (tap, k-group): one ds_read_b128 = the B operands of four MFMAs; the fragment of step i + 1 is
     // requested before the MFMAs of step i (four 64-cycle MFMAs cover the LDS round trip)
-    f32x4d fa[2];
-    auto read_step = [&](int i) {
+    f32x4d fa[3];                                // fragments two steps ahead of their MFMAs (512 cycles for the LDS
+    auto read_step = [&](int i) {                // round trip under eight wavefronts' reads + the DMA writes)
       const int tap = i >> 2, g = i & 3;
       const int q = q0 + (tap / 3) * IW + (tap % 3);
       return *reinterpret_cast<const f32x4d*>(base + q * 128 + (((g * 2 + lh) ^ key(q)) << 4));
     };
     fa[0] = read_step(0);
+    fa[1] = read_step(1);
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
-      if (i + 1 < 36) fa[(i + 1) & 1] = read_step(i + 1);
+      if (i + 2 < 36) fa[(i + 2) % 3] = read_step(i + 2);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][s], fa[i & 1][s], acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][s], fa[i % 3][s], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh
