@@ -1140,6 +1140,37 @@ def test_rccl_group_of_one_runs_the_extract_driver(tmp_path):
                open(os.path.join(mdir, "embeddings", "rccl", "xvector_%03d.ark" % j), "rb").read()
 
 
+def test_rccl_group_of_one_sharded_plda_matrix(tmp_path):
+    """SURVEY 8(e), last sentence: the LLR matrix with the enrollment rows sharded over the ranks and the blocks
+    collected by one all_gather -- here on an RCCL group of one (the real ws_plda_llr_matrix per block, a real
+    all_gather_into_tensor of float64 rows); equal to the plain call bit for bit.  World size 2 runs on gloo with the
+    oracle as the block scorer (tests/test_host_logic.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from fixtures import synth\n"
+        "from wespeaker_amd import TwoCovPLDA, parallel\n"
+        "rank, world, local = parallel.init_distributed()\n"
+        "assert parallel.collectives_active() and torch.distributed.get_backend() == 'nccl'\n"
+        "p = synth.synth_plda(192, seed=7)\n"
+        "plda = TwoCovPLDA.from_params(p['mu'], p['transform'], p['psi'], p['offset'], False)\n"
+        "emb, _ = synth.synth_embeddings(900, 192, seed=23)\n"
+        "e_t, t_t = plda.prepare_test(emb[:300]), plda.prepare_test(emb[300:])\n"
+        "full = plda.llr_matrix(e_t, 1, t_t)\n"
+        "got = parallel.llr_matrix_sharded(lambda lo, hi: plda.llr_matrix(e_t[lo:hi], 1, t_t), 300)\n"
+        "assert got.shape == (300, 600) and torch.equal(got, full)\n"
+        "torch.distributed.barrier(device_ids=[0]); torch.distributed.destroy_process_group()\n"
+        "print('sharded ok')\n" % root)
+    r = subprocess.run([sys.executable, str(script)], env=_rccl_env(root, 29875, tmp_path / "rccl.log"), cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-3000:]
+    _assert_rccl_ran(tmp_path / "rccl.log")
+
+
 def test_full_size_plda_one_million_trials():
     """configs[4]: 1 M trial pairs.  pairs == gather of the dense matrix; the uniform-n and per-model-n
     code paths agree; LLR(e, t, n) is invariant to the order in which the tables are given."""

@@ -88,6 +88,52 @@ def _gloo_worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
+def _gloo_llr_worker(rank, world, port, n_enroll, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from oracle import plda as oplda
+    from wespeaker_amd import parallel
+    parallel.init_distributed("gloo")
+    p = synth.synth_plda(16, seed=3)
+    emb, _ = synth.synth_embeddings(n_enroll + 9, 16, seed=5)
+    e_t = np.stack([oplda.prepare_test(p, v) for v in emb[:n_enroll]])
+    t_t = np.stack([oplda.prepare_test(p, v) for v in emb[n_enroll:]])
+    full_ref = oplda.llr_matrix_vectorised(p, e_t, np.ones(n_enroll, dtype=np.int64), t_t)
+    calls = []
+
+    def block(lo, hi):                     # the reference's arithmetic on this rank's enrollment rows only
+        calls.append((lo, hi))
+        return torch.from_numpy(oplda.llr_matrix_vectorised(p, e_t[lo:hi], np.ones(hi - lo, dtype=np.int64), t_t)
+                                .reshape(hi - lo, 9))
+    got = parallel.llr_matrix_sharded(block, n_enroll)
+    only0 = parallel.llr_matrix_sharded(block, n_enroll, to_rank0_only=True)
+    # (numpy's BLAS rounds a 1-row product differently from the same row inside a larger one: compare to 1e-12)
+    ok = bool(np.abs(got.numpy() - full_ref).max() < 1e-12) and calls[0] == parallel.shard_range(n_enroll, rank, world)
+    ok = ok and ((only0 is None) == (rank != 0))
+    q.put((rank, ok, tuple(got.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_enroll", [7, 2, 1])
+def test_world_size_2_sharded_plda_matrix_on_gloo(n_enroll):
+    """the LLR matrix with the enrollment rows sharded over two ranks equals the unsharded matrix, entry
+    for entry (7 rows: 4 + 3; 2: 1 + 1; 1: 1 + an empty shard)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() + n_enroll) % 90
+    procs = [ctx.Process(target=_gloo_llr_worker, args=(r, 2, port, n_enroll, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok and shape == (n_enroll, 9), (rank, ok, shape)
+
+
 @pytest.mark.parametrize("n_total", [11, 2, 1])
 def test_world_size_2_gather_on_gloo(n_total):
     ctx = mp.get_context("spawn")

@@ -135,3 +135,22 @@ def extract_sharded(extract_fn, wavs: torch.Tensor, batch_size: int = 256, group
         probe = extract_fn(wavs[:1])
         local = probe[:0]
     return gather_rows(local, n, group)
+
+
+def llr_matrix_sharded(block_fn, n_enroll: int, group=None, to_rank0_only: bool = False):
+    """The (n_enroll, n_test) PLDA LLR matrix with the ENROLLMENT rows sharded over the ranks (for
+    >= 1e8-trial matrices; the reference scores trial by trial on one process, two_cov_plda.py:246-256).
+
+    block_fn(lo, hi) -> (hi - lo, n_test) tensor: this rank's rows -- e.g.
+    `lambda lo, hi: plda.llr_matrix(enroll_t[lo:hi], n, test_t)` with the transformed test table replicated on every
+    rank (it is what `gather_rows` of the test embeddings returns).  Rank r takes rows shard_range(n_enroll, r, G); one
+    all_gather of the equal-size padded blocks assembles the matrix on every rank (to_rank0_only: ranks > 0 get None and
+    skip the copy of the full matrix -- the collective is the same).  Rows never mix: every entry is exactly what the
+    unsharded call computes."""
+    if not collectives_active(group):
+        return block_fn(0, n_enroll)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_enroll, rank, world)
+    block = block_fn(lo, hi)
+    full = gather_rows(block, n_enroll, group)
+    return full if (rank == 0 or not to_rank0_only) else None
