@@ -154,6 +154,24 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
   t.mel_off = fe->mel_off.as<int>(); t.mel_w = fe->mel_w.as<float>();
   t.frame_len = L; t.frame_shift = fe->frame_shift; t.fft_n = NF; t.num_bins = num_mel_bins;
   t.mel_w_total = (int)wts.size();
+  {   // the kernel's per-pass zero-padded weight table (fbank_kernel.inc): its size and how far its padded taps reach
+    int total = 0, reach = 0;
+    for (int ps = 0; ps * 16 < num_mel_bins; ++ps) {
+      int mx = 0;
+      for (int q = 0; q < 16 && ps * 16 + q < num_mel_bins; ++q) mx = std::max(mx, ln[ps * 16 + q]);
+      const int its = (((mx + 3) >> 2) + 1) & ~1;
+      total += its * 64;
+      for (int q = 0; q < 16 && ps * 16 + q < num_mel_bins; ++q) reach = std::max(reach, st[ps * 16 + q] + 4 * its);
+    }
+    t.mel_wpad_total = total; t.mel_pad_reach = reach;
+  }
+  if (t.mel_wpad_total > 2048 || t.mel_pad_reach > L) {
+    delete fe;
+    set_error("ws_frontend_create: %d mel bins at %d Hz need a padded filter table of %d floats reaching power-spectrum "
+              "index %d (limits: 2048 floats, the %d samples of a frame)", num_mel_bins, sample_rate, t.mel_wpad_total,
+              t.mel_pad_reach, L);
+    return WS_ERR_INVALID_ARG;
+  }
   *out = fe;
   return WS_OK;
 }

@@ -17,8 +17,10 @@ namespace wsamd {
 
 constexpr int FFT_N = 512;            // padded window (round_to_power_of_two)
 constexpr int CN = FFT_N / 2;         // complex FFT size
-constexpr int FRAMES_PER_BLOCK = 4;
+constexpr int FRAMES_PER_BLOCK = 16;    // wavefronts (= frames in flight) per workgroup
 constexpr int MEL_W_MAX = 1024;       // packed triangular weights (2 per FFT bin at most: 512)
+constexpr int MEL_WPAD_MAX = 2048;    // the same weights zero padded per 16-bin pass (80 bins at 16 kHz: 1536)
+constexpr int FBANK_WGS_PER_CU = 2;   // resident workgroups per CU: 32 wavefronts = the 8 per SIMD that <= 64 VGPRs allow (79 KB of LDS each)
 
 // Two builds of one kernel body (fbank_kernel.inc).  DESIGN.md 6.0: the round-3 build let hipcc's SLP vectoriser
 // pair the power-spectrum arithmetic into packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel and an
@@ -49,12 +51,13 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream, const int* frames) {
   if (T <= 0 || B <= 0) return hipSuccess;
-  if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128)
+  if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128 ||
+      t.mel_wpad_total > MEL_WPAD_MAX || t.mel_pad_reach > t.frame_len)
     return hipErrorInvalidValue;
   const long long total = (long long)B * T;
   const int cus = current_device_cus();
   long long blocks = (total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const long long resident = (long long)cus * 6;         // ~26 KB of LDS per workgroup: six per CU
+  const long long resident = (long long)cus * FBANK_WGS_PER_CU;
   if (blocks > resident) blocks = resident;
   const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
   if (g_fbank_mode.load(std::memory_order_relaxed) == 1)

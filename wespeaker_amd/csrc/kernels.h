@@ -251,6 +251,9 @@ struct FbankTables {
   const float* mel_w;            // packed weights
   int frame_len, frame_shift, fft_n, num_bins;
   int mel_w_total;               // number of packed weights
+  int mel_wpad_total;            // floats of the per-pass zero-padded weight table the kernel builds in LDS
+  int mel_pad_reach;             // 1 + the largest power-spectrum index a padded tap reads (must stay below frame_len:
+                                 // those LDS words hold this frame's samples, finite, and are multiplied by 0)
 };
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
