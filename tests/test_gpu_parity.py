@@ -969,6 +969,32 @@ def test_fbank_next_to_binary16_engines_keeps_its_bits():
     assert _lib.lib().ws_debug_fbank_mode(7) == -1 and b"mode" in _lib.lib().ws_last_error()
 
 
+def test_fbank_ragged_on_a_shared_frontend_from_two_streams():
+    """ws_fbank_ragged uploads a per-call frame-count table; round 3 kept ONE table per frontend and overwrote it
+    while kernels of an earlier call on another stream could still read it.  The tables now live in a ring of four
+    slots whose reuse waits for the consumers: ten ragged calls with different length sets, alternating between two
+    streams on ONE frontend, none synchronised in between -- every result equals its serial run."""
+    from bench import device_wavs
+    from wespeaker_amd.engine import Frontend
+    dev = torch.device("cuda:0")
+    fe = Frontend(16000, 80)
+    w = device_wavs(48, 40000, dev, 77)
+    rs = np.random.RandomState(3)
+    lens = [rs.randint(400, 40001, size=48).astype(np.int32) for _ in range(10)]
+    for ns in lens:
+        ns[rs.randint(48)] = 40000                      # (same padded length for every call)
+    ref = [fe.fbank_ragged(w, ns, cmn=True).clone() for ns in lens]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i, ns in enumerate(lens):
+        with torch.cuda.stream(streams[i & 1]):
+            outs.append(fe.fbank_ragged(w, ns, cmn=True))
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        assert torch.equal(o, r), i
+
+
 def test_engines_of_different_families_on_two_streams_keep_their_bits():
     """Two ws_engine handles on two streams is a documented use of the C-ABI (include/wespeaker_amd.h): an fp32 engine
     of every family next to a binary16 ECAPA engine, and a binary16 CAM++ / ResNet engine next to it, each keep the
