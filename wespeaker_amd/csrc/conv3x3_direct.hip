@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
   // chunk swizzle: eight consecutive pixels (= eight consecutive lanes of a fragment read) use eight different 16-B
   // slots of their 128-B rows, i.e. all 32 banks once (round 3's (q >> 1) & 7 gave every read a 2-way conflict)
   auto key = [](int q) { return q & 7; };
+  // stride 1: the residual tile of a patch (128 pixels x 128 B) also comes by LDS-DMA, one patch ahead, into two 16-KB
+  // stages behind the bias (chunk index XOR (pixel & 7)); the epilogue then has no global load left
+  constexpr bool RES_DMA = SH == 1 && SW == 1;
+  char* const res_s = lds_d + 2 * STAGE + 128;
 
   // ---- weights: lane (li, lh) keeps W[li][32 tap + 8 g + 4 lh .. + 3] for all 9 taps x 4 k-groups
   f32x4d wf[36];
@@ -241,6 +245,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     }
   };
 
+  // one piece of the next patch's halo: its address arithmetic + DMA ride in the shadow of one step's four MFMAs (a
+  // wavefront's serial phases are not covered by its SIMD partner here: measured, every serial phase costs its own time)
+  auto issue_piece = [&](int img, int iy0, int ix0, int stage, int k) {
+    int pi = wave * PPW + k;
+    if (pi > NP - 1) pi = NP - 1;
+    const int q = pi * PXP + (lane >> 3), pc = lane & 7;
+    const int ry = q / IW, rx = q - ry * IW;
+    const int iy = iy0 + ry, ix = ix0 + rx;
+    const bool ok = q < RP && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    const float* src = ok ? p.A + (((long long)img * p.Hin + iy) * p.Win + ix) * C + ((pc ^ key(q)) * 4) : p.zeros;
+    dma16_direct(src, lds_d + stage * STAGE + pi * 1024);
+  };
+
+  auto issue_res_piece = [&](int img, int oy0, int ox0, int stage, int r) {
+    const int pp = (wave * 4 + r) * 8 + (lane >> 3), pc = lane & 7;
+    const int oy = oy0 + (pp >> 4), ox = ox0 + (pp & 15);
+    const bool ok = oy < p.Hout && ox < p.Wout;
+    const float* src = ok ? p.residual + (((long long)img * p.Hout + oy) * p.Wout + ox) * p.ldr + p.r_off + ((pc ^ (pp & 7)) * 4)
+                          : p.zeros;
+    dma16_direct(src, res_s + stage * 16384 + (wave * 4 + r) * 1024);
+  };
+
   // ---- compute roles: lane li -> patch pixel (row 2 wave + li / 16, col li % 16)
   const int ppy = 2 * wave + (li >> 4), ppx = li & 15;
   const int q0 = ppy * SH * IW + ppx * SW;       // region pixel of tap (0, 0)
@@ -252,7 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
 
   int stage = 0;
   int patch = blockIdx.x;
-  if (patch < total) issue(patch, 0);
+  if (patch < total) {
+    issue(patch, 0);
+    if (RES_DMA && p.residual) {
+      const int t0 = patch / pxb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) issue_res_piece(t0 / pyb, (t0 % pyb) * PH, (patch % pxb) * PW, 0, r);
+    }
+  }
   bool stores_pending = false;                   // (wave-uniform) the previous patch's four row stores were issued
   for (; patch < total; patch += gridDim.x) {
     // ONE rendezvous per patch: this patch's pieces have landed, and everybody is done with the previous patch -- its
@@ -262,7 +295,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     if (stores_pending) wait_vm_barrier<4>();
     else wait_vm_barrier<0>();
     const int next = patch + gridDim.x;
-    if (next < total) issue(next, stage ^ 1);
+    const bool more = next < total;              // (uniform) the next patch's pieces go out behind steps 2 .. 2 + PPW
+    int n_img = 0, n_iy0 = 0, n_ix0 = 0;
+    if (more) {
+      const int nx = next % pxb, nt = next / pxb;
+      n_img = nt / pyb;
+      n_iy0 = (nt % pyb) * PH * SH - 1;
+      n_ix0 = nx * PW * SW - 1;
+    }
     const char* base = lds_d + stage * STAGE;
     const int pxi = patch % pxb, t = patch / pxb;
     const int pyi = t % pyb, img = t / pyb;
@@ -287,8 +327,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
       if (i + 2 < 36) fa[(i + 2) % 3] = read_step(i + 2);
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][s], fa[i % 3][s], acc, 0, 0, 0);
+      if (PPW <= 26 && i >= 2 && i < 2 + PPW && more) issue_piece(n_img, n_iy0, n_ix0, stage ^ 1, i - 2);
+      if (RES_DMA && PPW <= 26 && i >= 2 + PPW && i < 6 + PPW && more && p.residual)
+        issue_res_piece(n_img, (n_iy0 + 1) / SH, (n_ix0 + 1) / SW, stage ^ 1, i - 2 - PPW);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (PPW > 26 && more) issue(next, stage ^ 1);
     // C^T layout: column = pixel li, rows (channels) = (r & 3) + 8 (r >> 2) + 4 lh
     const bool padded = p.row_len && ox >= p.row_len[img];
     float* const drow = p.D + m * p.ldd + p.d_off + 4 * lh;
@@ -296,7 +340,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
     for (int j = 0; j < 4; ++j) {
       f32x4d v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
       v += *reinterpret_cast<const f32x4d*>(bias_s + 8 * j + 4 * lh);
-      if (p.residual) v += *reinterpret_cast<const f32x4d*>(p.residual + m * p.ldr + p.r_off + 8 * j + 4 * lh);
+      if (p.residual) {
+        if (RES_DMA) v += *reinterpret_cast<const f32x4d*>(res_s + stage * 16384 + (wave * 32 + li) * 128 +
+                                                             (((2 * j + lh) ^ (li & 7)) << 4));
+        else v += *reinterpret_cast<const f32x4d*>(p.residual + m * p.ldr + p.r_off + 8 * j + 4 * lh);
+      }
       if (p.act == ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
@@ -311,12 +359,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
 }
 
 // (Round 4 looked for what keeps this kernel at ~0.7 of the fp32 MFMA rate on ResNet34's first stage -- PMC: the matrix
-// pipe busy 0.715 of the kernel's cycles at 2.34 GHz, full occupancy -- and ruled out, one rocprofv3 run each: the
-// workgroup barrier per patch (a barrier-free form with one 2 x 16 patch and private LDS stages per wavefront: 1432 vs
-// 1443 us), the dependent accumulation chain (two chains per wavefront: same), lock step of the two wavefronts of a SIMD
-// (unequal s_setprio: same), the epilogue's store round trip (counted vmcnt: -4 %, kept) and its bias loads (LDS:
-// kept).  Without any LDS-DMA the same loop takes 1153 - 1296 us, without stores 1369, without residual loads 1373: no
-// single phase is the missing 30 %.  Open.)
+// pipe busy 0.715 of the kernel's cycles at 2.34 GHz, full occupancy.  Ruled out, one rocprofv3 run each: the workgroup
+// barrier per patch (a barrier-free form with one 2 x 16 patch and private LDS stages per wavefront: 1432 vs 1443 us),
+// the dependent accumulation chain (two chains per wavefront: same), lock step of the two wavefronts of a SIMD
+// (unequal s_setprio: same), LDS bank conflicts and the fragment prefetch distance (conflict-free swizzle, two steps
+// ahead: same).  What the ablations showed instead: every SERIAL phase of a wavefront costs its own time -- the SIMD
+// partner does not cover it -- without LDS-DMA the loop takes 1153 - 1296 us, without stores 1369, without residual
+// loads 1373.  So the serial phases were moved into the shadow of the wavefront's OWN MFMAs, as the persistent GEMM
+// does: the next patch's DMA pieces one per step (1437 -> 1372 us), the residual tile by LDS-DMA one patch ahead
+// (-> 1332 us), the bias from LDS and counted vmcnt for the stores (earlier: 1505 -> 1443).  Left exposed: the
+// rendezvous at the top of a patch and the epilogue's maths + stores; hiding those needs the 16 accumulator registers
+// twice, i.e. half of the 144 weight registers moved to LDS fragments.)
 
 bool conv3x3_direct_f32_supported(const ConvGemmParams& p) {
   static const int off = [] { const char* e = getenv("WS_DIRECT3X3_F32"); return e && atoi(e) == 0 ? 1 : 0; }();
@@ -336,7 +389,7 @@ template <int SH, int SW>
 static hipError_t launch_direct_f32(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int IH = (PH - 1) * SH + 3, IW = (PW - 1) * SW + 3;
   constexpr int NP = (IH * IW + 7) / 8;
-  constexpr size_t lds = 2 * (size_t)NP * 1024 + 128;        // two stages + the bias
+  constexpr size_t lds = 2 * (size_t)NP * 1024 + 128 + (SH == 1 && SW == 1 ? 2 * 16384 : 0);   // two stages + the bias (+ two residual stages)
   static_assert(lds <= 160 * 1024, "two stages fit the LDS");
   auto kern = conv3x3_direct_f32_kernel<SH, SW>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
