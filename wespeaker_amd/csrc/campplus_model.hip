@@ -13,6 +13,7 @@
 // and every layer appends its 32 channels at a channel offset (concat-free).  Pre-activation
 // BN-ReLU (CAM++ is BN -> ReLU -> conv) is applied while the GEMM stages its A operand; BN that
 // directly follows a conv is folded into the weights; the context mask multiplies in the epilogue.
+#include <cstdint>
 #include "model_common.h"
 
 namespace wsamd {
@@ -235,9 +236,42 @@ struct CamppModel : ModelBase {
     const int segs = (Tp + 99) / 100;
     int ch = 128;
     for (int k = 0; k < 3; ++k) {
-      for (size_t j = 0; j < layers[k].size(); ++j) {
+      // fp32, utterances of <= 128 trunk frames: the whole dense block is one launch, one workgroup per utterance
+      // (cam_dense_block_kernel); WS_CAM_BLOCK=0: one launch per layer
+      bool block_done = false;
+      if (gemm_precision == 0 && cam_dense_block_enabled() && (int)layers[k].size() <= WS_CAM_MAX_LAYERS &&
+          !layers[k].empty() && (reinterpret_cast<uintptr_t>(X) & 127) == 0 && (ldx & 31) == 0) {
+        bool ok = true;
+        for (size_t j = 0; j < layers[k].size(); ++j)
+          ok = ok && layers[k][j].cin == layers[k][0].cin + 32 * (int)j &&
+               cam_dense_fused_applies(Tp, layers[k][j].cin, kDil[k]);
+        if (ok) {
+          CamDenseBlockParams bp = {};
+          CamDenseParams& cp = bp.base;
+          cp.X = X; cp.Xout = X; cp.ldx = ldx; cp.cin = layers[k][0].cin; cp.c_off = cp.cin; cp.Tp = Tp; cp.lens = L1;
+          cp.dil = kDil[k];
+          bp.n_layers = (int)layers[k].size();
+          double fl = 0, by = 0;
+          for (size_t j = 0; j < layers[k].size(); ++j) {
+            const DenseLayerW& L = layers[k][j];
+            CamDenseLayerW& w = bp.layers[j];
+            w.pre_s = arena.at(L.pre_s); w.pre_b = arena.at(L.pre_b);
+            w.W1 = arena.at(L.lin1.w); w.b1 = arena.at(L.lin1.b); w.ldw1 = L.lin1.ldw;
+            w.Wl = arena.at(L.local.w); w.ldwl = L.local.ldw;
+            w.cw1 = arena.at(L.cw1); w.cb1 = arena.at(L.cb1); w.cw2 = arena.at(L.cw2); w.cb2 = arena.at(L.cb2);
+            fl += 2.0 * B * (double)Tp * (128.0 * L.cin + 3.0 * 128 * 32);
+            by += 4.0 * (B * (double)Tp * (L.cin + 32) + 128.0 * L.cin + 3.0 * 128 * 32);
+          }
+          if (prof.enabled) prof.begin(0, fl, by, st);
+          hipError_t ce = launch_cam_dense_block(bp, B, st);
+          prof.end(st);
+          WS_LAUNCH(ce);
+          block_done = true;
+        }
+      }
+      for (size_t j = 0; !block_done && j < layers[k].size(); ++j) {
         const DenseLayerW& L = layers[k][j];
-        // fp32, utterances of <= 128 trunk frames: the whole layer is one kernel, one workgroup per utterance
+        // ... or one kernel per layer
         if (gemm_precision == 0 && cam_dense_fused_applies(Tp, L.cin, kDil[k])) {
           CamDenseParams cp = {};
           cp.X = X; cp.Xout = X; cp.ldx = ldx; cp.cin = L.cin; cp.c_off = L.cin; cp.Tp = Tp; cp.lens = L1;

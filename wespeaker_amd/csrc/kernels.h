@@ -239,6 +239,21 @@ struct CamDenseParams {
 };
 bool cam_dense_fused_applies(int Tp, int cin, int dil);  // (WS_CAM_FUSED=0 switches it off)
 hipError_t launch_cam_dense_layer(const CamDenseParams& p, int B, hipStream_t stream);
+// A whole CAMDenseTDNNBlock (campplus.py:173-205) as ONE launch: layer l reads x[:, 0 : cin0 + 32 l) and appends its 32
+// channels, and nothing but the utterance's own rows is read or written -- the workgroup that owns the utterance runs
+// the layers back to back.  `base` carries what the layers share (X, ldx, Tp, lens, dil; cin / c_off of layer 0).
+constexpr int WS_CAM_MAX_LAYERS = 24;
+struct CamDenseLayerW {
+  const float *pre_s, *pre_b, *W1, *b1, *Wl, *cw1, *cb1, *cw2, *cb2;
+  int ldw1, ldwl;
+};
+struct CamDenseBlockParams {
+  CamDenseParams base;
+  int n_layers;
+  CamDenseLayerW layers[WS_CAM_MAX_LAYERS];
+};
+bool cam_dense_block_enabled();                           // (WS_CAM_BLOCK=0: one launch per layer)
+hipError_t launch_cam_dense_block(const CamDenseBlockParams& bp, int B, hipStream_t stream);
 
 // ---- frontend
 struct FbankTables {
