@@ -24,15 +24,15 @@ for _ in range(4):
     m.extract(fe, wav)
 torch.cuda.synchronize()
 f = getattr(L.lib(), "_ZN5wsamd24cam_trace_buffer_addressEv"); f.restype = ctypes.c_void_p
-buf = (ctypes.c_ulonglong * 1024)()
+buf = (ctypes.c_ulonglong * 2048)()
 hip = ctypes.CDLL("libamdhip64.so")
-r = hip.hipMemcpy(buf, ctypes.c_void_p(f()), 8192, 2)
+r = hip.hipMemcpy(buf, ctypes.c_void_p(f()), 16384, 2)
 t = list(buf)
 print("hipMemcpy", r, "batch", B)
 print("cin   nk | wave0: start  Kloop (per K-tile)  bar  h->LDS  mask  conv  total | wave3: Kloop conv total")
 fine = []
 for c in range(32):
-    a, b = t[c * 32: c * 32 + 16], t[c * 32 + 16: c * 32 + 32]
+    a, b = t[c * 64: c * 64 + 32], t[c * 64 + 32: c * 64 + 64]
     if not a[6]:
         continue
     cin = c * 32 if c else 1024
@@ -40,6 +40,9 @@ for c in range(32):
     print("%4d %4d | %6d %7d (%5d) %5d %6d %6d %6d %7d | %7d %6d %7d" % (
         cin, nk, a[1] - a[0], a[2] - a[1], (a[2] - a[1]) // nk, a[3] - a[2], a[4] - a[3], a[5] - a[4], a[6] - a[5],
         a[6] - a[0], b[2] - b[1], b[6] - b[5], b[6] - b[0]))
+    fine.append("%4d | h: bias %5d blocks %5d tail+halo %5d k3 issue %5d barrier %5d; wave3: %5d %5d %5d %5d %5d |" % (
+        cin, a[16] - a[3], a[17] - a[16], a[18] - a[17], a[19] - a[18], a[4] - a[19],
+        b[16] - b[3], b[17] - b[16], b[18] - b[17], b[19] - b[18], b[4] - b[19]))
     fine.append("%4d | h: regs->LDS %5d, k3 weights + barrier %5d | mask: sums %5d bar %5d ctx %5d fc1 %5d bar %5d fc2 %5d bar %5d"
                 " | k3: taps %5d %5d %5d store %5d" % (
         cin, a[7] - a[3], a[4] - a[7], a[8] - a[4], 0, a[9] - a[8], a[10] - a[9], a[11] - a[10], a[12] - a[11],

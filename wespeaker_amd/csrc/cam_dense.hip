@@ -35,13 +35,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef WS_TRACE
 // (trace builds only, tools/trace_cam_dense.py) cycle stamps of wavefronts 0 and 3 of workgroup 9, one row of 16 per
-// input width: [cin / 32][wavefront 0 | wavefront 3][16]
-__device__ unsigned long long g_cam_trace[32 * 32];
+// input width: [cin / 32][wavefront 0 | wavefront 3][32]
+__device__ unsigned long long g_cam_trace[32 * 64];
 #define WS_CSTAMP(i)                                                                              \
   if (blockIdx.x == 9 && (threadIdx.x == 0 || threadIdx.x == 192))                                \
-    g_cam_trace[((p.cin / 32) & 31) * 32 + (threadIdx.x ? 16 : 0) + (i)] = __builtin_readcyclecounter();
+    g_cam_trace[((p.cin / 32) & 31) * 64 + (threadIdx.x ? 32 : 0) + (i)] = __builtin_readcyclecounter();
+#define WS_CPIN(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WS_CSTAMP(i) asm volatile("" ::: "memory"); }
 #else
 #define WS_CSTAMP(i)
+#define WS_CPIN(i)
 #endif
 
 constexpr int CD_BK = 32;                  // K-tile
@@ -268,6 +270,7 @@ __device__ __forceinline__ void cam_dense_layer_body(const CamDenseParams& p, fl
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(b1s + 32 * wave + 8 * g + 4 * lh);
     if (TAIL && tail_wave) biast = *reinterpret_cast<const f32x4*>(b1s + 64 * wave + 4 * (lane >> 2));
+    WS_CPIN(16)
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
       const int t = 32 * mb + li;
@@ -276,19 +279,31 @@ __device__ __forceinline__ void cam_dense_layer_body(const CamDenseParams& p, fl
       for (int g = 0; g < 4; ++g) {
         const int n0 = 32 * wave + 8 * g + 4 * lh;
         const f32x4 bias = bias4[g];
+        // (two selects, kept apart by the opaque copy: merged, hipcc builds `valid && !(x < 0)` with one
+        // v_cmp -> s_and_b64 -> v_cndmask round trip through the scalar unit per ELEMENT, all 48 of them serialised on
+        // one SGPR pair -- 5 - 7 k cycles for this loop, measured; apart, the row's mask is one SGPR pair per block)
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(acc[mb][4 * g + r] + bias[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          float z = relu_f(acc[mb][4 * g + r] + bias[r]);
+          asm volatile("" : "+v"(z));
+          v[r] = valid ? z : 0.f;
+        }
         *reinterpret_cast<f32x4*>(&Hs[(t + CD_HALO) * CD_HS + n0]) = v;
       }
     }
+    WS_CPIN(17)
     if (TAIL && tail_wave) {
       const int t = 32 * NB + (lane & 3), n0 = 64 * wave + 4 * (lane >> 2);
       const bool valid = t < len;
       const f32x4 bias = biast;
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = valid ? relu_f(tacc[r] + bias[r]) : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        float z = relu_f(tacc[r] + bias[r]);
+        asm volatile("" : "+v"(z));
+        v[r] = valid ? z : 0.f;
+      }
       *reinterpret_cast<f32x4*>(&Hs[(t + CD_HALO) * CD_HS + n0]) = v;
     }
     // halo rows: 0, 1 and ROWS + 2, ROWS + 3 (4 rows x 128 floats)
@@ -297,6 +312,7 @@ __device__ __forceinline__ void cam_dense_layer_body(const CamDenseParams& p, fl
       *reinterpret_cast<f32x4*>(&Hs[(hr < 2 ? hr : ROWS + hr) * CD_HS + c]) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
+  WS_CPIN(18)
   WS_CSTAMP(7)
   // the first weight fragments of the k3 convolution: in flight while the mask is computed
   constexpr int RING = 8;
@@ -307,6 +323,7 @@ __device__ __forceinline__ void cam_dense_layer_body(const CamDenseParams& p, fl
   const int wl_step = tail3 ? 4 : 8;
 #pragma unroll
   for (int j = 0; j < RING; ++j) wl[j] = *reinterpret_cast<const f32x4*>(wl_ptr + wl_step * j);
+  WS_CPIN(19)
   WS_LDS_BARRIER();
   WS_CSTAMP(4)
   const int nseg = len > 100 ? 2 : 1;              // (T' <= 128: at most two 100-frame segments)
