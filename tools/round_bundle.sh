@@ -77,7 +77,7 @@ pmc f16 "gemm_f16_dma_kernel<128, 128|gemm_f16_p8_kernel|gemm_f16_dma_kernel<64,
 # the 2-D families: whole-forward HBM bytes tell whether their MFMA fraction is the binding limit at all
 pmc f16 "gemm_f16_dma_kernel|gemm_f16_p8_kernel|conv3x3_direct_f16_kernel" ResNet221
 pmc fp32 "gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel" ResNet34
-pmc fp32 "cam_dense_layer_kernel|gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel|conv3x3_direct_f32_kernel" CAMPPlus
+pmc fp32 "cam_dense_block_kernel|cam_dense_layer_kernel|gemm_f32_stream_kernel|conv_gemm_dual_kernel|conv_gemm_kernel|conv3x3_direct_f32_kernel" CAMPPlus
 fi
 cd "$REPO"
 ls "$OUT" | grep "^${TAG}_" | tr '\n' ' '
