@@ -85,7 +85,11 @@ WS_API int ws_wav_load_rows(const char* const* paths, int n, int threads, int16_
 /* -------------------------------------------------------------------------------- frontend */
 /* Replaces torchaudio.compliance.kaldi.fbank as called at cli/speaker.py:92-97 and
  * dataset/processor.py:518-525 (+ CMN cli/speaker.py:98-99, dataset_utils.py:19-26); native twin
- * runtime/core/frontend/fbank.h:33-97 (constructor: mel banks, window).  dither is always 0. */
+ * runtime/core/frontend/fbank.h:33-97 (constructor: mel banks, window).  dither is always 0.
+ * Any sample rate whose 25 ms frame pads to a transform of 16 .. 4096 points (fbank.h:33-52: fft_points =
+ * UpperPowerOfTwo(frame_length)): 8 kHz (the SRE recipe, examples/sre/v2/conf/resnet.yaml:31) -> 256, 16 kHz -> 512,
+ * 32 kHz -> 1024, 44.1 / 48 kHz -> 2048; 1..128 mel bins; low_freq 20 Hz, high_freq = Nyquist as in the reference's
+ * calls.  WS_ERR_INVALID_ARG outside that range. */
 WS_API int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out);
 WS_API void ws_frontend_destroy(ws_frontend* fe);
 /* wav: DEVICE (B, wav_stride) samples, the first num_samples of each row are used.
@@ -220,8 +224,10 @@ WS_API int ws_debug_row_gather(const double* table, int row_len, const int32_t* 
 /* Reproducer switch of the fbank kernel (process-wide; tests and tools/fbank_race_probe.py only -- DESIGN.md 6.0).
  * The round-3 build of runtime/core/frontend/fbank.h:138-198's arithmetic used the packed-fp32 instruction forms in
  * its power-spectrum loop; next to binary16 GEMMs on another stream those returned wrong values in lanes 48..63.
- * mode 0 = the shipped kernel (no packed-fp32 forms), 1 = the round-3 packed build.  Returns 0, or
- * WS_ERR_INVALID_ARG for an unknown mode. */
+ * mode 0 = the shipped kernels (no packed-fp32 forms), 1 = the round-3 packed build, 2 = the any-length kernel (the one
+ * that serves every rate whose 25 ms frame does not pad to 512 points) also for 512-point frontends: at 16 kHz its
+ * outputs are the specialised kernel's bits, which is how the tests pin it.  Returns 0, or WS_ERR_INVALID_ARG for an
+ * unknown mode. */
 WS_API int ws_debug_fbank_mode(int mode);
 /* Algorithmic FLOPs (2 x MACs of every conv/linear) of one forward at (batch, num_frames). */
 WS_API double ws_engine_flops(const ws_engine* eng, int batch, int num_frames);

@@ -23,6 +23,8 @@ What is recorded (all seeds live in fixtures/synth.py, inputs are regenerated fr
                        fixture and applied to 24 probe embeddings.
   * fbank_ref_native.npz -- log-mel output of the reference's own native fbank
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
+  * fbank_ref_native_rates.npz -- the same native fbank at 8 kHz (80 / 23 / 40 bins), 32 kHz and 48 kHz
+                       (256-, 1024- and 2048-point transforms: fbank.h:33-52 sizes the FFT from the frame).
   * kaldi_plda_*.bin / .txt + kaldi_plda_ref.npz -- Kaldi <Plda> files and what the reference's own
                        read_plda returns for them.
   * chunked_ref.npz -- the reference's own native SpeakerEngine (speaker_engine.cc, built into
@@ -41,20 +43,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shim  # noqa: E402
-from oracle.fbank import speaker_features  # noqa: E402
+from oracle.fbank import kaldi_fbank, speaker_features  # noqa: E402
 from fixtures import synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def ref_native_fbank(pcm_int16):
+def ref_native_fbank(pcm_int16, sample_rate=16000, bins=80):
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_fbank.so"))
     lib.ref_fbank.restype = ctypes.c_int
     x = np.ascontiguousarray(pcm_int16, dtype=np.float32)
-    out = np.zeros((2000, 80), np.float32)
-    n = lib.ref_fbank(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]), 80, 16000,
+    out = np.zeros((2000, bins), np.float32)
+    n = lib.ref_fbank(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]), bins, sample_rate,
                       out.ctypes.data_as(ctypes.c_void_p), 2000)
     return out[:n].copy()
+
+
+# (sample rate, mel bins, samples): 8 kHz = the reference's SRE recipe (examples/sre/v2/conf/resnet.yaml:31), 200-sample
+# frames -> 256-point transform; 32 kHz -> 1024; 48 kHz -> 2048.  The native reference sizes its frame as
+# sample_rate / 1000 * 25 (runtime/core/frontend/feature_pipeline.h), which equals torchaudio's int(rate * 0.025) at
+# these three rates (not at 44.1 kHz: 1100 vs 1102 samples -- that rate is checked against the restatement only).
+FBANK_RATES = ((8000, 80, 16000), (8000, 23, 16000), (8000, 40, 2000), (32000, 80, 64000), (48000, 80, 96000))
+
+
+def make_fbank_rates():
+    out = {}
+    for rate, bins, n in FBANK_RATES:
+        wav = synth.synth_wav(21 + rate // 8000, n)
+        ref = ref_native_fbank(wav, rate, bins)
+        mine = kaldi_fbank(wav.astype(np.float32), num_mel_bins=bins, sample_frequency=rate, window_type="hamming")
+        assert ref.shape == mine.shape, (rate, ref.shape, mine.shape)
+        out["r%d_b%d_n%d" % (rate, bins, n)] = ref
+        print("fbank %5d Hz %3d bins %6d samples: %d frames, native-ref vs restatement max|d| = %.3e mean|d| = %.3e"
+              % (rate, bins, n, ref.shape[0], np.abs(mine - ref).max(), np.abs(mine - ref).mean()))
+    np.savez_compressed(os.path.join(GOLD, "fbank_ref_native_rates.npz"), **out)
 
 
 def make_fbank():
@@ -302,7 +324,7 @@ def make_chunked():
     np.savez_compressed(os.path.join(GOLD, "chunked_ref.npz"), **out)
 
 
-SECTIONS = {"fbank": make_fbank, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
+SECTIONS = {"fbank": make_fbank, "fbank_rates": make_fbank_rates, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
             "plda": make_plda, "score": make_score, "plda_train": make_plda_train,
             "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda, "chunked": make_chunked}
 

@@ -29,6 +29,20 @@ def test_fbank_restatement_vs_reference_native(golden_dir):
     assert np.abs(short - g["short_logmel"]).max() < 5e-4
 
 
+def test_fbank_restatement_vs_reference_native_other_rates(golden_dir):
+    """8 kHz (the SRE recipe's rate, examples/sre/v2/conf/resnet.yaml:31), 32 kHz, 48 kHz: the restatement against the
+    reference's own native fbank (frontend/fbank.h sizes its FFT from the frame: 256 / 1024 / 2048 points)."""
+    g = np.load(os.path.join(golden_dir, "fbank_ref_native_rates.npz"))
+    assert len(g.files) == 5
+    for key in g.files:
+        rate, bins, n = (int(t[1:]) for t in key.split("_"))
+        wav = synth.synth_wav(21 + rate // 8000, n)
+        mine = ofbank.kaldi_fbank(wav.astype(np.float32), num_mel_bins=bins, sample_frequency=rate,
+                                  window_type="hamming")
+        assert mine.shape == g[key].shape == (1 + (n - rate // 40) // (rate // 100), bins)
+        assert np.abs(mine - g[key]).max() < 5e-4, key
+
+
 def test_fbank_edge_cases():
     assert ofbank.kaldi_fbank(np.zeros(399, np.float32), window_type="hamming").shape == (0, 80)
     assert ofbank.kaldi_fbank(np.zeros(400, np.float32), window_type="hamming").shape == (1, 80)

@@ -8,7 +8,9 @@ import os
 from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwespeaker_amd.so")
+# WS_LIB_PATH: another build of the same library (tools/ab_bench.sh compares two builds in one gpurun call); unset in
+# every shipped path, and a path that does not load raises like the default one
+LIB_PATH = os.environ.get("WS_LIB_PATH") or os.path.join(_HERE, "lib", "libwespeaker_amd.so")
 
 _lib = None
 

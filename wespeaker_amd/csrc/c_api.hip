@@ -82,10 +82,13 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
   fe->frame_len = (int)(sample_rate * 25.0 * 0.001);
   fe->frame_shift = (int)(sample_rate * 10.0 * 0.001);
   fe->fft_n = next_pow2(fe->frame_len);
-  if (fe->fft_n != 512) {
+  // any rate whose 25 ms frame pads to 16 .. 4096 points (640 Hz .. 163 kHz): 8 kHz -> 256 points (the reference's SRE
+  // recipe, examples/sre/v2/conf/resnet.yaml:31), 16 kHz -> 512 (the specialised kernel), 32 kHz -> 1024, 44.1 / 48 kHz
+  // -> 2048; the transform length follows the frame like runtime/core/frontend/fbank.h:33-52
+  if (fe->frame_shift <= 0 || fe->fft_n < 16 || fe->fft_n > 4096) {
+    const int got = fe->fft_n;
     delete fe;
-    set_error("ws_frontend_create: only 25 ms windows that pad to 512 points are supported "
-              "(sample_rate 10241..20480 Hz), got %d Hz", sample_rate);
+    set_error("ws_frontend_create: a 25 ms frame at %d Hz pads to %d points (supported: 16 .. 4096)", sample_rate, got);
     return WS_ERR_INVALID_ARG;
   }
   const int L = fe->frame_len, NF = fe->fft_n;
@@ -165,13 +168,8 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
     }
     t.mel_wpad_total = total; t.mel_pad_reach = reach;
   }
-  if (t.mel_wpad_total > 2048 || t.mel_pad_reach > L) {
-    delete fe;
-    set_error("ws_frontend_create: %d mel bins at %d Hz need a padded filter table of %d floats reaching power-spectrum "
-              "index %d (limits: 2048 floats, the %d samples of a frame)", num_mel_bins, sample_rate, t.mel_wpad_total,
-              t.mel_pad_reach, L);
-    return WS_ERR_INVALID_ARG;
-  }
+  // (a table the specialised 512-point kernel cannot hold -- more mel bins than its padded weights allow -- is not an
+  // error any more: launch_fbank sends such a frontend through the any-length kernel)
   *out = fe;
   return WS_OK;
 }
@@ -597,8 +595,9 @@ int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, in
 }
 
 int ws_debug_fbank_mode(int mode) {
-  if (mode < 0 || mode > 1) {
-    set_error("ws_debug_fbank_mode: mode %d (0 shipped kernel, 1 packed-fp32 reproducer build)", mode);
+  if (mode < 0 || mode > 2) {
+    set_error("ws_debug_fbank_mode: mode %d (0 shipped kernels, 1 packed-fp32 reproducer build, 2 any-length kernel for "
+              "every frontend)", mode);
     return WS_ERR_INVALID_ARG;
   }
   set_fbank_debug_mode(mode);

@@ -43,24 +43,201 @@ constexpr int FBANK_WGS_PER_CU = 2;   // resident workgroups per CU: 32 wavefron
 #undef WS_FBANK_FN
 #undef WS_FBANK_ATTR
 
-// ws_debug_fbank_mode: 0 shipped kernel, 1 the packed-fp32 build (tests and tools/fbank_race_probe.py only)
+// ------------------------------------------------------------------ any power-of-two FFT length
+// The kernel above is specialised for the 512-point transform of 16 kHz-class rates (25 ms = 400 samples).  The
+// reference takes any rate: the CLI passes `sample_frequency=sample_rate` through (wespeaker/cli/speaker.py:90-97;
+// the SRE recipe extracts at 8 kHz, examples/sre/v2/conf/resnet.yaml:31) and its native twin sizes the transform from
+// the frame length (runtime/core/frontend/fbank.h:33-52, fft_points_ = UpperPowerOfTwo(frame_length_)).  This kernel
+// is the same pipeline for fft_n = 16 .. 4096 (200 samples -> 256 points at 8 kHz, 800 -> 1024 at 32 kHz, 1102 / 1200
+// -> 2048 at 44.1 / 48 kHz): one wavefront per frame, the real transform as a complex Stockham FFT of fft_n / 2 points
+// in LDS -- radix-4 stages, one closing radix-2 stage when log2(fft_n / 2) is odd, every lane walking the butterflies
+// lane, lane + 64, ... of a stage -- the same split / power step, and the mel filters four lanes per bin straight from
+// the packed weights (taps beyond a filter's end are skipped, not zero padded).  At fft_n = 512 every value goes
+// through the same operations in the same order as in the specialised kernel (ws_debug_fbank_mode(2) routes 16 kHz
+// input here: the tests compare the two bit for bit); it is also where a 16 kHz-class frontend with more mel bins than
+// the specialised kernel's padded weight table holds ends up.
+__attribute__((target("no-packed-fp32-ops"))) __device__ __forceinline__ void fbank_any_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__attribute__((target("no-packed-fp32-ops"))) __device__ __forceinline__ float2 fbank_any_cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__attribute__((target("no-packed-fp32-ops"))) __global__ __launch_bounds__(1024) void fbank_any_kernel(
+    const FbankTables tb, const void* __restrict__ wav, int wav_dtype, long long wav_stride, float scale,
+    const float* __restrict__ window, int T, long long total_frames, float* __restrict__ feats,
+    const int* __restrict__ frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char any_lds[];
+  const int NF = tb.fft_n, CNn = NF >> 1;
+  const int waves = blockDim.x >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // LDS: twiddles [NF] float2 | mel_start, mel_len, mel_off [128] ints each | per wavefront: A [CN] float2, B [CN + 4] float2
+  float2* const tw = reinterpret_cast<float2*>(any_lds);
+  int* const mel_start_s = reinterpret_cast<int*>(tw + NF);
+  int* const mel_len_s = mel_start_s + 128;
+  int* const mel_off_s = mel_len_s + 128;
+  float2* const bufs = reinterpret_cast<float2*>(mel_off_s + 128);
+  float2* const bufA = bufs + (size_t)wave * (2 * CNn + 4);
+  float2* const bufB = bufA + CNn;
+  for (int i = threadIdx.x; i < NF; i += blockDim.x) tw[i] = reinterpret_cast<const float2*>(tb.twiddle)[i];
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+    const bool has = i < tb.num_bins;
+    mel_start_s[i] = has ? tb.mel_start[i] : 0; mel_len_s[i] = has ? tb.mel_len[i] : 0; mel_off_s[i] = has ? tb.mel_off[i] : 0;
+  }
+  __syncthreads();
+  const int L = tb.frame_len;
+  float* const xs = reinterpret_cast<float*>(bufB);      // raw samples (<= NF floats)
+  float* const zr = reinterpret_cast<float*>(bufA);      // windowed, zero padded = complex input
+  const long long fstride = (long long)gridDim.x * waves;
+  for (long long frame = (long long)blockIdx.x * waves + wave; frame < total_frames; frame += fstride) {
+    const int b = (int)(frame / T), f = (int)(frame - (long long)b * T);
+    float* const frow = feats + frame * tb.num_bins;
+    if (frames && f >= frames[b]) {
+      for (int i = lane; i < tb.num_bins; i += 64) frow[i] = 0.f;
+      continue;
+    }
+    const long long s0 = (long long)b * wav_stride + (long long)f * tb.frame_shift;
+    // 1. load + DC offset
+    float part = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      float v;
+      if (wav_dtype == 0) v = (float)reinterpret_cast<const short*>(wav)[s0 + j];
+      else v = reinterpret_cast<const float*>(wav)[s0 + j];
+      v *= scale;
+      xs[j] = v;
+      part += v;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    const float mean = part / (float)L;
+    fbank_any_wave_sync();
+    // 2. pre-emphasis (replicate-pad first sample) + window, zero pad to NF
+    for (int j = lane; j < NF; j += 64) {
+      float y = 0.f;
+      if (j < L) {
+        const float cur = xs[j] - mean;
+        const float prev = xs[j > 0 ? j - 1 : 0] - mean;
+        y = (cur - 0.97f * prev) * window[j];
+      }
+      zr[j] = y;
+    }
+    fbank_any_wave_sync();
+    // 3. CN-point complex FFT, Stockham autosort: radix-4 stages, then one radix-2 stage if a factor 2 is left
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    for (; Ns * 4 <= CNn; Ns *= 4) {
+      const int nb = CNn >> 2;
+      for (int j = lane; j < nb; j += 64) {
+        const int k = j & (Ns - 1);
+        float2 v0 = src[j], v1 = src[j + nb], v2 = src[j + 2 * nb], v3 = src[j + 3 * nb];
+        if (Ns > 1) {
+          const int step = (NF / (Ns * 4)) * k;
+          v1 = fbank_any_cmul(v1, tw[step]);
+          v2 = fbank_any_cmul(v2, tw[2 * step]);
+          v3 = fbank_any_cmul(v3, tw[3 * step]);
+        }
+        const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+        const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+        const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+        const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i * (v1 - v3)
+        const int d0 = ((j - k) << 2) + k;
+        dst[d0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+        dst[d0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+        dst[d0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+        dst[d0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+      }
+      fbank_any_wave_sync();
+      float2* t = src; src = dst; dst = t;
+    }
+    if (Ns < CNn) {                                   // Ns * 2 == CN
+      const int nb = CNn >> 1;
+      for (int j = lane; j < nb; j += 64) {
+        const int k = j & (Ns - 1);
+        const float2 v0 = src[j];
+        const float2 v1 = fbank_any_cmul(src[j + nb], tw[(NF / (Ns * 2)) * k]);
+        const int d0 = ((j - k) << 1) + k;
+        dst[d0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+        dst[d0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+      }
+      fbank_any_wave_sync();
+      float2* t = src; src = dst; dst = t;
+    }
+    // 4. unpack to the real-input spectrum, power: P[k], k = 0..CN
+    float* P = reinterpret_cast<float*>(dst);
+    for (int k = lane; k <= CNn; k += 64) {
+      const float2 zk = src[k & (CNn - 1)];
+      const float2 zc = src[(CNn - k) & (CNn - 1)];
+      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+      const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+      const float2 w = tw[k & (NF - 1)];
+      const float xr = er + (orr * w.x - oi * w.y);
+      const float xi = ei + (orr * w.y + oi * w.x);
+      P[k] = xr * xr + xi * xi;
+    }
+    fbank_any_wave_sync();
+    // 5. mel filterbank + log: four lanes per bin, lane sub takes taps sub, sub + 4, ...
+    for (int b0 = 0; b0 < tb.num_bins; b0 += 16) {
+      const int bin = b0 + (lane >> 2), sub = lane & 3;
+      const int len = mel_len_s[bin];                 // (0 beyond num_bins)
+      const float* pp = P + mel_start_s[bin];
+      const float* wp = tb.mel_w + mel_off_s[bin];
+      float acc = 0.f;
+      for (int i = sub; i < len; i += 4) acc += wp[i] * pp[i];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      if (bin < tb.num_bins && sub == 0) frow[bin] = v;
+    }
+    fbank_any_wave_sync();
+  }
+}
+
+// ws_debug_fbank_mode: 0 shipped kernel, 1 the packed-fp32 build, 2 the any-length kernel for every frontend (tests and tools/fbank_race_probe.py only)
 static std::atomic<int> g_fbank_mode{0};
 void set_fbank_debug_mode(int mode) { g_fbank_mode.store(mode, std::memory_order_relaxed); }
+
+// LDS of the any-length kernel: twiddles, the three bin tables, per wavefront the two transform buffers
+static size_t fbank_any_lds_bytes(int fft_n, int waves) {
+  return (size_t)fft_n * 8 + 3 * 128 * 4 + (size_t)waves * ((size_t)fft_n + 4) * 8;
+}
+static int fbank_any_waves(int fft_n) {
+  int w = 16;
+  while (w > 1 && fbank_any_lds_bytes(fft_n, w) > 150 * 1024) --w;
+  return w;
+}
+bool fbank_fast_kernel_fits(const FbankTables& t) {
+  return t.fft_n == FFT_N && t.frame_len <= FFT_N && t.mel_w_total <= MEL_W_MAX && t.num_bins <= 128 &&
+         t.mel_wpad_total <= MEL_WPAD_MAX && t.mel_pad_reach <= FFT_N;
+}
 
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream, const int* frames) {
   if (T <= 0 || B <= 0) return hipSuccess;
-  if (t.fft_n != FFT_N || t.frame_len > FFT_N || t.mel_w_total > MEL_W_MAX || t.num_bins > 128 ||
-      t.mel_wpad_total > MEL_WPAD_MAX || t.mel_pad_reach > t.frame_len)
+  if (t.fft_n < 16 || t.fft_n > 4096 || (t.fft_n & (t.fft_n - 1)) || t.frame_len > t.fft_n || t.num_bins > 128)
     return hipErrorInvalidValue;
   const long long total = (long long)B * T;
   const int cus = current_device_cus();
+  const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
+  const int mode = g_fbank_mode.load(std::memory_order_relaxed);
+  if (mode == 2 || !fbank_fast_kernel_fits(t)) {
+    const int waves = fbank_any_waves(t.fft_n);
+    const size_t lds_bytes = fbank_any_lds_bytes(t.fft_n, waves);
+    static size_t lds_granted[WS_MAX_DEVICES] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fbank_any_kernel), lds_bytes, lds_granted);
+    if (e != hipSuccess) return e;
+    long long blocks = (total + waves - 1) / waves;
+    const long long per_cu = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 40 * 1024 ? 2 : 4);
+    if (blocks > cus * per_cu) blocks = cus * per_cu;
+    hipLaunchKernelGGL(fbank_any_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, stream, t, wav, wav_dtype,
+                       (long long)wav_stride, scale, window, T, total, feats, frames);
+    return hipGetLastError();
+  }
   long long blocks = (total + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const long long resident = (long long)cus * FBANK_WGS_PER_CU;
   if (blocks > resident) blocks = resident;
-  const float* window = window_type == 1 ? t.window_povey : t.window_hamming;
-  if (g_fbank_mode.load(std::memory_order_relaxed) == 1)
+  if (mode == 1)
     hipLaunchKernelGGL(fbank_kernel_packed, dim3((unsigned)blocks), dim3(64 * FRAMES_PER_BLOCK), 0, stream, t, wav,
                        wav_dtype, N, (long long)wav_stride, scale, window, T, total, feats, frames);
   else

@@ -267,13 +267,19 @@ struct FbankTables {
   int frame_len, frame_shift, fft_n, num_bins;
   int mel_w_total;               // number of packed weights
   int mel_wpad_total;            // floats of the per-pass zero-padded weight table the kernel builds in LDS
-  int mel_pad_reach;             // 1 + the largest power-spectrum index a padded tap reads (must stay below frame_len:
-                                 // those LDS words hold this frame's samples, finite, and are multiplied by 0)
+  int mel_pad_reach;             // 1 + the largest power-spectrum index a zero-weight (padded) tap of the 512-point
+                                 // kernel reads.  Those reads land in bufB behind P[0..256]: words 257..511 hold the
+                                 // frame's OWN third-stage FFT output (stage 2 rewrites all of bufB[0..511] every
+                                 // frame, so they are finite for finite input and get multiplied by 0); words 512..519
+                                 // (the row padding) are never written.  Hence reach <= 512 = fft_n; a table that
+                                 // reaches further -- or a change of the FFT ping-pong that stops rewriting bufB --
+                                 // must go through the any-length kernel, which skips taps instead of padding them
 };
 hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, int B, int N,
                         int64_t wav_stride, float scale, int window_type, int T, float* feats,
                         hipStream_t stream, const int* frames = nullptr);
-void set_fbank_debug_mode(int mode);   // ws_debug_fbank_mode (0 shipped kernel, 1 packed-fp32 reproducer)
+bool fbank_fast_kernel_fits(const FbankTables& t);   // the specialised 512-point kernel takes this frontend
+void set_fbank_debug_mode(int mode);   // ws_debug_fbank_mode (0 shipped kernels, 1 packed-fp32 reproducer, 2 any-length kernel for all)
 // lens (optional, [B]): valid frames per utterance of a ragged batch -- fbank writes zero rows beyond
 // them, CMN averages over / subtracts from the valid rows only
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr);
