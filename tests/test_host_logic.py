@@ -335,3 +335,24 @@ def test_chain_string_parser_known_answers():
         for c in (example, "whitening | length-norm ", " length-norm", "mean-subtract --scp a|length-norm",
                   "lda --dim=20 --scp  x --utt2spk=u --eps 1e-5"):
             assert chain_string_to_dict(c) == ref(c)
+
+
+def test_subsegment_mirror_matches_reference_golden():
+    """wespeaker_amd.speaker.subsegment / subsegment_ids / ws_num_windows against what the reference's own
+    diar/extract_emb.py:55-83 returned (tests/golden/subsegment_ref.npz, row-index features)."""
+    import os
+    from wespeaker_amd import _lib
+    from wespeaker_amd.speaker import subsegment, subsegment_ids
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subsegment_ref.npz"))
+    n_cases = len([k for k in g.files if k.endswith("_params")])
+    assert n_cases == 8
+    for k in range(n_cases):
+        nf, seg_len, win, per = (int(v) for v in g["case%d_params" % k])
+        fb = np.repeat(np.arange(nf, dtype=np.float32)[:, None], 4, axis=1)
+        seg_id = "{:08d}-{:08d}".format(1230, 1230 + seg_len * 10)
+        names, wins = subsegment(fb, seg_id, win, per, 10)
+        assert names == [str(x) for x in g["case%d_names" % k]]
+        assert np.array_equal(np.stack(wins)[:, :, 0].astype(np.int32), g["case%d_rows" % k])
+        assert subsegment_ids(seg_id, seg_len, win, per) == names
+        assert _lib.lib().ws_num_windows(seg_len, win, per) == len(names)
+    assert _lib.lib().ws_num_windows(0, 150, 75) == 0 and _lib.lib().ws_num_windows(10, 0, 75) == 0

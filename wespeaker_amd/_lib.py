@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("WS_LIB_PATH") or os.path.join(_HERE, "lib", "libwespe
 
 _lib = None
 
-ABI_VERSION = 102      # = WS_VERSION of include/wespeaker_amd.h
+ABI_VERSION = 103      # = WS_VERSION of include/wespeaker_amd.h
 
 # name -> (restype, argtypes); also used by the ABI test to check every header symbol is exported
 SIGNATURES = {
@@ -48,6 +48,10 @@ SIGNATURES = {
     "ws_resample": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "ws_extract_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_void_p]),
+    "ws_cmn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ws_num_windows": (c_int, [c_int, c_int, c_int]),
+    "ws_extract_windows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                   c_int, c_void_p, c_int, c_void_p]),
     "ws_engine_set_precision": (c_int, [c_void_p, c_int]),
     "ws_engine_check_range": (c_int, [c_void_p, c_void_p]),
     "ws_debug_dispatch_log": (c_int, [c_int]),

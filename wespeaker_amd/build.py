@@ -73,11 +73,20 @@ def build(force=False, verbose=True):
         vmap = os.path.join(OBJDIR, "exports.map")
         with open(vmap, "w") as f:
             f.write("{ global: ws_*; local: *; };\n")
+        # linked under a temporary name, ISA-checked there, and only then moved into place: a library that fails the
+        # check never sits at LIB, where the next build() (no jobs, LIB present) would have returned it unchecked
+        tmp_lib = LIB + ".tmp"
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + vmap,
-               "-o", LIB] + objs
+               "-o", tmp_lib] + objs
         rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError("link failed:\n" + out)
+        bad = check_isa(tmp_lib)
+        if bad:
+            os.remove(tmp_lib)
+            raise RuntimeError("forbidden packed-fp32 instruction forms in the library (DESIGN.md 6.0):\n" +
+                               "\n".join("  %s: %d x %s" % b for b in bad))
+        os.replace(tmp_lib, LIB)
     # the C++ caller of the C-ABI (native twin of runtime/core/bin/extract_emb_main.cc)
     main_src = os.path.join(CSRC, "bin", "extract_emb_main.cc")
     if (need_link or not os.path.exists(MAIN_BIN)
@@ -91,11 +100,6 @@ def build(force=False, verbose=True):
         rc, out = run(cmd)
         if rc != 0:
             raise RuntimeError("extract_emb_main build failed:\n" + out)
-    if need_link:
-        bad = check_isa(LIB)
-        if bad:
-            raise RuntimeError("forbidden packed-fp32 instruction forms in the library (DESIGN.md 6.0):\n" +
-                               "\n".join("  %s: %d x %s" % b for b in bad))
     return LIB
 
 

@@ -208,8 +208,14 @@ int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, 
   if (T == 0 || batch == 0) return WS_OK;
   hipStream_t st = (hipStream_t)stream;
   WS_HIP_CHECK(hipSetDevice(fe->device));
+  // (validated BEFORE a ring slot is taken: a refused call must not advance the ring or touch a slot's table)
+  for (int b = 0; b < batch; ++b) {
+    if (num_samples[b] < 0 || num_samples[b] > max_samples) {
+      set_error("ws_fbank_ragged: utterance %d has %d samples, max_samples is %d", b, num_samples[b], max_samples);
+      return WS_ERR_INVALID_ARG;
+    }
+  }
   ws_frontend::FrameSlot& sl = fe->slots[fe->next_slot];
-  fe->next_slot = (fe->next_slot + 1) % ws_frontend::FRAME_SLOTS;
   if (!sl.done) WS_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   if (sl.used) WS_HIP_CHECK(hipEventSynchronize(sl.done));     // the kernels that read this slot's table have finished
   if ((size_t)batch > sl.cap) {
@@ -220,19 +226,21 @@ int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, 
     WS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), cap * sizeof(int), 0));
     sl.cap = cap;
   }
-  for (int b = 0; b < batch; ++b) {
-    if (num_samples[b] < 0 || num_samples[b] > max_samples) {
-      set_error("ws_fbank_ragged: utterance %d has %d samples, max_samples is %d", b, num_samples[b], max_samples);
-      return WS_ERR_INVALID_ARG;
-    }
-    sl.pinned[b] = ws_num_frames(num_samples[b], fe->sample_rate);
-  }
-  WS_HIP_CHECK(hipMemcpyAsync(sl.dev.ptr, sl.pinned, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, st));
-  WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, max_samples, wav_stride, scale, window_type, T,
-                            feats, st, sl.dev.as<int>()));
-  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st, sl.dev.as<int>()));
-  WS_HIP_CHECK(hipEventRecord(sl.done, st));
+  fe->next_slot = (fe->next_slot + 1) % ws_frontend::FRAME_SLOTS;
+  for (int b = 0; b < batch; ++b) sl.pinned[b] = ws_num_frames(num_samples[b], fe->sample_rate);
+  // From the copy on, the slot's pinned / device tables may be in use by the stream: whatever fails below, the event
+  // is recorded behind everything that was enqueued and the slot is marked used, so that its next user waits for it
+  // (a failed launch used to leave `done` unrecorded: the next reuse could rewrite the table under a copy in flight)
+  hipError_t he = hipMemcpyAsync(sl.dev.ptr, sl.pinned, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess)
+    he = launch_fbank(fe->tables, wav, wav_dtype, batch, max_samples, wav_stride, scale, window_type, T, feats, st,
+                      sl.dev.as<int>());
+  if (he == hipSuccess && cmn) he = launch_cmn(feats, batch, T, fe->num_bins, st, sl.dev.as<int>());
+  const hipError_t re = hipEventRecord(sl.done, st);
   sl.used = true;
+  if (re != hipSuccess) (void)hipStreamSynchronize(st);        // no event to wait for: drain the stream instead
+  WS_HIP_CHECK(he);
+  WS_HIP_CHECK(re);
   return WS_OK;
 }
 
@@ -557,6 +565,66 @@ int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav
   if (r) return r;
   WS_HIP_CHECK(launch_chunk_average(cemb, n_chunks, E, emb, st));
   return n_chunks;
+}
+
+int ws_cmn(float* feats, int batch, int num_frames, int feat_dim, ws_stream stream) {
+  if (!feats || batch < 0 || num_frames < 0 || feat_dim <= 0) { set_error("ws_cmn: invalid argument"); return WS_ERR_INVALID_ARG; }
+  if (batch == 0 || num_frames == 0) return WS_OK;
+  WS_HIP_CHECK(launch_cmn(feats, batch, num_frames, feat_dim, (hipStream_t)stream));
+  return WS_OK;
+}
+
+int ws_num_windows(int seg_length, int window_frames, int period_frames) {
+  if (seg_length <= 0 || window_frames <= 0 || period_frames <= 0) return 0;
+  if (seg_length <= window_frames) return 1;
+  // len(range(0, seg_length - window + period, period))   (diar/extract_emb.py:74-75)
+  return (seg_length - window_frames + period_frames + period_frames - 1) / period_frames;
+}
+
+int ws_extract_windows(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int num_samples,
+                       int seg_length, int window_frames, int period_frames, float scale, int window_type,
+                       int subseg_cmn, float* emb, int max_windows, ws_stream stream) {
+  if (!eng || !fe || !wav || !emb || window_frames <= 0 || period_frames <= 0 || seg_length <= 0) {
+    set_error("ws_extract_windows: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_extract_windows: engine not finalized"); return WS_ERR_STATE; }
+  if (fe->num_bins != eng->feat_dim) {
+    set_error("ws_extract_windows: frontend has %d mel bins, model expects %d", fe->num_bins, eng->feat_dim);
+    return WS_ERR_SHAPE;
+  }
+  const int F = fe->num_bins, E = eng->embed_dim;
+  const int total = ws_num_frames(num_samples, fe->sample_rate);
+  if (total <= 0) { set_error("ws_extract_windows: segment shorter than one frame"); return WS_ERR_INVALID_ARG; }
+  if (window_frames > eng->model->max_frames()) {
+    set_error("ws_extract_windows: %d frames per window exceed the finalized capacity %d", window_frames,
+              eng->model->max_frames());
+    return WS_ERR_CAPACITY;
+  }
+  const int n_win = ws_num_windows(seg_length, window_frames, period_frames);
+  if (n_win > max_windows) {
+    set_error("ws_extract_windows: %d windows, the output holds %d", n_win, max_windows);
+    return WS_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  // scratch: [total][F] segment feats | [n_win][window][F] window tensor
+  const size_t n_feats = ((size_t)total * F + 3) & ~size_t(3);
+  const size_t need = (n_feats + (size_t)n_win * window_frames * F) * sizeof(float);
+  if (eng->chunk_scratch.bytes < need) {
+    WS_HIP_CHECK(hipStreamSynchronize(st));       // earlier calls may still read the old buffer
+    WS_HIP_CHECK(eng->chunk_scratch.alloc(need + need / 2));
+  }
+  float* feats = eng->chunk_scratch.as<float>();
+  float* wins = feats + n_feats;
+  int r = ws_fbank(fe, wav, wav_dtype, 1, num_samples, num_samples, scale, window_type, 0, feats, stream);
+  if (r) return r;
+  WS_HIP_CHECK(launch_window_gather(feats, total, F, window_frames, period_frames, seg_length, n_win, wins, st));
+  if (subseg_cmn) WS_HIP_CHECK(launch_cmn(wins, n_win, window_frames, F, st));
+  r = eng->model->forward(wins, n_win, window_frames, emb, st);
+  (void)E;
+  if (r) return r;
+  return n_win;
 }
 
 int ws_engine_set_precision(ws_engine* eng, int mode) {

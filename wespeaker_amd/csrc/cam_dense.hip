@@ -199,7 +199,7 @@ __device__ __forceinline__ void cam_dense_layer_body(const CamDenseParams& p, fl
   {
     const int i1 = tid + 256;                      // Wl: 32 rows x 384 floats = 32 x 12 lines
     warm[0] = p.Wl[(long long)(tid / 12) * p.ldwl + (tid % 12) * 32];
-    warm[1] = i1 < 32 * 12 ? p.Wl[(long long)(i1 / 12) * p.ldwl + (i1 % 12) * 32] : p.cw2[(i1 - 32 * 12) * 32];
+    warm[1] = i1 < 32 * 12 ? p.Wl[(long long)(i1 / 12) * p.ldwl + (i1 % 12) * 32] : p.cw2[((i1 - 32 * 12) & 63) * 32];   // (64 lines: stay inside cw2)
     warm[2] = p.cw1[tid * 32];                     // cw1 [64][128] = 256 lines; cw2 [32][64] = 64 lines (above)
   }
   __builtin_amdgcn_sched_barrier(0);

@@ -464,6 +464,43 @@ hipError_t launch_chunk_gather(const float* feats, int total, int F, int cf, int
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ diarization sub-segment windows
+// subsegment() of wespeaker/diar/extract_emb.py:55-83 on the device: window w covers frames [w * period,
+// min(w * period + window, seg_length)) of the segment's fbank -- clipped to the num_frames rows that exist, like the
+// numpy slice -- and is completed to `window` rows by tiling ITS OWN rows cyclically (np.resize of the slice); a
+// segment of seg_length <= window is ONE window tiled from the whole fbank.  A window without any row is zeros
+// (np.resize of an empty array).  dst [n_windows][window][F], one float4 per thread.
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ feats, int num_frames, int F,
+                                                            int window, int period, int seg_length, int n_windows,
+                                                            float* __restrict__ dst) {
+  const int f4 = F >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_windows * window * f4) return;
+  const int c4 = (int)(i % f4);
+  const long long rowi = i / f4;
+  const int r = (int)(rowi % window), w = (int)(rowi / window);
+  int begin = 0, len = num_frames;
+  if (seg_length > window) {
+    begin = w * period;
+    int end = begin + window < seg_length ? begin + window : seg_length;
+    if (end > num_frames) end = num_frames;
+    len = end - begin;
+  }
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (len > 0) v = reinterpret_cast<const float4*>(feats)[(long long)(begin + r % len) * f4 + c4];
+  reinterpret_cast<float4*>(dst)[i] = v;
+}
+
+hipError_t launch_window_gather(const float* feats, int num_frames, int F, int window, int period, int seg_length,
+                                int n_windows, float* dst, hipStream_t stream) {
+  if ((F & 3) || window <= 0 || period <= 0) return hipErrorInvalidValue;
+  const long long n = (long long)n_windows * window * (F >> 2);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(window_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, feats, num_frames,
+                     F, window, period, seg_length, n_windows, dst);
+  return hipGetLastError();
+}
+
 // avg[e] = (1/n) sum_c emb[c][e]   (speaker_engine.cc:147-158; summed in chunk order like the loop)
 __global__ __launch_bounds__(256) void chunk_average_kernel(const float* __restrict__ emb, int n,
                                                             int E, float* __restrict__ avg) {

@@ -285,6 +285,9 @@ void set_fbank_debug_mode(int mode);   // ws_debug_fbank_mode (0 shipped kernels
 hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr);
 hipError_t launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens,
                                    hipStream_t stream);
+// diarization sub-segment windows of one segment's fbank (diar/extract_emb.py:55-83): dst [n_windows][window][F]
+hipError_t launch_window_gather(const float* feats, int num_frames, int F, int window, int period, int seg_length,
+                                int n_windows, float* dst, hipStream_t stream);
 hipError_t launch_resample(const float* x, long long n_in, const float* kern, int orig, int nw, int width,
                            float* y, long long n_out, hipStream_t stream);
 // binary16 im2col of a k-tap "same" Conv1d over time: out[(b,t)][tap*F + f] = feats[b][t + tap - pad][f]
@@ -331,9 +334,6 @@ hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const dou
                                  int64_t num_trials, double* out, hipStream_t stream);
 hipError_t launch_row_gather_probe(const double* T, int K, const int32_t* idx, int64_t n, double* out,
                                    hipStream_t stream);   // ws_debug_row_gather (bench yardstick)
-hipError_t launch_plda_llr_pairs_auto(const double* EA, const double* rowc, const double* colc, const double* TT, int K,
-                                      const int32_t* idx_e, const int32_t* idx_t, int64_t num_trials, double* out,
-                                      unsigned long long* breaks, hipStream_t stream);
 
 // -------- direct 3x3, 32 -> 32 channel convolution on binary16 maps (conv3x3_direct.hip)
 bool conv3x3_direct_supported(const ConvGemmParams& p);

@@ -404,6 +404,38 @@ class NativeSpeakerModel:
         return emb, n_chunks
 
 
+    def extract_windows(self, frontend: Frontend, wav: torch.Tensor, seg_length=None, window_frames=150,
+                        period_frames=75, subseg_cmn=True, window_type="hamming", scale=1.0):
+        """Diarization sub-segment embeddings of ONE speech segment in one call (ws_extract_windows): fbank of the
+        whole segment -> the windows of diar/extract_emb.py:55-83 (`window_frames` every `period_frames`, laid out
+        from `seg_length`, the last one completed by tiling its own frames) -> optional per-window CMN -> forward
+        (cli/speaker.py:232-251, 108-123).  seg_length None = num_frames + 2, what the reference's time stamps give
+        for its own VAD segments.  Returns an (n_windows, E) tensor on the GPU."""
+        wav = wav.reshape(-1)
+        if wav.dtype == torch.int16:
+            dt = 0
+        else:
+            wav = wav.to(torch.float32)
+            dt = 1
+        wav = wav.to(self.device).contiguous()
+        n = int(wav.shape[0])
+        total = frontend.num_frames(n)
+        if seg_length is None:
+            seg_length = total + 2
+        n_win = _lib.lib().ws_num_windows(int(seg_length), int(window_frames), int(period_frames))
+        if total <= 0 or n_win <= 0:
+            raise ValueError("segment of %d samples is shorter than one frame" % n)
+        self._ensure_capacity(int(window_frames))
+        emb = torch.empty((n_win, self.embed_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            got = _lib.check(_lib.lib().ws_extract_windows(
+                self._h, frontend._h, _lib.ptr(wav), dt, n, int(seg_length), int(window_frames), int(period_frames),
+                float(scale), WINDOW_TYPES[window_type], 1 if subseg_cmn else 0, _lib.ptr(emb), n_win,
+                _lib.current_stream_ptr(self.device)), "ws_extract_windows")
+        assert got == n_win
+        return emb
+
+
 class LaneResult:
     """One batch in flight on a lane: the embeddings tensor becomes valid when `event` has fired."""
 

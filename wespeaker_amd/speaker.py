@@ -61,6 +61,34 @@ def load_model_pt(model_name_or_path: str, device=None, max_batch=64, max_frames
     return model
 
 
+def subsegment_ids(seg_id, seg_length, window_fs, period_fs):
+    """The sub-segment names of diar/extract_emb.py:55-83 ("<seg_id>-<first frame:08d>-<last frame:08d>")."""
+    if seg_length <= window_fs:
+        return [seg_id + "-{:08d}-{:08d}".format(0, seg_length)]
+    out = []
+    for begin in range(0, seg_length - window_fs + period_fs, period_fs):
+        out.append(seg_id + "-{:08d}-{:08d}".format(begin, min(begin + window_fs, seg_length)))
+    return out
+
+
+def subsegment(fbank, seg_id, window_fs, period_fs, frame_shift):
+    """Host mirror of diar/extract_emb.py:55-83 (same name, arguments and return value): (subseg ids, list of
+    (window_fs, F) arrays).  `extract_subsegment_embeddings` does this on the device; this form is for callers that
+    hold features on the host, like the reference's `extract_emb.py` reading an fbank scp."""
+    seg_begin, seg_end = seg_id.split('-')[-2:]
+    seg_length = (int(seg_end) - int(seg_begin)) // frame_shift
+    fbank = np.asarray(fbank)
+    feat_dim = fbank.shape[1]
+    subsegs = subsegment_ids(seg_id, seg_length, window_fs, period_fs)
+    if seg_length <= window_fs:
+        return subsegs, [np.resize(fbank, (window_fs, feat_dim))]
+    feats = []
+    for name in subsegs:
+        b, e = (int(t) for t in name.split('-')[-2:])
+        feats.append(np.resize(fbank[b:e], (window_fs, feat_dim)))
+    return subsegs, feats
+
+
 class Speaker:
 
     def __init__(self, model_dir: str, device=None, max_batch=64, max_frames=400):
@@ -140,18 +168,60 @@ class Speaker:
         return self._frontend(sample_rate).fbank(wav, window_type=self.window_type, cmn=cmn)
 
     def extract_embedding_from_feats(self, fbanks, batch_size, subseg_cmn):
-        """list of (T, F) arrays -> (N, E) numpy (speaker.py:108-123)."""
-        arr = np.stack(fbanks)
-        if subseg_cmn:
-            arr = arr - np.mean(arr, axis=1, keepdims=True)
-        arr_t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+        """list of (T, F) arrays (or one (N, T, F) array / tensor) -> (N, E) numpy (speaker.py:108-123).  One upload of
+        the stacked windows; the per-window CMN (`fbanks_array - np.mean(fbanks_array, axis=1)`, :110-112) runs on the
+        device (ws_cmn), then `batch_size` windows per forward like the reference's loop."""
+        if isinstance(fbanks, torch.Tensor):
+            arr_t = fbanks.to(device=self.device, dtype=torch.float32)
+            arr_t = arr_t.clone() if subseg_cmn else arr_t            # (the CMN below is in place)
+        else:
+            arr = np.ascontiguousarray(np.stack(fbanks), dtype=np.float32)
+            arr_t = torch.from_numpy(arr).to(self.device)
+        arr_t = arr_t.contiguous()
+        if arr_t.dim() != 3:
+            raise ValueError("expected N windows of (T, F) features, got shape %s" % (tuple(arr_t.shape),))
+        n, t, f = arr_t.shape
+        if subseg_cmn and n:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().ws_cmn(_lib.ptr(arr_t), n, t, f, _lib.current_stream_ptr(self.device)), "ws_cmn")
         out = []
-        for i in range(0, arr_t.shape[0], batch_size):
+        for i in range(0, n, batch_size):
             emb = self.model(arr_t[i:i + batch_size])
             emb = emb[-1] if isinstance(emb, tuple) else emb
-            out.append(emb.detach().cpu().numpy())
+            out.append(emb)
+        res = torch.cat(out).cpu().numpy() if out else np.zeros((0, self.model.embed_dim), np.float32)
         self.model.check_range()
-        return np.vstack(out)
+        return res
+
+    def extract_subsegment_embeddings(self, pcm, sample_rate, begin_ms=0, end_ms=None):
+        """One speech segment -> (subseg ids, (n, E) numpy embeddings): the body of the per-segment loop of
+        `Speaker.diarize` (cli/speaker.py:232-251) -- compute_features(cmn=False), `subsegment()`
+        (diar/extract_emb.py:55-83) with this Speaker's window / period / frame shift, per-window CMN if
+        `diar_subseg_cmn`, forward -- as ONE device call (ws_extract_windows); no feature tensor or window stack is
+        built on the host.  `pcm` is the segment's samples ((N,) or (1, N), int16-scale like the reference's
+        `pcm[0, begin_idx:end_idx]`); [begin_ms, end_ms) its position in the recording (end_ms None = begin_ms + its
+        duration): the reference lays the windows out from (end_ms - begin_ms) // frame_shift, not from the frame
+        count, and names them "{begin_ms:08d}-{end_ms:08d}-{first:08d}-{last:08d}".  (The VAD that produces the segments
+        and the clustering behind them stay out of scope: SURVEY.md s.2.)"""
+        pcm = pcm.reshape(-1)
+        if sample_rate != self.resample_rate:
+            from .audio import resample
+            pcm = resample(pcm.to(torch.float), sample_rate, self.resample_rate, self.device)
+        n = int(pcm.shape[0])
+        if end_ms is None:
+            end_ms = int(begin_ms) + n * 1000 // self.resample_rate
+        window_fs = int(self.diar_window_secs * 1000) // self.diar_frame_shift
+        period_fs = int(self.diar_period_secs * 1000) // self.diar_frame_shift
+        seg_length = (int(end_ms) - int(begin_ms)) // self.diar_frame_shift
+        seg_id = "{:08d}-{:08d}".format(int(begin_ms), int(end_ms))
+        subsegs = subsegment_ids(seg_id, seg_length, window_fs, period_fs)
+        emb = self.model.extract_windows(self._frontend(self.resample_rate), pcm, seg_length=seg_length,
+                                         window_frames=window_fs, period_frames=period_fs,
+                                         subseg_cmn=self.diar_subseg_cmn, window_type=self.window_type)
+        res = emb.cpu().numpy()
+        self.model.check_range()
+        assert len(subsegs) == res.shape[0]
+        return subsegs, res
 
     # ------------------------------------------------------------------------------ extraction
     def extract_embedding(self, audio_path: str):
