@@ -444,6 +444,19 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def collective_info():
+        """What the data path's collectives ran on, for the driver's SCALE record: backend ("nccl" = RCCL on ROCm),
+        the number of ranks the process group holds, and the library version torch reports for it."""
+        if not active:
+            return {"backend": None, "ranks": 1, "library_version": None}
+        ver = None
+        if nccl:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                ver = None
+        return {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "library_version": ver}
+
     def make_model(model_name, embed_dim, max_batch, frames):
         if STUB:
             return StubExtractor(embed_dim, num_samples)
@@ -490,6 +503,14 @@ def main(argv=None):
         else:
             wav = device_wavs(max(1, n_local), num_samples, device, seed_base=1000 + rank)[:n_local]
         scorer = None
+        if rank == 0 and n_trials > 0 and STUB:
+            # host stand-in of rank 0's scoring step: the same trial list, cosine in numpy (control flow only)
+            ie_s, it_s = synth.synth_trial_pairs(n_trials, n_utts, n_utts, seed=99)
+
+            def scorer(emb):
+                u = torch.nn.functional.normalize(emb.double(), dim=1)
+                cos = (u[torch.from_numpy(ie_s).long()] * u[torch.from_numpy(it_s).long()]).sum(1)
+                return cos, cos
         if rank == 0 and n_trials > 0 and not STUB:
             from wespeaker_amd import TwoCovPLDA
             from wespeaker_amd import score as wscore
@@ -530,14 +551,19 @@ def main(argv=None):
                "steps": steps, "shard": "rank r of %d takes utterances [r*ceil(U/G), (r+1)*ceil(U/G)) "
                                          "(parallel.shard_range = tools/extract_embedding.sh's split rule)" % world,
                "per_rank_utts": parallel.shard_size(n_utts, world), "batch": per_batch,
+               "shards": [list(parallel.shard_range(n_utts, r, world)) for r in range(world)],
                "batches_per_rank": [cuts[i + 1] - cuts[i] for i in range(n_b)],
                "batches_in_flight": set_lanes.lanes if set_lanes is not None else 1}
         if sc is not None:
+            res["trials_scored_on_rank0"] = int(sc[0].shape[0])
             res["trials_per_s_inside_the_step"] = n_trials * steps / dt
             res["scores_finite"] = bool(torch.isfinite(sc[0]).all()) and bool(torch.isfinite(sc[1]).all())
         if rank == 0:
             assert emb.shape == (n_utts, embed_dim) and bool(torch.isfinite(emb).all())
             res["embedding_checksum"] = float(emb.double().abs().sum().item())
+            # order-sensitive: row i weighted by i + 1 (a gather that permuted the shards keeps the plain checksum)
+            wts = torch.arange(1, n_utts + 1, dtype=torch.float64, device=emb.device)
+            res["embedding_order_checksum"] = float((emb.double().abs().sum(1) * wts).sum().item())
         return res, m
 
     if set_mode:
@@ -555,6 +581,8 @@ def main(argv=None):
                            "total_utts": total_utts, "trials": set_trials, "per_gpu_batch": batch,
                            "engine_chunk": chunk, "frames": T, "parallelism": "utterance-sharded x%d" % world},
                 "set": res,
+                "collective_backend": dist.get_backend() if active else None,
+                "collective": collective_info(),
             }
             print(json.dumps(line), flush=True)
         if active:
@@ -926,6 +954,7 @@ def main(argv=None):
             line["throughput_vs_per_gpu_batch"] = batch_sweep
         line["embedding_checksum"] = float(all_emb.double().abs().sum().item())
         line["collective_backend"] = dist.get_backend() if active else None
+        line["collective"] = collective_info()
         if world == 1 and not args.no_cpu_baseline and not args.headline_only and not STUB:
             heavy = name.startswith("ResNet") and name not in ("ResNet18", "ResNet34")
             line["cpu_baseline"] = cpu_baseline(name, E, args.cpu_utts, budget_s=6.0 if heavy else 8.0)

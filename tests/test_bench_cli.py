@@ -51,3 +51,35 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode != 0 and "--gpus" in r.stderr
+
+
+@pytest.mark.parametrize("workload,world,total,trials", [("vox1o", 8, 4874, 37611), ("vox1o", 4, 4874, 37611),
+                                                         ("stream10k", 4, 10000, 0), ("stream10k", 8, 10000, 0)])
+def test_baseline_sets_on_four_and_eight_ranks(workload, world, total, trials):
+    """BASELINE configs 2 / 3 as the driver's 8-GPU node will run them (`bench.py --gpus N --workload ...`), here with
+    the host stand-in on gloo: contiguous ceil(U / G) shards in list order with a short last shard (VoxCeleb1-O over 8
+    ranks: 7 x 610 + 604, tools/extract_embedding.sh:39-67), equal batches inside a shard, one gather that keeps the
+    list order (the order-sensitive checksum equals the one-rank run's), rank 0 scoring the full trial list, and the
+    collective the line says it ran on."""
+    args = ("--workload", workload, "--batch", "512", "--steps", "1", "--warmup", "1", "--seconds", "0.1")
+    one = run_bench("--gpus", "1", *args)
+    many = run_bench("--gpus", str(world), *args)
+    assert many["n_gpus"] == world and many["scaling"] == "strong" and many["config"]["total_utts"] == total
+    per = -(-total // world)
+    shards = many["set"]["shards"]
+    assert len(shards) == world and shards[0][0] == 0 and shards[-1][1] == total
+    assert all(shards[r][1] == shards[r + 1][0] for r in range(world - 1))          # contiguous, in list order
+    assert [hi - lo for lo, hi in shards[:-1]] == [per] * (world - 1)
+    assert shards[-1][1] - shards[-1][0] == total - per * (world - 1) <= per         # the short last shard
+    if workload == "vox1o" and world == 8:
+        assert [hi - lo for lo, hi in shards] == [610] * 7 + [604]
+    b = many["set"]["batches_per_rank"]                                              # rank 0's plan: equal batches
+    assert sum(b) == per and max(b) - min(b) <= 1 and len(b) == -(-per // 512)
+    assert many["set"]["trials_scored_per_step"] == trials
+    if trials:
+        assert many["set"]["trials_scored_on_rank0"] == trials and many["set"]["scores_finite"]
+    for key in ("embedding_checksum", "embedding_order_checksum"):
+        x, y = one["set"][key], many["set"][key]
+        assert abs(x - y) <= 1e-9 * abs(x), key
+    assert many["collective_backend"] == "gloo" and many["collective"]["ranks"] == world
+    assert one["collective"]["ranks"] == 1 and one["collective_backend"] is None
