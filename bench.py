@@ -37,6 +37,7 @@ gather / JSON logic of THIS file can run on CPU at world size 2.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import statistics
@@ -378,6 +379,9 @@ def parse_args(argv):
     ap.add_argument("--headline-only", action="store_true",
                     help="only the --precision back-end: no other back-ends, no config legs, no PLDA, no CPU "
                          "baseline (for rocprofv3 runs: the kernel statistics then describe one workload)")
+    ap.add_argument("--sustain-s", type=float, default=5.0,
+                    help="length of the sustained window of the headline back-end (same step function, one timed "
+                         "region of this many seconds, the shader clock sampled next to it): `value_sustained`; 0 = off")
     ap.add_argument("--lanes", type=int, default=2,
                     help="batches in flight per GPU (wespeaker_amd.SpeakerModelLanes: one engine + HIP stream per "
                          "lane, step i runs on lane i %% lanes); 1 = one stream, every launch behind the previous one")
@@ -769,6 +773,65 @@ def main(argv=None):
     blocks = {}
     blocks[args.precision], all_emb = run_backend(args.precision, args.steps, args.warmup, max(1, args.windows))
 
+    # ---- sustained window: the contract's region is K steps (80 ms at the default K); the same
+    # step function held for --sustain-s seconds in ONE timed region, with the shader clock sampled every 10 ms by a
+    # one-wavefront probe on a side stream (csrc/probes.hip), so that the peak the fractions are priced against can be
+    # compared with the clock the chip held under this very load
+    sustained = None
+    if rank == 0 and world == 1 and not STUB and args.sustain_s > 0:
+        from wespeaker_amd import _lib as _wl
+        use_lanes[0] = lm is not None
+        (lm if lm is not None else model).set_precision(args.precision)
+        est_ms = blocks[args.precision]["ms_per_step"]
+        n_steps = max(args.steps, int(math.ceil(args.sustain_s * 1e3 / est_ms)))
+        period_ticks = 1000000                                          # 10 ms at the counter's nominal 100 MHz
+        n_samp = min(4096, int(n_steps * est_ms / 10.0) + 8)
+        buf = torch.zeros(2 * n_samp, dtype=torch.int64, device=device)
+        side = torch.cuda.Stream(device=device)
+        for _ in range(2):
+            step()
+        drain(None)
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            e0.record(side)
+            _wl.check(_wl.lib().ws_debug_clock_probe(_wl.ptr(buf), n_samp, period_ticks, side.cuda_stream),
+                      "ws_debug_clock_probe")
+            e1.record(side)
+        sdt, _p, _o = timed_window(n_steps)
+        side.synchronize()
+        raw = buf.cpu().numpy().astype(np.uint64).reshape(n_samp, 2)
+        cyc, rt = raw[:, 0].astype(np.float64), raw[:, 1].astype(np.float64)
+        probe_s = e0.elapsed_time(e1) * 1e-3
+        rt_hz = (rt[-1] - rt[0]) / probe_s * (n_samp / max(1.0, n_samp - 1.0)) if probe_s > 0 else 1e8
+        inside = (rt - rt[0]) / max(rt_hz, 1.0) <= sdt                    # samples taken while the window ran
+        d_c, d_r = np.diff(cyc), np.diff(rt)
+        mhz = (d_c / np.maximum(d_r, 1.0)) * rt_hz / 1e6
+        mhz_in = mhz[inside[1:]] if inside[1:].any() else mhz
+        sval = n_total * n_steps / sdt
+        sustained = {"seconds": sdt, "steps": n_steps, "value": sval, "unit": "embeddings/s",
+                     "ms_per_step": sdt / n_steps * 1e3,
+                     "rel_to_value": sval / blocks[args.precision]["value"] - 1.0,
+                     "batches_in_flight": n_lanes if lm is not None else 1,
+                     "shader_clock_mhz": {"mean": float(mhz_in.mean()), "min": float(mhz_in.min()),
+                                          "max": float(mhz_in.max()), "samples": int(mhz_in.size),
+                                          "sample_period_ms": 10.0,
+                                          "first_100ms_mean": float(mhz[:10].mean()),
+                                          "constant_counter_hz": rt_hz},
+                     "whole_step_frac_of_peak": (model.flops(1, T) * batch * n_steps / sdt / 1e12) /
+                                                (FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else F16_MFMA_PEAK_TFLOPS),
+                     "how": "one timed region (barrier + synchronize on both sides) of the same step function as "
+                            "`value`; clock = d(s_memtime) / d(s_memrealtime) of a one-wavefront probe kernel "
+                            "running on a side stream next to the window (ws_debug_clock_probe), the constant "
+                            "counter's rate calibrated against HIP events around the probe"}
+        # the peak of the guide (157.3 TF fp32) is quoted at the boost clock: the same fraction against the clock held
+        if args.precision == "fp32":
+            # 256 CUs x 4 SIMDs x (32x32x2 MACs per 64-cycle MFMA = 32 MACs per cycle) x 2 flops: 157.3 TF at 2.4 GHz
+            held_peak = 256 * 4 * 32 * 2 * sustained["shader_clock_mhz"]["mean"] * 1e6 / 1e12
+            sustained["fp32_mfma_peak_at_held_clock_tflops"] = held_peak
+            sustained["whole_step_frac_of_peak_at_held_clock"] = (model.flops(1, T) * batch * n_steps / sdt / 1e12) / held_peak
+        use_lanes[0] = False
+
     # ---- rows of the TIMED output against a small-batch run of the same utterances (the timed kernels did the work)
     self_check = None
     if rank == 0 and not STUB:
@@ -938,6 +1001,8 @@ def main(argv=None):
                              "`backends`" % args.precision,
             "value_one_batch_in_flight": (head.get("one_batch_in_flight") or {}).get("value"),
             "value_median_over_windows": head["median"],
+            "value_sustained": sustained["value"] if sustained else None,
+            "sustained": sustained,
             "value_spread_rel": head["spread_rel"],
             "roofline": head.get("roofline"),
             "self_check": self_check,

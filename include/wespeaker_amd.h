@@ -245,6 +245,11 @@ WS_API long long ws_debug_dispatch_report(char* buf, long long cap);
  * operand.  Device pointers; row_len even. */
 WS_API int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, int64_t n, double* out,
                                ws_stream stream);
+/* Clock probe of bench.py's sustained leg (no reference counterpart): ONE wavefront that stores `samples` pairs
+ * (shader-clock counter, constant-rate counter) into out[2 * samples] (DEVICE), one pair every `period_ticks` ticks of
+ * the constant-rate counter, sleeping in between.  Enqueued on a side stream it runs next to whatever the other
+ * streams execute and shows the shader clock the chip held under that load.  1..4096 samples, period 1..2^24 ticks. */
+WS_API int ws_debug_clock_probe(uint64_t* out, int samples, int64_t period_ticks, ws_stream stream);
 /* Reproducer switch of the fbank kernel (process-wide; tests and tools/fbank_race_probe.py only -- DESIGN.md 6.0).
  * The round-3 build of runtime/core/frontend/fbank.h:138-198's arithmetic used the packed-fp32 instruction forms in
  * its power-spectrum loop; next to binary16 GEMMs on another stream those returned wrong values in lanes 48..63.

@@ -9,7 +9,7 @@ OUT=gpurun_out/${TAG}.jsonl
 mkdir -p gpurun_out; rm -f "$OUT"
 point() {
   local envs="${1%%|*}" args="${1#*|}" line
-  line=$(env $envs timeout 300 python bench.py $args --headline-only --no-cpu-baseline 2> /dev/null | tail -1)
+  line=$(env $envs timeout 300 python bench.py $args --headline-only --no-cpu-baseline --sustain-s 0 2> /dev/null | tail -1)
   python - "$envs" "$args" "$line" >> "$OUT" <<'PY'
 import json, sys
 envs, args, line = sys.argv[1:4]

@@ -10,7 +10,7 @@ mkdir -p gpurun_out; rm -f "$OUT"
 point() {  # model precision batch lanes steps
   local line
   line=$(timeout 240 python bench.py --model $1 --precision $2 --batch $3 --lanes $4 --steps $5 --warmup 2 --windows 2 \
-         --headline-only --no-cpu-baseline 2> /dev/null | tail -1)
+         --headline-only --no-cpu-baseline --sustain-s 0 2> /dev/null | tail -1)
   python - "$1" "$2" "$3" "$4" "$line" >> "$OUT" <<'PY'
 import json, sys
 m, prec, b, l, line = sys.argv[1:6]

@@ -56,6 +56,7 @@ SIGNATURES = {
     "ws_engine_check_range": (c_int, [c_void_p, c_void_p]),
     "ws_debug_dispatch_log": (c_int, [c_int]),
     "ws_debug_fbank_mode": (c_int, [c_int]),
+    "ws_debug_clock_probe": (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     "ws_debug_row_gather": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "ws_debug_dispatch_report": (c_int64, [c_char_p, c_int64]),
     "ws_engine_profile_enable": (c_int, [c_void_p, c_int]),

@@ -662,6 +662,17 @@ int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, in
   return WS_OK;
 }
 
+int ws_debug_clock_probe(uint64_t* out, int samples, int64_t period_ticks, ws_stream stream) {
+  // bounded: at most 4096 samples and 2^24 ticks (0.17 s at 100 MHz) between two of them
+  if (!out || samples <= 0 || samples > 4096 || period_ticks <= 0 || period_ticks > (1LL << 24)) {
+    set_error("ws_debug_clock_probe: invalid argument (1..4096 samples, period 1..2^24 ticks)");
+    return WS_ERR_INVALID_ARG;
+  }
+  WS_HIP_CHECK(launch_clock_probe(reinterpret_cast<unsigned long long*>(out), samples,
+                                  (unsigned long long)period_ticks, (hipStream_t)stream));
+  return WS_OK;
+}
+
 int ws_debug_fbank_mode(int mode) {
   if (mode < 0 || mode > 2) {
     set_error("ws_debug_fbank_mode: mode %d (0 shipped kernels, 1 packed-fp32 reproducer build, 2 any-length kernel for "

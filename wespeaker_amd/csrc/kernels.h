@@ -332,6 +332,8 @@ hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, const doub
 hipError_t launch_plda_llr_pairs(const double* EA, const double* rowc, const double* colc,
                                  const double* TT, int K, const int32_t* idx_e, const int32_t* idx_t,
                                  int64_t num_trials, double* out, hipStream_t stream);
+// one wavefront sampling (shader-clock counter, constant-rate counter) pairs every period_ticks (probes.hip)
+hipError_t launch_clock_probe(unsigned long long* out, int samples, unsigned long long period_ticks, hipStream_t stream);
 hipError_t launch_row_gather_probe(const double* T, int K, const int32_t* idx, int64_t n, double* out,
                                    hipStream_t stream);   // ws_debug_row_gather (bench yardstick)
 
