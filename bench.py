@@ -275,6 +275,62 @@ def plda_leg(args, device, with_cpu_baseline):
     e1k = plda.prepare_test(emb_tab[:1000])
     t1k = plda.prepare_test(emb_tab[n_emb:n_emb + 1000])
     mdt, mat_dev = timed(lambda: plda.llr_matrix(e1k, nn, t1k), k)
+    # dense matrices at the size where the MFMA loop matters: 10 000 x 10 000 = 1e8 trials, the
+    # per-rank block of parallel.llr_matrix_sharded, at D = 192 (ECAPA) and D = 512 (CAM++); 800 MB of float64 scores
+    dense = {}
+    for dd in (D, 512):
+        pd = synth.synth_plda(dd, seed=7)
+        pl = plda if dd == D else TwoCovPLDA.from_params(pd["mu"], pd["transform"], pd["psi"], pd["offset"], False,
+                                                          device=device)
+        tab, _ = synth.synth_embeddings(2 * n_emb, dd, seed=11)
+        tab = torch.from_numpy(tab).to(device)
+        ea, tb = pl.prepare_test(tab[:n_emb]), pl.prepare_test(tab[n_emb:])
+        out_holder = [None]
+
+        def dense_step():
+            out_holder[0] = None                      # (release the previous 800 MB before the next launch allocates)
+            out_holder[0] = pl.llr_matrix(ea, nn, tb)
+
+        ddt, ddev = timed(dense_step, 5)
+        # the shader clock held under this kernel (f64 MFMA at full rate is the chip's most power-hungry loop): the
+        # one-wavefront probe of the sustained leg on a side stream, a pair of counters every 0.2 ms, next to 20 launches
+        from wespeaker_amd import _lib as _wl
+        n_samp = 256
+        cbuf = torch.zeros(2 * n_samp, dtype=torch.int64, device=device)
+        side = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize(device)
+        with torch.cuda.stream(side):
+            _wl.check(_wl.lib().ws_debug_clock_probe(_wl.ptr(cbuf), n_samp, 20000, side.cuda_stream), "ws_debug_clock_probe")
+        t_c = time.perf_counter()
+        n_l = 0
+        while time.perf_counter() - t_c < n_samp * 0.2e-3 * 1.05:
+            dense_step()
+            n_l += 1
+            if n_l % 4 == 0:
+                torch.cuda.current_stream(device).synchronize()
+        torch.cuda.synchronize(device)
+        raw = cbuf.cpu().numpy().astype(np.uint64).reshape(n_samp, 2).astype(np.float64)
+        mhz = np.diff(raw[:, 0]) / np.maximum(np.diff(raw[:, 1]), 1.0) * 100.0      # (counter: nominal 100 MHz)
+        mhz = mhz[8:-8]
+        tf = 2.0 * n_emb * n_emb * dd / ddev / 1e12
+        out_gbs = n_emb * n_emb * 8 / ddev / 1e9
+        dense["D%d" % dd] = {
+            "workload": "dense %d x %d LLR matrix, D = %d, float64 (1e8 trials per launch)" % (n_emb, n_emb, dd),
+            "trials_per_s": n_emb * n_emb / ddt, "ms": ddt * 1e3, "kernel_only_ms": ddev * 1e3,
+            "roofline": {"kernel": "plda_gemm_f64_big (v_mfma_f64_16x16x4_f64, 128x128 tiles, 64x64 per wavefront)",
+                         "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / F64_MFMA_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": 2.0 * n_emb * n_emb * dd,
+                         "output_write_gbs": out_gbs, "output_write_frac_of_hbm": out_gbs / HBM_PEAK_GBS,
+                         "shader_clock_mhz_under_this_kernel": {"mean": float(mhz.mean()), "min": float(mhz.min()),
+                                                                "max": float(mhz.max()), "samples": int(mhz.size)},
+                         # 256 CUs x 4 SIMDs x 16 f64 FMAs per cycle x 2: 78.6 TF at 2.4 GHz
+                         "peak_at_held_clock": 256 * 4 * 16 * 2 * float(mhz.mean()) * 1e6 / 1e12,
+                         "frac_at_held_clock": tf / (256 * 4 * 16 * 2 * float(mhz.mean()) * 1e6 / 1e12)},
+            "finite": bool(torch.isfinite(out_holder[0][::997, ::991]).all())}
+        out_holder[0] = None
+        del ea, tb, tab
+    torch.cuda.empty_cache()
     # the same trials as a trial FILE lists them -- grouped by enrollment model (two_cov_plda.py:246-256 walks the file
     # line by line; eval_sv orders its index list this way): 16 consecutive trials of a workgroup then share the
     # enrollment row, which comes from L1 -- half the cache-gather bytes
@@ -333,6 +389,7 @@ def plda_leg(args, device, with_cpu_baseline):
                                        "comes from L1: one test-row gather per trial)",
                              "bound": "cache-gather", "achieved": grouped_gbs, "peak": gather_peak_gbs, "unit": "GB/s",
                              "frac": grouped_gbs / gather_peak_gbs, "algorithmic_bytes_per_trial": bpt_g},
+        "dense_1e8": dense,
         "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
         "matrix_workload": "dense 1000x1000 LLR matrix D=%d" % D,
         "matrix_roofline": {"kernel": "plda_gemm_f64 (v_mfma_f64_16x16x4_f64, 64x64 tiles)", "bound": "mfma",
@@ -346,7 +403,7 @@ def plda_leg(args, device, with_cpu_baseline):
             {"mu": p["mu"], "transform": p["transform"], "psi": p["psi"], "offset": p["offset"],
              "normalize_length": False},
             e_t.cpu().numpy(), t_t.cpu().numpy(), ie, it)
-        return plda_info
+    return plda_info
 
 
 # ------------------------------------------------------------------------------------------ main

@@ -1485,6 +1485,31 @@ def test_full_size_plda_one_million_trials():
     assert np.abs(pairs_u.cpu().numpy()[::5000] - ref).max() < 1e-8
 
 
+def test_plda_dense_matrix_big_tiles_same_bits_and_oracle():
+    """The 128x128-tile f64 GEMM that large LLR matrices take (>= 1024 such tiles: 4096 x 4096 and up, i.e. the >= 1e8
+    -trial blocks of llr_matrix_sharded) accumulates every output's k-steps in the 64x64 kernel's order: a 4100 x 4130
+    matrix (ragged edges) equals, bit for bit, the blocks the small kernel computes for row / column sub-ranges; both
+    n-session forms (K = D with a per-test constant, K = 2 D per-model n); spot trials against the reference's formula."""
+    from wespeaker_amd import TwoCovPLDA
+    p = synth.synth_plda(192, seed=7)
+    plda = TwoCovPLDA.from_params(p["mu"], p["transform"], p["psi"], p["offset"], False)
+    emb, _ = synth.synth_embeddings(4100 + 4130, 192, seed=23)
+    e_t = plda.prepare_test(emb[:4100])
+    t_t = plda.prepare_test(emb[4100:])
+    n_per = torch.from_numpy((1 + np.arange(4100) % 3).astype(np.int32))
+    for n_sessions in (1, n_per):
+        big = plda.llr_matrix(e_t, n_sessions, t_t)                       # 33 x 33 big tiles
+        assert big.shape == (4100, 4130) and bool(torch.isfinite(big).all())
+        for r0, r1, c0, c1 in ((0, 900, 0, 1000), (3300, 4100, 3200, 4130), (2000, 2064, 100, 164)):
+            ns = n_sessions if isinstance(n_sessions, int) else n_sessions[r0:r1]
+            small = plda.llr_matrix(e_t[r0:r1], ns, t_t[c0:c1])           # < 1024 big tiles: the 64x64 kernel
+            assert torch.equal(small, big[r0:r1, c0:c1]), (r0, c0)
+    e_np, t_np = e_t.cpu().numpy(), t_t.cpu().numpy()
+    got = plda.llr_matrix(e_t, 1, t_t).cpu().numpy()
+    for (i, j) in ((0, 0), (4099, 4129), (2047, 2048), (128, 4000), (3333, 77)):
+        assert abs(got[i, j] - oplda.log_likelihood_ratio(p, e_np[i], t_np[j], 1)) < 1e-8
+
+
 def test_full_size_fbank_scale_property(frontend):
     """log-mel(alpha x) = log-mel(x) + 2 log alpha, so CMN'd features are scale invariant
     (floor effects aside); checked on a 256-utterance batch."""

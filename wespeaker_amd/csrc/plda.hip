@@ -340,10 +340,124 @@ __global__ __launch_bounds__(256) void plda_gemm_f64_kernel(const double* __rest
       }
 }
 
+// The same product on 128x128 tiles for matrices with many tiles (the >= 1e8-trial matrices that
+// llr_matrix_sharded hands every rank, two_cov_plda.py:165-184 evaluated for a whole trial matrix): four wavefronts as
+// 2 x 2, each 64x64 = 4 x 4 MFMA tiles, so a k-step of 4 issues 16 MFMAs (1024 cycles of the f64 pipe) for 8 LDS reads
+// and a 16-wide K-tile 64 MFMAs per wavefront between two barriers -- the 64x64 kernel has 16 there and runs the pipe at
+// well under half its rate.  Every output accumulates its k-steps in the same order as in the 64x64 kernel: same bits.
+// K % 16 == 0 only (the general case stays on the small kernel).
+__global__ __launch_bounds__(256, 2) void plda_gemm_f64_big_kernel(const double* __restrict__ A,
+                                                                   const double* __restrict__ rowc,
+                                                                   const double* __restrict__ colc, int M,
+                                                                   const double* __restrict__ Bm, int N, int K,
+                                                                   int n_tiles, double* __restrict__ out) {
+  __shared__ double As[128 * DS];
+  __shared__ double Bs[128 * DS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (M + 127) / 128;
+  const int li = lane & 15, lk = lane >> 4;
+  // staging: 128 rows x 16 doubles per operand; thread -> row tid >> 1, 8 doubles
+  const int sr = tid >> 1, sk = (tid & 1) * 8;
+  double2 av[4], bv[4];
+  const double* ap = nullptr;
+  const double* bp = nullptr;
+  // consecutive tiles walk down a column of tiles: they share the B panel (and each A panel is reused by the tiles of
+  // the next columns while it is still in L2)
+  auto set_tile = [&](int tile, int& m0, int& n0) {
+    const int tn = tile / tiles_m, tm = tile - tn * tiles_m;
+    m0 = tm * 128; n0 = tn * 128;
+    const int ma = m0 + sr < M ? m0 + sr : M - 1, nb = n0 + sr < N ? n0 + sr : N - 1;   // (clamped rows reach no store)
+    ap = A + (long long)ma * K + sk;
+    bp = Bm + (long long)nb * K + sk;
+  };
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = *reinterpret_cast<const double2*>(ap + k0 + 2 * q);
+      bv[q] = *reinterpret_cast<const double2*>(bp + k0 + 2 * q);
+    }
+  };
+  // Persistent workgroups (two per CU), tiles tile, tile + grid, ...: a tile's 128 KB of scores are STORED WHILE THE
+  // NEXT TILE IS MULTIPLIED -- the next tile's first K-tile is requested before the stores are issued (vmcnt retires in
+  // order: waiting for those loads then does not wait for the stores behind them).  Measured (10 000 x 10 000, round 5):
+  // the stores cost 0.18 ms of 0.96 (D = 192) either way -- one workgroup per tile, two LDS stages with one barrier per
+  // K-tile and this persistent form all land at 0.49 - 0.51 (D = 192) / 0.62 - 0.65 (D = 512) of the f64 peak at a held
+  // clock of 2.3 GHz; with the stores compiled out 0.62 / 0.70: what is left is the K loop itself (8 ds_read_b64 per 16
+  // MFMAs, two barriers per 16-wide K-tile) at ~0.75 of the pipe's rate.
+  int m0, n0;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  set_tile(tile, m0, n0);
+  fetch(0);
+  while (true) {
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += DBK) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        As[sr * DS + sk + 2 * q] = av[q].x; As[sr * DS + sk + 2 * q + 1] = av[q].y;
+        Bs[sr * DS + sk + 2 * q] = bv[q].x; Bs[sr * DS + sk + 2 * q + 1] = bv[q].y;
+      }
+      __syncthreads();
+      if (k0 + DBK < K) fetch(k0 + DBK);
+#pragma unroll
+      for (int ks = 0; ks < DBK; ks += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int im = 0; im < 4; ++im) a[im] = As[(wm * 64 + im * 16 + li) * DS + ks + lk];
+#pragma unroll
+        for (int in = 0; in < 4; ++in) b[in] = Bs[(wn * 64 + in * 16 + li) * DS + ks + lk];
+#pragma unroll
+        for (int im = 0; im < 4; ++im)
+#pragma unroll
+          for (int in = 0; in < 4; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[im], b[in], acc[im][in], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    const int cm0 = m0, cn0 = n0;
+    const int next = tile + (int)gridDim.x;
+    if (next < n_tiles) {
+      set_tile(next, m0, n0);
+      fetch(0);                                  // in front of this tile's stores
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int im = 0; im < 4; ++im)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = cm0 + wm * 64 + im * 16 + lk + 4 * r;
+        if (m >= M) continue;
+        const double rc = rowc ? rowc[m] : 0.0;
+#pragma unroll
+        for (int in = 0; in < 4; ++in) {
+          const int n = cn0 + wn * 64 + in * 16 + li;
+          if (n < N) out[(long long)m * N + n] = acc[im][in][r] + rc + (colc ? colc[n] : 0.0);
+        }
+      }
+    if (next >= n_tiles) break;
+    tile = next;
+  }
+}
+
 hipError_t launch_plda_llr_gemm(const double* EA, const double* rowc, const double* colc,
                                 int n_enroll, const double* TT, int n_test, int K, double* out,
                                 hipStream_t stream) {
   if (n_enroll <= 0 || n_test <= 0) return hipSuccess;
+  // env WS_PLDA_BIG_TILES: 0 = always the 64x64 kernel, 1 = the 128x128 kernel whenever K % 16 == 0; unset = the big
+  // tiles once they fill the chip twice over (>= 1024 of them)
+  static const int big_mode = [] { const char* ev = getenv("WS_PLDA_BIG_TILES"); return ev ? atoi(ev) : -1; }();
+  const long long big_tiles = (long long)((n_enroll + 127) / 128) * ((n_test + 127) / 128);
+  if ((K & 15) == 0 && big_mode != 0 && (big_mode == 1 || big_tiles >= 1024) && big_tiles < (1LL << 31)) {
+    const long long resident = 2LL * current_device_cus();
+    hipLaunchKernelGGL(plda_gemm_f64_big_kernel, dim3((unsigned)(big_tiles < resident ? big_tiles : resident)), dim3(256),
+                       0, stream, EA, rowc, colc, n_enroll, TT, n_test, K, (int)big_tiles, out);
+    return hipGetLastError();
+  }
   dim3 grid((n_test + 63) / 64, (n_enroll + 63) / 64);
   hipLaunchKernelGGL(plda_gemm_f64_kernel, grid, dim3(256), 0, stream, EA, rowc, colc, n_enroll, TT,
                      n_test, K, out);
