@@ -398,6 +398,34 @@ def plda_leg(args, device, with_cpu_baseline):
                             "note": "0.38 GFLOP + 8 MB of output in one %.0f-us launch: latency-bound at this "
                                     "size, not MFMA-bound" % (mat_dev * 1e6)},
         "dtype": "f64"}
+    # memory-side counters of the pair kernel (separate rocprofv3 --pmc passes of `bench.py --plda-only`, committed
+    # summary: tools/pmc_cmd.sh + tools/pmc_plda_summary.py).  The guide's counters see what leaves the L2 -- Infinity
+    # Cache hits included -- so `traffic` is fabric-side bytes per launch, and the rate is quoted against the HBM peak
+    # next to the measured gather yardstick
+    pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_plda.json")
+    if os.path.exists(pmc_path) and args.trials == 1000000:
+        with open(pmc_path) as fp:
+            pmc = json.load(fp)
+        for key, roof, dev_s, algo in (("plda_llr_pairs_random_list", "roofline", pair_dev, bpt),
+                                       ("plda_llr_pairs_grouped_list", "roofline_grouped", grouped_dev, bpt_g)):
+            c = pmc[key]
+            r = plda_info[roof]
+            r["traffic"] = c["traffic_bytes_per_launch"]
+            r["traffic_unit"] = "bytes per launch that left the L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC; Infinity-Cache hits are counted)"
+            r["traffic_source"] = "profiles/r05_pmc_plda.json"
+            r["l2_hit_rate"] = c["l2_hit_rate"]
+            r["l2_request_bytes_per_launch"] = c["l2_requests_x128B_bytes"]
+            r["fabric_gbs"] = c["traffic_bytes_per_launch"] / dev_s / 1e9
+            r["algorithmic_gbs_frac_of_hbm_peak"] = args.trials * algo / dev_s / 1e9 / HBM_PEAK_GBS
+            r["fabric_gbs_frac_of_hbm_peak"] = r["fabric_gbs"] / HBM_PEAK_GBS
+        plda_info["roofline"]["note"] = (
+            "PMC: %.0f %% of the row gathers hit the 4-MB L2 of their XCD; %.2f GB per launch leave it (algorithmic "
+            "%.2f GB) = %.1f TB/s in this run -- served by the 256-MB Infinity Cache, which holds both 15-MB tables "
+            "whole, and HBM behind it (the memory-side counters count Infinity-Cache hits too, so they cannot split "
+            "the two); against HBM's %.0f GB/s spec peak that is %.2f, against the measured gather yardstick `frac`"
+            % (100 * plda_info["roofline"]["l2_hit_rate"], plda_info["roofline"]["traffic"] / 1e9,
+               args.trials * bpt / 1e9, plda_info["roofline"]["fabric_gbs"] / 1e3, HBM_PEAK_GBS,
+               plda_info["roofline"]["fabric_gbs_frac_of_hbm_peak"]))
     if with_cpu_baseline:
         plda_info["cpu_baseline"] = plda_cpu_baseline(
             {"mu": p["mu"], "transform": p["transform"], "psi": p["psi"], "offset": p["offset"],
