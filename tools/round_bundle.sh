@@ -36,9 +36,11 @@ cd /tmp && export TMPDIR=/tmp
 # kernel tables: one headline-only run per back-end / family, so every table describes ONE workload
 prof() {  # name, bench args...
   local name=$1; shift
+  # PROFS="fp32 fp32_2lanes": only the named tables
+  if [ -n "$PROFS" ]; then case " $PROFS " in *" $name "*) ;; *) return 0;; esac; fi
   rm -rf "$OUT/prof_$name"
   # --lanes 1: every launch behind the previous one, so that a kernel's begin -> end in the table is its own duration
-  local base="--headline-only --steps 20 --windows 1 --lanes 1"
+  local base="--headline-only --steps 20 --windows 1 --lanes 1 --sustain-s 0"
   [ "$name" = plda ] && base=""
   rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o p -- python "$REPO/bench.py" $base "$@" > "$OUT/prof_$name.log" 2>&1
   python "$REPO/tools/rocprof_summary.py" "$(ls $OUT/prof_$name/*.db 2>/dev/null | head -1)" > "$OUT/${TAG}_kernel_stats_$name.md" 2>/dev/null

@@ -213,6 +213,19 @@ struct EcapaModel : ModelBase {
       if (y2_half) { p3.A16 = y2_16; p3.lda16 = C; }
       if (allf16) { p3.D = nullptr; p3.D16 = y3_16; p3.ldd16 = C; }
       p3.row_len = L0;
+      // fp32 activations, T >= 64: the SE FCs, the scale and the block residual are ONE launch (a workgroup per
+      // utterance; WS_SE_FUSED=0: the two launches, same bits)
+      static const bool se_fused_off = getenv("WS_SE_FUSED") && atoi(getenv("WS_SE_FUSED")) == 0;
+      if (T >= 64 && !allf16 && !se_fused_off && se_fc_scale_residual_supported(T, C, 128)) {
+        p3.colsum = colsum;
+        WS_LAUNCH(gemm(p3, st));
+        WS_LAUNCH(other(3 * mc, st, [&] {
+          return launch_se_fc_scale_residual(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
+                                             arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, L0, x, ldx, x_off,
+                                             y3, C, cat, 3 * C, L * C, st, f16io ? cat16 : nullptr);
+        }));
+        continue;
+      }
       if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;

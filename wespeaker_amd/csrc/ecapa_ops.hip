@@ -94,15 +94,18 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
 }
 
 // ------------------------------------------------------ SE FCs from GEMM-epilogue column sums
-// grid = B, block = 512.  C <= 1024, bottleneck <= 256.  Both FCs keep many independent 16-B
-// weight loads in flight per lane (the dependent one-row-at-a-time form was L2-latency bound).
-__global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
-    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
-    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-    int bott, float* __restrict__ s, const int* __restrict__ lens) {
-  __shared__ __attribute__((aligned(16))) float mean[1024];
-  __shared__ __attribute__((aligned(16))) float hidden[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// C <= 1024, bottleneck <= 256.  Both FCs keep many independent 16-B weight loads in flight per lane (the dependent
+// one-row-at-a-time form was L2-latency bound).  One body for the stand-alone kernel (512 threads) and the fused
+// FC + scale + residual kernel (1024 threads): an output's sum does not depend on the thread count (FC1: one
+// wavefront per row, the lanes split the C columns the same way; FC2: one thread per channel), so both give the same
+// bits.  Leaves s[0..C) in `mean` (the LDS vector is reused) when S_TO_LDS, else in s_out.
+template <int NT, bool S_TO_LDS>
+__device__ __forceinline__ void se_fc_body(const float* __restrict__ colsum, int b, int T, int C,
+                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                           const float* __restrict__ w2, const float* __restrict__ b2, int bott,
+                                           float* __restrict__ s_out, const int* __restrict__ lens, float* mean,
+                                           float* hidden, float* s_lds) {
+  const int tid = threadIdx.x;
   // ragged batch: the rows beyond lens[b] were stored as zeros, so the tile sums are right as they are and
   // only the divisor is the utterance's own length
   const float inv_len = 1.f / (float)(lens ? lens[b] : T);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
   // the tile partials of an utterance (<= 8 for T <= 448; more fall back to the serial loop): all
   // requested at once, in tile order -- a serial loop exposed one L2 round trip per tile
-  for (int c = tid; c < C; c += 512) {
+  for (int c = tid; c < C; c += NT) {
     float v = 0.f;
     if (t_last - t_first < 8) {
       float part[8];
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   // FC1: hidden = relu(W1 mean + b1); 8 rows per wavefront pass (8 x C/256 independent 16-B loads in flight:
-  // the kernel is a chain of L2 round trips, so fewer, wider passes -- 2 instead of 4 for bott = 128)
-  for (int j0 = wave * 8; j0 < bott; j0 += 64) {
+  // the kernel is a chain of L2 round trips, so fewer, wider passes -- 2 instead of 4 for bott = 128 with 8 wavefronts)
+  for (int j0 = wave * 8; j0 < bott; j0 += NT / 8) {
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // (bott % 32 == 0 on the host: a wave's 8 rows are all inside or all outside)
     const f32x4 bias1a = *reinterpret_cast<const f32x4*>(b1 + j0);   // (not behind the lane-0 branch below)
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
   }
   __syncthreads();
   // FC2: thread per output channel; its weight row is bott contiguous floats, 8 loads in flight
-  for (int c = tid; c < C; c += 512) {
+  for (int c = tid; c < C; c += NT) {
     const float* wr = w2 + (long long)c * bott;
     const float bias2 = b2[c];
     float v = 0.f;
@@ -171,8 +174,20 @@ __global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
         v += w[q][0] * h[0] + w[q][1] * h[1] + w[q][2] * h[2] + w[q][3] * h[3];
       }
     }
-    s[(long long)b * C + c] = 1.f / (1.f + expf(-(v + bias2)));
+    const float sg = 1.f / (1.f + expf(-(v + bias2)));
+    s_out[(long long)b * C + c] = sg;
+    if (S_TO_LDS) s_lds[c] = sg;
   }
+}
+
+// grid = B, block = 512
+__global__ __launch_bounds__(512) void se_fc_from_colsum_kernel(
+    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    int bott, float* __restrict__ s, const int* __restrict__ lens) {
+  __shared__ __attribute__((aligned(16))) float mean[1024];
+  __shared__ __attribute__((aligned(16))) float hidden[256];
+  se_fc_body<512, false>(colsum, blockIdx.x, T, C, w1, b1, w2, b2, bott, s, lens, mean, hidden, nullptr);
 }
 
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
@@ -219,6 +234,91 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(se_scale_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx,
                      x_off, y, ldy, s, out, ldo, o_off, T, C, total4, out16);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------- SE FCs + scale + block residual in ONE launch (round 5)
+// grid = B, block = 1024: the workgroup of utterance b first requests the first rows of x and y (their latency runs
+// under the FCs), computes s[b][:] from the column sums exactly like se_fc_from_colsum_kernel (se_fc_body: same bits),
+// keeps it in LDS and streams the utterance's T rows: out = x + y * s (the expression of se_scale_residual_kernel:
+// same bits).  A thread owns 4 fixed channels -- its s values are registers -- and every (1024 / (C/4))-th row;
+// U row slots of x / y are in flight per thread (16 16-B loads: 256 KB per CU, what one workgroup per CU needs to
+// keep HBM busy).  Replaces a 19-us latency-bound launch + a launch boundary per SE block.
+template <bool OUT16>
+__global__ __launch_bounds__(1024) void se_fc_scale_residual_kernel(
+    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, int bott, float* __restrict__ s_out,
+    const int* __restrict__ lens, const float* __restrict__ x, int ldx, int x_off, const float* __restrict__ y,
+    int ldy, float* __restrict__ out, int ldo, int o_off, uint16_t* __restrict__ out16) {
+  __shared__ __attribute__((aligned(16))) float mean[1024];
+  __shared__ __attribute__((aligned(16))) float hidden[256];
+  __shared__ __attribute__((aligned(16))) float s_lds[1024];
+  constexpr int U = 8;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cols4 = C >> 2;                  // 128 / 256 (C = 512 / 1024): divides the 1024 threads
+  const int c = (tid % cols4) * 4, r0 = tid / cols4, rp = 1024 / cols4;
+  const long long m0 = (long long)b * T;
+  const float* xp = x + m0 * ldx + x_off + c;
+  const float* yp = y + m0 * ldy + c;
+  constexpr int PRE = 4;                     // slots requested in front of the FCs (more would spill there)
+  f32x4 xv[U], yv[U];
+  auto request = [&](int u) {
+    const int r = r0 + u * rp;
+    if (r < T) {
+      xv[u] = *reinterpret_cast<const f32x4*>(xp + (long long)r * ldx);
+      yv[u] = *reinterpret_cast<const f32x4*>(yp + (long long)r * ldy);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) request(u);
+  se_fc_body<1024, true>(colsum, b, T, C, w1, b1, w2, b2, bott, s_out, lens, mean, hidden, s_lds);
+#pragma unroll
+  for (int u = PRE; u < U; ++u) request(u);
+  __syncthreads();
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_lds[c]);
+  float* op = out + m0 * ldo + o_off + c;
+  uint16_t* op16 = OUT16 ? out16 + m0 * ldo + o_off + c : nullptr;
+  for (int rb = r0; rb < T; rb += U * rp) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u * rp;
+      if (r < T) {
+        const f32x4 v = xv[u] + yv[u] * sv;
+        *reinterpret_cast<f32x4*>(op + (long long)r * ldo) = v;
+        if (OUT16) {                                 // binary16 copy for the f16 GEMM back-end
+          typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+          f16x4e hv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
+          *reinterpret_cast<f16x4e*>(op16 + (long long)r * ldo) = hv;
+        }
+        const int rn = r + U * rp;                   // this slot's next row
+        if (rn < T) {
+          xv[u] = *reinterpret_cast<const f32x4*>(xp + (long long)rn * ldx);
+          yv[u] = *reinterpret_cast<const f32x4*>(yp + (long long)rn * ldy);
+        }
+      }
+    }
+  }
+}
+
+bool se_fc_scale_residual_supported(int T, int C, int bottleneck) {
+  return C <= 1024 && (C & 255) == 0 && bottleneck <= 256 && (bottleneck & 31) == 0 && T >= 64 &&
+         1024 % (C >> 2) == 0;
+}
+
+hipError_t launch_se_fc_scale_residual(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, int bottleneck, float* s,
+                                       const int* lens, const float* x, int ldx, int x_off, const float* y, int ldy,
+                                       float* out, int ldo, int o_off, hipStream_t stream, uint16_t* out16) {
+  if (!se_fc_scale_residual_supported(T, C, bottleneck) || ((ldx | x_off | ldy | ldo | o_off) & 3))
+    return hipErrorInvalidValue;
+  if (out16)
+    hipLaunchKernelGGL(se_fc_scale_residual_kernel<true>, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2,
+                       b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16);
+  else
+    hipLaunchKernelGGL(se_fc_scale_residual_kernel<false>, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2,
+                       b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16);
   return hipGetLastError();
 }
 

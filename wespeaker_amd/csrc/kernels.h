@@ -169,6 +169,12 @@ hipError_t launch_se_scale_residual_f16(const uint16_t* x16, int ldx, int x_off,
 hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const float* y, int ldy,
                                     const float* s, float* out, int ldo, int o_off, int B, int T,
                                     int C, hipStream_t stream, uint16_t* out16 = nullptr);
+// the SE FCs and the scale + residual pass in one launch (one workgroup per utterance; same bits as the two launches)
+bool se_fc_scale_residual_supported(int T, int C, int bottleneck);
+hipError_t launch_se_fc_scale_residual(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, int bottleneck, float* s,
+                                       const int* lens, const float* x, int ldx, int x_off, const float* y, int ldy,
+                                       float* out, int ldo, int o_off, hipStream_t stream, uint16_t* out16 = nullptr);
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
 // over T of h, then bias_img[b][j] = b1[j] + W1[j][C:2C].mean + W1[j][2C:3C].std
 hipError_t launch_astp_std_from_colsum(const float* h, int ldh, int B, int T, int C,
