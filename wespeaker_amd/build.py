@@ -84,7 +84,7 @@ def build(force=False, verbose=True):
         bad = check_isa(tmp_lib)
         if bad:
             os.remove(tmp_lib)
-            raise RuntimeError("forbidden packed-fp32 instruction forms in the library (DESIGN.md 6.0):\n" +
+            raise RuntimeError("forbidden instruction forms / pairs in the library (DESIGN.md 6.0):\n" +
                                "\n".join("  %s: %d x %s" % b for b in bad))
         os.replace(tmp_lib, LIB)
     # the C++ caller of the C-ABI (native twin of runtime/core/bin/extract_emb_main.cc)
@@ -155,7 +155,8 @@ def check_isa(lib_path=LIB):
             txt = subprocess.run([objdump, "-d", f.name], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                  text=True, check=True).stdout
         cur = "?"
-        for line in txt.splitlines():
+        lines = txt.splitlines()
+        for li, line in enumerate(lines):
             m = sym.match(line)
             if m:
                 cur = m.group(1)
@@ -163,7 +164,57 @@ def check_isa(lib_path=LIB):
             m = pat.search(line)
             if m and not any(e in cur for e in ISA_CHECK_EXEMPT):
                 hits[(cur, m.group(1))] = hits.get((cur, m.group(1)), 0) + 1
+            if _store_data_overwritten(lines, li):
+                key = (cur, "wide store + VALU write of its data registers")
+                hits[key] = hits.get(key, 0) + 1
     return sorted((k, n, op) for (k, op), n in hits.items())
+
+
+_WIDE_STORE = None
+
+
+def _store_data_overwritten(lines, li):
+    """A second rule (round 5): a store of more than 64 bits whose data VGPRs a VALU instruction
+    overwrites within the next two wait states.  LLVM pads that pair with s_nop only when the store has no scalar
+    offset register; `buffer_store_dwordx4 v[12:15], v185, s[28:31], s0 offen` directly in front of
+    `v_pk_add_f32 v[12:13], ..` went out unpadded and MI355X stored the new values of some lanes
+    (tools/conv_stream_probe: the last tile of every workgroup of the persistent kernel's CONV form)."""
+    import re
+    global _WIDE_STORE
+    if _WIDE_STORE is None:
+        _WIDE_STORE = (re.compile(r"^\s*((?:buffer|global|flat|scratch)_store_dwordx[34])\s+([^/]*)"),
+                       re.compile(r"v\[(\d+):(\d+)\]"), re.compile(r"^v(\d+)$"))
+    st, vrange, vone = _WIDE_STORE
+    m = st.match(lines[li])
+    if not m:
+        return False
+    ops = [x.strip() for x in m.group(2).split(",")]
+    data = ops[0] if m.group(1).startswith("buffer") else (ops[1] if len(ops) > 1 else "")
+    dm = vrange.match(data)
+    if not dm:
+        return False
+    lo, hi = int(dm.group(1)), int(dm.group(2))
+    waited = 0
+    for nxt in lines[li + 1:li + 4]:
+        ins = nxt.split("//")[0].strip()
+        if not ins:
+            continue
+        if ins.startswith("s_nop"):
+            waited += int(ins.split()[1], 0) + 1
+        elif ins.startswith("v_") and not ins.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+            dst = ins.split(None, 1)[1].split(",")[0].strip() if " " in ins else ""
+            wm = vrange.match(dst) or vone.match(dst)
+            if wm:
+                wlo = int(wm.group(1))
+                whi = int(wm.group(2)) if wm.re is vrange else wlo
+                if wlo <= hi and whi >= lo:
+                    return waited < 2
+            waited += 1
+        else:
+            waited += 1
+        if waited >= 2:
+            return False
+    return False
 
 
 if __name__ == "__main__":

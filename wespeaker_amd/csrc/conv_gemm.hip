@@ -1879,7 +1879,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // fp32 back-end, plain 1x1 layer with a bias / ReLU / BN epilogue: whole rounds of 128x128 tiles go to the
   // persistent kernel (gemm_f32_stream.hip), the remaining rows re-enter below with m_begin set
   if constexpr (PREC == 0) {
-    if (mode == 3) {
+    // (... and the 3x3 / stride 1 layers with 32-channel K-tiles inside one tap: the same kernel's CONV form)
+    if (mode == 3 || (mode == 0 && gemm_f32_stream_is_conv3(p))) {
       const int srows = gemm_f32_stream_rows(p, slots / 2);
       if (srows > 0) {
         hipError_t e = launch_gemm_f32_stream(p, srows, slots / 2, stream);

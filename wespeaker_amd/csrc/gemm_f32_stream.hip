@@ -97,7 +97,13 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // kernels (same bits).  Its rows -- the same 128-B row segments the block's stores write -- are requested into
 // registers one K-tile ahead of the tile's last K-tile (16 or 8 raw buffer loads per wavefront in the free MFMA gaps
 // of k-groups 1 and 2) and consumed in epilogue steps 5..8.
-template <int WM, int TN, int COLSUM, bool RES = false>       // COLSUM: 0 none, 1 column sums, 2 column sums + sums of squares
+// CONV (round 5): the A operand of a 3x3 / stride 1 / pad 1 convolution over channels-last images (the BasicBlock
+// and Bottleneck 3x3 layers of wespeaker/models/resnet.py:35-107 with 128 / 256 planes).  K-tile kt is 32 channels of
+// ONE filter tap (k = tap * Cin + ci, the implicit-GEMM kernels' order: same bits), so a piece's source is the row's
+// centre pixel + a wave-uniform tap offset; a tap that falls outside the image reads 16 zero bytes instead (nine
+// validity bits per piece row, computed once per tile) -- every piece is still exactly one DMA operation, which the
+// vmcnt arithmetic of the barriers relies on.
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
 __global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
   constexpr int WN = 4 / TN;                 // wavefront columns
@@ -167,6 +173,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // [8 (q - APIECES), +8) of W; wavefront w copies pieces [w NP, (w + 1) NP).
   // lane l of a piece: row rr = l >> 3, physical 16-B chunk pc = l & 7 <- logical chunk pc ^ key(row).
   unsigned voff[NP];
+  unsigned vmask[CONV ? NP : 1];             // CONV: bit (3 ty + tx) = tap (ty, tx) of the piece row lies inside the image
   auto piece_is_w = [&](int i) { return wave * NP + i >= APIECES; };          // wave-uniform
   auto set_tile_offsets = [&](int seq) {
     int m0, n0;
@@ -178,16 +185,44 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       const int row = q * 8 + r8;
       const int c = c8 ^ ((row >> 1) & 7);
       const int ld = isw ? p.ldw : p.lda, off = isw ? 0 : p.a_off, row0 = isw ? n0 : m0;
-      voff[i] = (unsigned)(((unsigned long long)(row0 + row) * ld + off) * 4ull + c * 16);   // (< 2^32: the guard)
+      unsigned long long lin = (unsigned long long)(row0 + row);      // plain forms: the operand's own row
+      if (CONV) {
+        // the row's centre pixel (stride 1, pad 1: the input pixel under tap (1, 1)) and which taps lie inside the
+        // image; (computed for the W pieces too and not used there: a select instead of a branch)
+        const int m = m0 + row;
+        const int img = m / HW, rem = m - img * HW;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const unsigned pix = (unsigned)((img * p.Hin + oy) * p.Win + ox);
+        lin = isw ? lin : (unsigned long long)pix;
+        const unsigned cm = (ox > 0 ? 1u : 0u) | 2u | (ox + 1 < p.Win ? 4u : 0u);
+        const unsigned rm = (oy > 0 ? 1u : 0u) | 8u | (oy + 1 < p.Hin ? 64u : 0u);
+        vmask[i] = cm * rm;
+      }
+      voff[i] = (unsigned)((lin * ld + off) * 4ull + c * 16);   // (< 2^32: the guard)
     }
   };
   int pf_seq = 0, pf_kt = 0, pf_stage = 0;
+  // CONV: filter tap / 32-channel group of K-tile pf_kt, and the byte offset of that tap's pixel from the centre pixel
+  const int cpt = CONV ? p.Cin / S_BK : 1;
+  int pf_tap = 0, pf_kc = 0;
+  long long pf_delta = CONV ? -(long long)(p.Win + 1) * p.lda * 4 : 0;
   set_tile_offsets(0);
   auto dma_piece = [&](int i) {
+    char* dst = ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024;
+    if (CONV) {
+      // one instruction stream for the A and the W pieces (the split is a wave-uniform RUN-TIME property: a branch
+      // here would sit between the MFMAs): scalar select of the base, lane select of the zero source
+      const bool isw = piece_is_w(i);
+      const char* base = isw ? reinterpret_cast<const char*>(p.W) + (size_t)(unsigned)(pf_kt * (S_BK * 4))
+                             : reinterpret_cast<const char*>(p.A) + pf_delta;
+      const bool ok = isw || ((vmask[i] >> pf_tap) & 1u);
+      s_dma_16B(ok ? base + voff[i] : reinterpret_cast<const char*>(p.zeros), dst);
+      return;
+    }
     // wave-uniform 64-bit base (operand + K offset) + 32-bit lane offset: the saddr form of the instruction
     const char* gbase = piece_is_w(i) ? reinterpret_cast<const char*>(p.W) : reinterpret_cast<const char*>(p.A);
     const char* kb = gbase + (size_t)(unsigned)(pf_kt * (S_BK * 4));
-    s_dma_16B(kb + voff[i], ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024);
+    s_dma_16B(kb + voff[i], dst);
   };
   // the channel vectors of tile `seq`: three 256-B pieces (64 lanes x 4 B) of this wavefront's columns into its
   // private slots; always three, so that every wavefront counts the same VMEM operations (a missing vector is read
@@ -217,7 +252,14 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         set_tile_offsets(pf_seq);
       } else {
         pf_kt = nk - 1;       // past the end: repeat the last K-tile (keeps the vmcnt arithmetic uniform)
+        return;
       }
+    }
+    if (CONV) {
+      if (pf_kt == 0) { pf_tap = 0; pf_kc = 0; }
+      else if (++pf_kc == cpt) { pf_kc = 0; ++pf_tap; }
+      const int ty = pf_tap / 3, tx = pf_tap - 3 * ty;
+      pf_delta = ((long long)(ty - 1) * p.Win + (tx - 1)) * p.lda * 4 + pf_kc * (S_BK * 4);
     }
   };
 
@@ -313,7 +355,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // One block's epilogue in 15 steps (each small enough for the shadow of one MFMA).  im / in: the block,
   // t: its tile; steps 0-1 take the accumulator quads `q` (C^T block: lane (li, lh) holds channels
   // 8 g + 4 lh .. +3 of pixel li in registers 4 g .. 4 g + 3).
-  auto epi_step = [&](int step, int im, int in, const TileOut& t, const f32x16& q) {
+  // TAIL: the step runs with no MFMA in front of it (the two MFMA-free tails below): its stores then carry the row
+  // offset in the VGPR offset instead of the scalar one -- see the note at the tail behind the tile loop
+  auto epi_step = [&](int step, int im, int in, const TileOut& t, const f32x16& q, bool tail = false) {
     if (step == 0 || step == 1) {
 #pragma unroll
       for (int g = 2 * step; g < 2 * step + 2; ++g)
@@ -342,10 +386,16 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     } else if (step >= 9 && step <= 12) {
       const int i = step - 9;
       const int srow = im * 32 + 8 * i;
-      __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff, (srow * p.ldd + in * 32) * 4, 0);
+      const int so = (srow * p.ldd + in * 32) * 4, so2 = (srow * p.ldd2 + in * 32) * 4;
+      // (the four-wavefront form too: hipcc sinks its rows' maths behind the previous row's stores inside one MFMA gap)
+      const bool voff_form = tail || NW == 4;
+      if (voff_form) __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff + so, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff, so, 0);
       // (d2_col0 is a multiple of 32: a 32-column block goes to D2 as a whole -- a wave-uniform branch)
-      if (p.D2 && t.nblk + in * 32 >= p.d2_col0)
-        __builtin_amdgcn_raw_buffer_store_b128(ev[i], d2_rsrc, t.d2voff, (srow * p.ldd2 + in * 32) * 4, 0);
+      if (p.D2 && t.nblk + in * 32 >= p.d2_col0) {
+        if (voff_form) __builtin_amdgcn_raw_buffer_store_b128(ev[i], d2_rsrc, t.d2voff + so2, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(ev[i], d2_rsrc, t.d2voff, so2, 0);
+      }
     } else if (COLSUM && (step == 13 || step == 14)) {
 #pragma unroll
       for (int i = 2 * (step - 13); i < 2 * (step - 13) + 2; ++i) {
@@ -403,9 +453,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // the epilogue of a tile's LAST block behind its scratch round trip (ev[] holds its rows): d = 0 channel vectors,
   // 1-4 row maths, 5-8 row stores, 9-10 column-sum accumulation, 11-13 column-sum butterfly, 14 column-sum store
   constexpr int DEF_STEPS = 15;
-  auto deferred_step = [&](int d, const TileOut& t) {
+  auto deferred_step = [&](int d, const TileOut& t, bool tail = false) {
     const f32x16 none = {};
-    if (d < 11) epi_step(d + 4, 1, TN - 1, t, none);
+    if (d < 11) epi_step(d + 4, 1, TN - 1, t, none, tail);
     else colsum_step(d - 11, t);
   };
   // ---- prologue: two K-tiles in flight, the first one landed, its first fragments in registers
@@ -565,7 +615,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       pending = true;
     } else {
 #pragma unroll
-      for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, cur);
+      for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, cur, true);   // (TAIL: see behind the tile loop)
     }
     WS_FSTAMP(trace_now, 160 + 9)
   };
@@ -593,15 +643,23 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     trace_now = false;
   }
   WS_SSTAMP(stamp++)
+  // No MFMAs between these steps, so hipcc packs the rows' maths and stores tightly, and the register file of the
+  // CONV form left `buffer_store_dwordx4 v[12:15], v185, s[28:31], s0 offen` DIRECTLY in front of
+  // `v_pk_add_f32 v[12:13], ..`: MI355X then stores the NEW values in some lanes (a few wrong elements in rows 8..15
+  // of the last block of every workgroup's last tile, different from run to run; found with tools/conv_stream_probe).
+  // LLVM's hazard recogniser pads a >64-bit store in front of a VALU write of its data registers only when the store
+  // has NO scalar-offset register; with one it assumes there is no hazard.  So the MFMA-free tails store with the row
+  // offset in the VGPR offset (TAIL) -- the form the recogniser does pad -- and build.check_isa refuses the unpadded
+  // pair anywhere in the library.
   if (DEFER && pending) {
 #pragma unroll
-    for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, prev);
+    for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, prev, true);
   }
   // drain the DMA pieces that ran past the end of the stream before the LDS goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WM, int TN, int COLSUM, bool RES = false>
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
   constexpr int NW = WM * (4 / TN), NP = (8 * WM + 16) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
@@ -609,7 +667,7 @@ hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) 
                                (size_t)NW * 2 * 3 * 64 * 4;
   static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
-  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES>;
+  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV>;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
@@ -667,6 +725,7 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
 }
 StreamPlan plan(const ConvGemmParams& p, int cus) {
   const int m = g_ws_stream;
+  if (p.kh == 3) return plan_mode(p, cus, 3);            // (the convolution form exists for the 256x128 tile only)
   if (m >= 1 && m <= 3) return plan_mode(p, cus, m);
   const StreamPlan a = plan_mode(p, cus, 2), b = plan_mode(p, cus, 3);
   if (!b.rows) return a;
@@ -674,6 +733,23 @@ StreamPlan plan(const ConvGemmParams& p, int cus) {
   return b.cycles <= a.cycles ? b : a;
 }
 }  // namespace
+
+// env WS_STREAM_CONV=0: the 3x3 layers stay on the implicit-GEMM tile kernels
+int g_ws_stream_conv = -1;
+
+// a 3x3 / stride 1 / pad 1 / dilation 1 convolution over channels-last images whose K-tiles lie inside one tap
+bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
+  if (g_ws_stream_conv < 0) {
+    const char* ev = getenv("WS_STREAM_CONV");
+    g_ws_stream_conv = ev ? atoi(ev) : 1;
+  }
+  return g_ws_stream_conv > 0 && p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 3 && p.kw == 3 &&
+         p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 1 && p.pad_w == 1 && p.dil_h == 1 && p.dil_w == 1 &&
+         p.Hin == p.Hout && p.Win == p.Wout && p.Cin % S_BK == 0 && p.K == 9 * p.Cin && p.D && !p.D16 && !p.D2_16 &&
+         !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
+         (p.act == ACT_NONE || p.act == ACT_RELU) && p.zeros &&
+         (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32);
+}
 
 // Rows of [p.m_begin, p.M) that the persistent kernel should take (whole tile rows: whole rounds of tiles over
 // `cus` workgroups, or all of them); 0 = not this kernel's problem.
@@ -683,11 +759,14 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
     g_ws_stream = ev ? atoi(ev) : 4;
   }
   if (g_ws_stream <= 0) return 0;
+  const bool conv3 = gemm_f32_stream_is_conv3(p);
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
                      !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
                      p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
-  if (!plain) return 0;
+  if (!plain && !conv3) return 0;
+  // the convolution form: whole tiles only (no rows behind the last image), the 256x128 form, no column sums
+  if (conv3 && (p.colsum || p.D2 || (g_ws_stream != 3 && g_ws_stream != 4) || p.M % 256 != 0 || p.m_begin != 0)) return 0;
   if (p.N % S_BN != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
   if (p.colsum && p.Hout * p.Wout < 64) return 0;
   if ((p.m_begin & 63) || ((p.lda | p.a_off | p.ldd | p.d_off) & 3)) return 0;
@@ -714,10 +793,16 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
   const int grid = p.n_big < cus ? p.n_big : cus;
   if (dispatch_log_enabled()) {
     char k[96];
-    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx128 tile, %d waves> tiles=%d", bm, mode == 1 ? 4 : 8, p.n_big);
+    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx128 tile, %d waves%s> tiles=%d", bm, mode == 1 ? 4 : 8,
+             p.kh == 3 ? ", conv" : "", p.n_big);
     dispatch_log_note(p, k);
   }
   const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);
+  if (p.kh == 3) {
+    if (mode != 3) return hipErrorInvalidValue;
+    return p.residual ? launch_stream<4, 2, 0, true, true>(p, grid, stream)
+                      : launch_stream<4, 2, 0, false, true>(p, grid, stream);
+  }
   if (p.residual) {
     if (mode == 2) return launch_stream<2, 1, 0, true>(p, grid, stream);
     if (mode == 3) return launch_stream<4, 2, 0, true>(p, grid, stream);

@@ -121,6 +121,9 @@ void dispatch_log_clear();
 // [p.m_begin, p.M) that kernel takes (whole rounds of 128x128 tiles over `cus` workgroups; 0 = not its problem);
 // the caller sends the remaining rows through the tile kernels with m_begin advanced.
 int gemm_f32_stream_rows(const ConvGemmParams& p, int cus);
+// ... and of the 3x3 / stride 1 / pad 1 convolutions whose K-tiles lie inside one filter tap (Cin % 32 == 0,
+// N % 128 == 0): the same kernel with the A pieces addressed per tap (CONV form; env WS_STREAM_CONV=0 turns it off)
+bool gemm_f32_stream_is_conv3(const ConvGemmParams& p);
 hipError_t launch_gemm_f32_stream(const ConvGemmParams& p, int rows, int cus, hipStream_t stream);
 
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
