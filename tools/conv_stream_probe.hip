@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
   };
   const size_t maxRows = 512ull * 1000;
   float *A, *W, *D, *R, *Z, *bias;
-  CK(hipMalloc(&A, maxRows * 128 * 4 + 4096)); CK(hipMalloc(&W, 256ull * 2304 * 4)); CK(hipMalloc(&D, maxRows * 128 * 4));
+  CK(hipMalloc(&A, maxRows * 128 * 4 + 4096)); CK(hipMemset(A + maxRows * 128, 0, 4096)); CK(hipMalloc(&W, 256ull * 2304 * 4)); CK(hipMalloc(&D, maxRows * 128 * 4));
   CK(hipMalloc(&R, maxRows * 128 * 4)); CK(hipMalloc(&Z, 256)); CK(hipMemset(Z, 0, 256)); CK(hipMalloc(&bias, 256 * 4));
   std::vector<float> h(maxRows * 128);
   srand(7);
@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     p.Hin = p.Hout = c.H; p.Win = p.Wout = c.W; p.stride_h = p.stride_w = 1; p.kh = p.kw = 3; p.dil_h = p.dil_w = 1;
     p.pad_h = p.pad_w = 1; p.bias = bias; p.act = ACT_RELU; p.splitk = 1; p.zeros = Z;
     if (c.res) { p.residual = R; p.ldr = c.N; }
+    p.a_zero_off = (long long)maxRows * 128 * 4;         // zeros behind the input buffer
     const size_t nD = (size_t)M * c.N;
     std::vector<float> ref(nD), got(nD);
     printf("== %s: M=%d N=%d K=%d\n", c.name, M, c.N, K);

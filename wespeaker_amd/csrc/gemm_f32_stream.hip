@@ -100,9 +100,10 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // CONV (round 5): the A operand of a 3x3 / stride 1 / pad 1 convolution over channels-last images (the BasicBlock
 // and Bottleneck 3x3 layers of wespeaker/models/resnet.py:35-107 with 128 / 256 planes).  K-tile kt is 32 channels of
 // ONE filter tap (k = tap * Cin + ci, the implicit-GEMM kernels' order: same bits), so a piece's source is the row's
-// centre pixel + a wave-uniform tap offset; a tap that falls outside the image reads 16 zero bytes instead (nine
-// validity bits per piece row, computed once per tile) -- every piece is still exactly one DMA operation, which the
-// vmcnt arithmetic of the barriers relies on.
+// centre pixel + a wave-uniform tap offset; a tap that falls outside the image reads 16 zero bytes that the caller
+// keeps behind the tensor (ConvGemmParams::a_zero_off; nine validity bits per piece row, computed once per tile, one
+// lane select of the 32-bit offset per piece) -- every piece is still exactly one DMA operation, which the vmcnt
+// arithmetic of the barriers relies on.
 template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
 __global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
@@ -206,6 +207,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   const int cpt = CONV ? p.Cin / S_BK : 1;
   int pf_tap = 0, pf_kc = 0;
   long long pf_delta = CONV ? -(long long)(p.Win + 1) * p.lda * 4 : 0;
+  // ... and where the 16 zero bytes behind the tensor lie from that tap's base: the offset of a lane whose tap falls
+  // outside the image (one lane select per piece; the base stays scalar: the saddr form like the plain pieces)
+  const unsigned zero_lo = CONV ? (unsigned)p.a_zero_off : 0u;        // (a_zero_off - delta < 2^32: the guard)
   set_tile_offsets(0);
   auto dma_piece = [&](int i) {
     char* dst = ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024;
@@ -216,7 +220,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       const char* base = isw ? reinterpret_cast<const char*>(p.W) + (size_t)(unsigned)(pf_kt * (S_BK * 4))
                              : reinterpret_cast<const char*>(p.A) + pf_delta;
       const bool ok = isw || ((vmask[i] >> pf_tap) & 1u);
-      s_dma_16B(ok ? base + voff[i] : reinterpret_cast<const char*>(p.zeros), dst);
+      s_dma_16B(base + (ok ? voff[i] : zero_lo - (unsigned)pf_delta), dst);
       return;
     }
     // wave-uniform 64-bit base (operand + K offset) + 32-bit lane offset: the saddr form of the instruction
@@ -747,8 +751,9 @@ bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
          p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 1 && p.pad_w == 1 && p.dil_h == 1 && p.dil_w == 1 &&
          p.Hin == p.Hout && p.Win == p.Wout && p.Cin % S_BK == 0 && p.K == 9 * p.Cin && p.D && !p.D16 && !p.D2_16 &&
          !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
-         (p.act == ACT_NONE || p.act == ACT_RELU) && p.zeros &&
-         (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32);
+         (p.act == ACT_NONE || p.act == ACT_RELU) && p.a_zero_off > 0 &&
+         (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32) &&
+         p.a_zero_off + ((long long)p.Win + 2) * p.lda * 4 + 16 < (1LL << 32);
 }
 
 // Rows of [p.m_begin, p.M) that the persistent kernel should take (whole tile rows: whole rounds of tiles over

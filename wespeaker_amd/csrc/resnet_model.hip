@@ -40,6 +40,7 @@ struct ResNetModel : ModelBase {
   bool two_emb = false;
   size_t seg_bn_scale = 0, seg_bn_shift = 0;
   float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t act_floats = 0;                     // floats per activation buffer (64 zero floats follow each)
   float *pooled = nullptr, *partial = nullptr, *emb_a = nullptr;
   int stats_dim = 0;
   static constexpr int kSplitK = 16;
@@ -132,13 +133,22 @@ struct ResNetModel : ModelBase {
     size_t total = 0;
     auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
     size_t ob[4];
-    for (int i = 0; i < 4; ++i) ob[i] = take(act);
+    // (+ 64 floats of zeros behind every activation buffer, never written: the border taps of the persistent
+    // kernel's CONV form read them -- ConvGemmParams::a_zero_off)
+    for (int i = 0; i < 4; ++i) ob[i] = take(act + 64);
+    act_floats = act;
     size_t o_pool = take((size_t)maxB * 2 * stats_dim),
            o_part = take((size_t)kSplitK * maxB * embed_dim), o_emba = take((size_t)maxB * embed_dim),
            o_feats = take((size_t)maxB * maxT * feat_dim);
     if ((err = alloc_workspace(total))) return err;
     float* base = ws.as<float>();
-    for (int i = 0; i < 4; ++i) buf[i] = base + ob[i];
+    for (int i = 0; i < 4; ++i) {
+      buf[i] = base + ob[i];
+      if (hipMemset(buf[i] + act, 0, 64 * sizeof(float)) != hipSuccess) {
+        set_error("zero pad of activation buffer %d", i);
+        return WS_ERR_HIP;
+      }
+    }
     pooled = base + o_pool; partial = base + o_part; emb_a = base + o_emba; feats_ws = base + o_feats;
     return 0;
   }
@@ -163,6 +173,8 @@ struct ResNetModel : ModelBase {
                     int s_, int pad, int act, const float* res, int ldr, int out_lvl) {
       ConvGemmParams p = conv2d(cw, in, Cin_, 0, out, Cout_, 0, B, Hin_, Win_, s_, s_, 1, 1, pad, pad, act);
       p.row_len = cur_lens[out_lvl];                       // stride level of this launch's OUTPUT width
+      for (int i = 0; i < 4; ++i)                          // the zero pad behind the input's buffer
+        if (in == buf[i]) p.a_zero_off = (long long)act_floats * (long long)sizeof(float);
       if (f16io) {
         p.A16 = reinterpret_cast<const uint16_t*>(in); p.lda16 = Cin_;
         p.D = nullptr; p.D16 = reinterpret_cast<uint16_t*>(out); p.ldd16 = Cout_;
