@@ -137,3 +137,27 @@ def test_library_has_no_forbidden_packed_fp32_form():
     finally:
         build.ISA_CHECK_EXEMPT = exempt
     assert len(seen) == 1 and "fbank_kernel_packed" in seen[0][0], seen
+
+
+def test_isa_gate_sees_a_wide_store_in_front_of_a_write_of_its_data_registers():
+    """DESIGN.md 6.0, second rule (round 5): a store of more than 64 bits followed within two wait states by a VALU
+    write of its data VGPRs stores the new values in some lanes on MI355X when the store carries a scalar offset -- the
+    form LLVM's hazard recogniser does not pad.  The rule on hand-made listings: the pair that went out of hipcc
+    (tools/conv_stream_probe found it), the padded and the harmless neighbours."""
+    from wespeaker_amd.build import _store_data_overwritten as hit
+    bad = ["\tbuffer_store_dwordx4 v[12:15], v185, s[28:31], s0 offen    // 0001: E07C1000",
+           "\tv_pk_add_f32 v[12:13], v[6:7], v[70:71]                    // 0002: D3B2400C",
+           "\tv_pk_add_f32 v[14:15], v[4:5], v[68:69]"]
+    assert hit(bad, 0)
+    one_between = [bad[0], "\tv_pk_add_f32 v[40:41], v[58:59], v[66:67]", "\tv_pk_add_f32 v[14:15], v[4:5], v[68:69]"]
+    assert hit(one_between, 0)                                    # one wait state is not two
+    padded = [bad[0], "\ts_nop 1", bad[1]]
+    assert not hit(padded, 0)
+    other_regs = [bad[0], "\tv_pk_add_f32 v[16:17], v[6:7], v[70:71]", "\tv_mov_b32_e32 v11, v3", "\tv_mov_b32_e32 v12, v3"]
+    assert not hit(other_regs, 0)                                 # v12 is written three instructions later
+    narrow = ["\tbuffer_store_dwordx2 v[12:13], v185, s[28:31], s0 offen", bad[1]]
+    assert not hit(narrow, 0)                                     # 64 bits: no hazard
+    glob = ["\tglobal_store_dwordx4 v[84:85], v[74:77], off", "\tv_cvt_pk_f16_f32 v77, v76, v77"]
+    assert hit(glob, 0)
+    reader = [bad[0], "\tv_cmp_eq_u32_e32 vcc, 1, v12", "\tv_readlane_b32 s0, v12, 3", bad[1]]
+    assert not hit(reader, 0)                                     # reads do not count; the write comes after two states
