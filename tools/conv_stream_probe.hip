@@ -26,6 +26,8 @@ int main(int argc, char** argv) {
       {512, 10, 25, 256, 256, 0, "ResNet34 stage 4 (B=512)"},
       {256, 20, 50, 128, 128, 1, "ResNet34 stage 3 +res (B=256)"},
       {512, 20, 50, 128, 128, 0, "ResNet34 stage 3 (B=512)"},
+      {128, 40, 99, 64, 64, 0, "ResNet34 stage 2 (B=128): 256x64 tiles"},
+      {128, 40, 99, 64, 64, 1, "ResNet34 stage 2 +res (B=128): 256x64 tiles"},
       {96, 20, 50, 128, 128, 0, "1.46 rounds (not taken)"},
   };
   const size_t maxRows = 512ull * 1000;

@@ -37,7 +37,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int S_BN = 128, S_BK = 32;
+constexpr int S_BK = 32;
 constexpr int S_SCR_STRIDE = 36;                              // floats per row of the transpose scratch
 constexpr int S_SCR_BYTES = 32 * S_SCR_STRIDE * 4;            // per wavefront
 
@@ -104,20 +104,24 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // keeps behind the tensor (ConvGemmParams::a_zero_off; nine validity bits per piece row, computed once per tile, one
 // lane select of the 32-bit offset per piece) -- every piece is still exactly one DMA operation, which the vmcnt
 // arithmetic of the barriers relies on.
-template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
-__global__ __launch_bounds__(64 * WM * (4 / TN), WM * (4 / TN) / 4)
+// WNP (round 5): wavefront columns, 4 / TN (a 128-column tile) unless given: <4, 1, .., 2> is eight wavefronts of
+// 64 x 32 over a 256 x 64 tile for the 64-channel layers (ResNet stage 2 / the 64-plane bottleneck layers).
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
+__global__ __launch_bounds__(64 * WM * WNP, WM * WNP / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
-  constexpr int WN = 4 / TN;                 // wavefront columns
+  constexpr int WN = WNP;                    // wavefront columns
   constexpr int NW = WM * WN;
   constexpr int S_BM = 64 * WM;
-  constexpr int S_STAGE_BYTES = (S_BM + S_BN) * S_BK * 4;       // 32 / 48 KiB
+  constexpr int S_BN = 32 * TN * WN;         // 128 (64: WNP = 2 with TN = 1)
+  constexpr int WPIECES = S_BN / 8;          // 1-KiB pieces of W rows per stage
+  constexpr int S_STAGE_BYTES = (S_BM + S_BN) * S_BK * 4;       // 32 / 48 / 40 KiB
   constexpr int S_W_BYTE0 = S_BM * S_BK * 4;                    // W rows behind the A rows of a stage
   constexpr int S_NSTAGE = 3;
   constexpr int APIECES = S_BM / 8;          // 1-KiB pieces of A rows per stage (8 rows of 128 B each)
   constexpr int GM = 8 * TN;                 // MFMAs per k-group (8 k) of a K-tile
-  constexpr int NP = (APIECES + 16) / NW;    // 1-KiB DMA pieces per wavefront and K-tile
+  constexpr int NP = (APIECES + WPIECES) / NW;   // 1-KiB DMA pieces per wavefront and K-tile
   constexpr int NF = 2 + TN;                 // fragment reads per k-group
-  static_assert((APIECES + 16) % NW == 0 && NP <= 8, "pieces divide over the wavefronts");
+  static_assert((APIECES + WPIECES) % NW == 0 && NP <= 8, "pieces divide over the wavefronts");
   // the scratch inside the wavefront's own DMA slice of the free stage when it fits, else behind the stages
   constexpr bool SCR_ALIAS = NP * 1024 >= S_SCR_BYTES;
   constexpr int SCR_OFF = S_NSTAGE * S_STAGE_BYTES;
@@ -663,15 +667,15 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false>
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
-  constexpr int NW = WM * (4 / TN), NP = (8 * WM + 16) / NW;
+  constexpr int NW = WM * WNP, BN = 32 * TN * WNP, NP = (8 * WM + BN / 8) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
-  constexpr size_t lds_bytes = (size_t)3 * (64 * WM + S_BN) * S_BK * 4 + (alias ? 0 : (size_t)NW * S_SCR_BYTES) +
+  constexpr size_t lds_bytes = (size_t)3 * (64 * WM + BN) * S_BK * 4 + (alias ? 0 : (size_t)NW * S_SCR_BYTES) +
                                (size_t)NW * 2 * 3 * 64 * 4;
   static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
-  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV>;
+  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV, WNP>;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
@@ -695,8 +699,11 @@ unsigned long long* stream_trace_buffer_address() {
 namespace {
 // Cycles per K-tile of one tile (measured, steady state) and the per-tile overhead of the first / last K-tile.
 struct StreamPlan { int mode, bm, rows; long long cycles; };
+// mode 5 (round 5): the 256 x 64 tile of the 64-channel layers, eight wavefronts of 64 x 32 (per wavefront the work of
+// mode 2: 32 MFMAs per K-tile)
+constexpr int bn_of(int mode) { return mode == 5 ? 64 : 128; }
 StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
-  const int bm = mode == 3 ? 256 : 128;
+  const int bm = mode == 3 || mode == 5 ? 256 : 128, S_BN = bn_of(mode);
   const long long per_kt = mode == 3 ? 8500 : 4400, per_tile = mode == 3 ? 5500 : 2500;
   const long long tiles_n = p.N / S_BN, tiles_m = (p.M - p.m_begin) / bm, nk = p.K / S_BK;
   const long long total = tiles_m * tiles_n, rounds = total / cus;
@@ -729,7 +736,8 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
 }
 StreamPlan plan(const ConvGemmParams& p, int cus) {
   const int m = g_ws_stream;
-  if (p.kh == 3) return plan_mode(p, cus, 3);            // (the convolution form exists for the 256x128 tile only)
+  if (p.N % 128 != 0) return plan_mode(p, cus, 5);       // (N % 64 == 0: the 256x64 tile)
+  if (p.kh == 3) return plan_mode(p, cus, 3);            // (the convolution form exists for the 256-row tiles only)
   if (m >= 1 && m <= 3) return plan_mode(p, cus, m);
   const StreamPlan a = plan_mode(p, cus, 2), b = plan_mode(p, cus, 3);
   if (!b.rows) return a;
@@ -738,8 +746,9 @@ StreamPlan plan(const ConvGemmParams& p, int cus) {
 }
 }  // namespace
 
-// env WS_STREAM_CONV=0: the 3x3 layers stay on the implicit-GEMM tile kernels
+// env WS_STREAM_CONV=0: the 3x3 layers stay on the implicit-GEMM tile kernels; WS_STREAM64=0: the 64-channel layers
 int g_ws_stream_conv = -1;
+int g_ws_stream64 = -1;
 
 // a 3x3 / stride 1 / pad 1 / dilation 1 convolution over channels-last images whose K-tiles lie inside one tap
 bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
@@ -764,6 +773,10 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
     g_ws_stream = ev ? atoi(ev) : 4;
   }
   if (g_ws_stream <= 0) return 0;
+  if (g_ws_stream64 < 0) {
+    const char* ev = getenv("WS_STREAM64");
+    g_ws_stream64 = ev ? atoi(ev) : 1;
+  }
   const bool conv3 = gemm_f32_stream_is_conv3(p);
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
@@ -772,7 +785,9 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   if (!plain && !conv3) return 0;
   // the convolution form: whole tiles only (no rows behind the last image), the 256x128 form, no column sums
   if (conv3 && (p.colsum || p.D2 || (g_ws_stream != 3 && g_ws_stream != 4) || p.M % 256 != 0 || p.m_begin != 0)) return 0;
-  if (p.N % S_BN != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
+  if (p.N % 64 != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
+  // the 256x64 tile: plain / convolution layers without column sums or a second output, default dispatch only
+  if (p.N % 128 != 0 && (g_ws_stream64 <= 0 || g_ws_stream != 4 || p.colsum || p.D2 || (p.residual && !conv3))) return 0;
   if (p.colsum && p.Hout * p.Wout < 64) return 0;
   if ((p.m_begin & 63) || ((p.lda | p.a_off | p.ldd | p.d_off) & 3)) return 0;
   if (p.D2 && (((p.ldd2 | p.d2_off) & 3) || (p.d2_col0 & 31))) return 0;
@@ -794,15 +809,21 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
   if (pl.rows != rows) return hipErrorInvalidValue;      // (rows must come from gemm_f32_stream_rows)
   p.tail_begin = p.m_begin + rows;
   const int mode = pl.mode, bm = pl.bm;
-  p.n_big = rows / bm * (p.N / S_BN);
+  p.n_big = rows / bm * (p.N / bn_of(mode));
   const int grid = p.n_big < cus ? p.n_big : cus;
   if (dispatch_log_enabled()) {
     char k[96];
-    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx128 tile, %d waves%s> tiles=%d", bm, mode == 1 ? 4 : 8,
+    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx%d tile, %d waves%s> tiles=%d", bm, bn_of(mode), mode == 1 ? 4 : 8,
              p.kh == 3 ? ", conv" : "", p.n_big);
     dispatch_log_note(p, k);
   }
   const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);
+  if (mode == 5) {
+    if (p.kh == 3)
+      return p.residual ? launch_stream<4, 1, 0, true, true, 2>(p, grid, stream)
+                        : launch_stream<4, 1, 0, false, true, 2>(p, grid, stream);
+    return p.residual ? hipErrorInvalidValue : launch_stream<4, 1, 0, false, false, 2>(p, grid, stream);
+  }
   if (p.kh == 3) {
     if (mode != 3) return hipErrorInvalidValue;
     return p.residual ? launch_stream<4, 2, 0, true, true>(p, grid, stream)
