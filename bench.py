@@ -774,7 +774,7 @@ def main(argv=None):
         # HBM traffic of the dominant kernel class: separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed aggregate of the newest round
         tag = "" if model_name == "ECAPA_TDNN_GLOB_c512" else "_" + model_name
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_dominant_kernel_%s%s.json" % (rnd, prec, tag))
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fpmc:
