@@ -24,6 +24,8 @@
 //     conv_gemm.hip: the outputs are bit-identical;
 //   * only whole rounds of tiles are taken (the dispatcher hands the remaining rows to the 64x64 kernel),
 //     XCD-aware order inside a round (an XCD's 32 workgroups share A row panels in its private L2).
+// Round 5: the same kernel also takes the 3x3 / stride-1 convolutions whose K-tiles lie inside one filter tap (CONV:
+// wespeaker/models/resnet.py:35-107, stages 2-4) and, on a 256x64 tile (WNP = 2), the 64-channel layers.
 #include "kernels.h"
 
 #include <cstdio>
