@@ -102,10 +102,10 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // CONV (round 5): the A operand of a 3x3 / stride 1 / pad 1 convolution over channels-last images (the BasicBlock
 // and Bottleneck 3x3 layers of wespeaker/models/resnet.py:35-107 with 128 / 256 planes).  K-tile kt is 32 channels of
 // ONE filter tap (k = tap * Cin + ci, the implicit-GEMM kernels' order: same bits), so a piece's source is the row's
-// centre pixel + a wave-uniform tap offset; a tap that falls outside the image reads 16 zero bytes that the caller
-// keeps behind the tensor (ConvGemmParams::a_zero_off; nine validity bits per piece row, computed once per tile, one
-// lane select of the 32-bit offset per piece) -- every piece is still exactly one DMA operation, which the vmcnt
-// arithmetic of the barriers relies on.
+// centre pixel + a wave-uniform tap offset; a tap that falls outside the image reads zeros that the caller keeps
+// behind the tensor (ConvGemmParams::a_zero_off: Cin zero floats; nine validity bits per piece row, computed once per
+// tile; the lane offsets of the current tap are selected once per TAP) -- every piece is still exactly one DMA
+// operation, which the vmcnt arithmetic of the barriers relies on.
 // WNP (round 5): wavefront columns, 4 / TN (a 128-column tile) unless given: <4, 1, .., 2> is eight wavefronts of
 // 64 x 32 over a 256 x 64 tile for the 64-channel layers (ResNet stage 2 / the 64-plane bottleneck layers).
 template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
@@ -216,17 +216,30 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // ... and where the 16 zero bytes behind the tensor lie from that tap's base: the offset of a lane whose tap falls
   // outside the image (one lane select per piece; the base stays scalar: the saddr form like the plain pieces)
   const unsigned zero_lo = CONV ? (unsigned)p.a_zero_off : 0u;        // (a_zero_off - delta < 2^32: the guard)
+  // The lane offsets of the CURRENT tap: the centre-pixel offset, or -- the tap outside the image -- the zeros minus
+  // the tap's pixel offset, so that base(tap) + 128 kc + loff lands inside the Cin zero floats for every channel
+  // group kc.  Recomputed when the tap changes (every Cin / 32 K-tiles), not per piece and K-tile: the DMA issue of a
+  // CONV piece is then the plain form's (scalar base + lane offset).
+  unsigned loff[CONV ? NP : 1];
+  auto set_tap = [&](int tap) {
+    const int ty = tap / 3, tx = tap - 3 * ty;
+    const unsigned tapdelta = (unsigned)(((ty - 1) * p.Win + (tx - 1)) * p.lda * 4);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = piece_is_w(i) || ((vmask[CONV ? i : 0] >> tap) & 1u);
+      loff[CONV ? i : 0] = ok ? voff[i] : zero_lo - tapdelta;
+    }
+  };
   set_tile_offsets(0);
+  if (CONV) set_tap(0);
   auto dma_piece = [&](int i) {
     char* dst = ldsb + pf_stage * S_STAGE_BYTES + (wave * NP + i) * 1024;
     if (CONV) {
       // one instruction stream for the A and the W pieces (the split is a wave-uniform RUN-TIME property: a branch
-      // here would sit between the MFMAs): scalar select of the base, lane select of the zero source
-      const bool isw = piece_is_w(i);
-      const char* base = isw ? reinterpret_cast<const char*>(p.W) + (size_t)(unsigned)(pf_kt * (S_BK * 4))
-                             : reinterpret_cast<const char*>(p.A) + pf_delta;
-      const bool ok = isw || ((vmask[i] >> pf_tap) & 1u);
-      s_dma_16B(base + (ok ? voff[i] : zero_lo - (unsigned)pf_delta), dst);
+      // here would sit between the MFMAs): scalar select of the base
+      const char* base = piece_is_w(i) ? reinterpret_cast<const char*>(p.W) + (size_t)(unsigned)(pf_kt * (S_BK * 4))
+                                       : reinterpret_cast<const char*>(p.A) + pf_delta;
+      s_dma_16B(base + loff[CONV ? i : 0], dst);
       return;
     }
     // wave-uniform 64-bit base (operand + K offset) + 32-bit lane offset: the saddr form of the instruction
@@ -270,6 +283,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       else if (++pf_kc == cpt) { pf_kc = 0; ++pf_tap; }
       const int ty = pf_tap / 3, tx = pf_tap - 3 * ty;
       pf_delta = ((long long)(ty - 1) * p.Win + (tx - 1)) * p.lda * 4 + pf_kc * (S_BK * 4);
+      if (pf_kc == 0) set_tap(pf_tap);
     }
   };
 
@@ -764,7 +778,7 @@ bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
          !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
          (p.act == ACT_NONE || p.act == ACT_RELU) && p.a_zero_off > 0 &&
          (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32) &&
-         p.a_zero_off + ((long long)p.Win + 2) * p.lda * 4 + 16 < (1LL << 32);
+         p.a_zero_off + ((long long)p.Win + 2) * p.lda * 4 + 4LL * p.Cin + 16 < (1LL << 32);
 }
 
 // Rows of [p.m_begin, p.M) that the persistent kernel should take (whole tile rows: whole rounds of tiles over

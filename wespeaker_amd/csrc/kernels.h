@@ -99,7 +99,7 @@ struct ConvGemmParams {
                                               // and image part -> pool_partial[ceil(M/64)*2][N][4]
   float* partial;  int splitk;                // splitk > 1: raw partial sums -> partial[z][M][N]
   const float* zeros;                         // >= 16 B of zeros in device memory (masked loads)
-  long long a_zero_off;                       // optional: byte offset FROM A of 16 zero bytes that lie behind the
+  long long a_zero_off;                       // optional: byte offset FROM A of Cin zero floats that lie behind the
                                               // tensor within 32-bit reach (ResNet: a pad behind every activation
                                               // buffer); the CONV form of the persistent fp32 GEMM reads a border
                                               // tap from there with the same scalar base as its valid lanes

@@ -40,7 +40,7 @@ struct ResNetModel : ModelBase {
   bool two_emb = false;
   size_t seg_bn_scale = 0, seg_bn_shift = 0;
   float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t act_floats = 0;                     // floats per activation buffer (64 zero floats follow each)
+  size_t act_floats = 0;                     // floats per activation buffer (512 zero floats follow each)
   float *pooled = nullptr, *partial = nullptr, *emb_a = nullptr;
   int stats_dim = 0;
   static constexpr int kSplitK = 16;
@@ -133,9 +133,9 @@ struct ResNetModel : ModelBase {
     size_t total = 0;
     auto take = [&](size_t n) { size_t o = total; total += (n + 63) & ~size_t(63); return o; };
     size_t ob[4];
-    // (+ 64 floats of zeros behind every activation buffer, never written: the border taps of the persistent
-    // kernel's CONV form read them -- ConvGemmParams::a_zero_off)
-    for (int i = 0; i < 4; ++i) ob[i] = take(act + 64);
+    // (+ 512 floats of zeros behind every activation buffer, never written: the border taps of the persistent
+    // kernel's CONV form read Cin <= 512 of them -- ConvGemmParams::a_zero_off)
+    for (int i = 0; i < 4; ++i) ob[i] = take(act + 512);
     act_floats = act;
     size_t o_pool = take((size_t)maxB * 2 * stats_dim),
            o_part = take((size_t)kSplitK * maxB * embed_dim), o_emba = take((size_t)maxB * embed_dim),
@@ -144,7 +144,7 @@ struct ResNetModel : ModelBase {
     float* base = ws.as<float>();
     for (int i = 0; i < 4; ++i) {
       buf[i] = base + ob[i];
-      if (hipMemset(buf[i] + act, 0, 64 * sizeof(float)) != hipSuccess) {
+      if (hipMemset(buf[i] + act, 0, 512 * sizeof(float)) != hipSuccess) {
         set_error("zero pad of activation buffer %d", i);
         return WS_ERR_HIP;
       }
