@@ -799,8 +799,9 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
                      !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
                      p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
   if (!plain && !conv3) return 0;
-  // the convolution form: whole tiles only (no rows behind the last image), the 256x128 form, no column sums
-  if (conv3 && (p.colsum || p.D2 || (g_ws_stream != 3 && g_ws_stream != 4) || p.M % 256 != 0 || p.m_begin != 0)) return 0;
+  // the convolution form: the 256-row tiles, no column sums (rows behind the last whole tile go to the tile kernels
+  // like the plain form's; their taps may read any input pixel, so only a launch from row 0 is taken)
+  if (conv3 && (p.colsum || p.D2 || (g_ws_stream != 3 && g_ws_stream != 4) || p.m_begin != 0)) return 0;
   if (p.N % 64 != 0 || p.K % S_BK != 0 || p.K < 4 * S_BK) return 0;
   // the 256x64 tile: plain / convolution layers without column sums or a second output, default dispatch only
   if (p.N % 128 != 0 && (g_ws_stream64 <= 0 || g_ws_stream != 4 || p.colsum || p.D2 || (p.residual && !conv3))) return 0;
