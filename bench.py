@@ -199,6 +199,12 @@ def cpu_baseline(model_name, embed_dim, sample_utts, budget_s=8.0):
             "what": "oracle/ (numpy fbank + torch-fp32 functional restatement of the reference forward, "
                     "bit-identical to the reference nn.Module on the golden cases); the reference checkout "
                     "itself is not on the GPU box, so this is a port, not `reference`",
+            #  the reference's OWN nn.Module, timed once where the checkout exists -- the build
+            # container's 8 host cores, forward only, no fbank: BASELINE.md section 3
+            "reference_module_on_the_build_container": {
+                "value": 68.3, "unit": "embeddings/s", "cores": 8, "one_thread": 28.4,
+                "what": "wespeaker.models.ecapa_tdnn ECAPA_TDNN_GLOB_c512 forward on (1, 198, 80) inputs, batch 1 x "
+                        "100, torch CPU fp32 (BASELINE.md:73); a constant quoted beside the port, not measured in this run"},
             "sample": "%d synthetic 2 s utts in %.1f s, batch 1 (the Speaker.extract_embedding_list "
                       "loop), %s; best of 1/8/32 threads" % (best[2], best[3], model_name)}
 
