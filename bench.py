@@ -90,7 +90,8 @@ def kernel_text(model_name, prec):
     if prec == "fp32":
         return ("gemm_f32_stream_kernel (persistent: one workgroup of eight 64x64 wavefronts per CU walks whole rounds "
                 "of 256x128 tiles, operands by LDS-DMA into a 3-stage ring of 48-KB K-tiles, v_mfma_f32_32x32x2_f32, "
-                "exact fp32 products: the plain 1x1 layers, and ECAPA's k5 layer as an im2col GEMM) + "
+                "exact fp32 products: the plain 1x1 layers, ECAPA's k5 layer as an im2col GEMM, and -- CONV form, per-tap "
+                "A pieces; 256x64 tile for 64 channels -- the 3x3 / stride-1 layers of the ResNets' stages 2-4) + "
                 + ("astp_fused_kernel (attention linear1 -> tanh -> linear2 -> softmax pooling, one workgroup per "
                    "utterance, v_mfma_f32_16x16x4_f32) + " if ecapa else "")
                 + "conv_gemm_dual_kernel / conv_gemm_kernel<..,PREC=0> "
