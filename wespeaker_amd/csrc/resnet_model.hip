@@ -150,6 +150,8 @@ struct ResNetModel : ModelBase {
       }
     }
     pooled = base + o_pool; partial = base + o_part; emb_a = base + o_emba; feats_ws = base + o_feats;
+    // (hipMemset runs on the null stream, the forwards on the caller's: the pads are zero before reserve() returns)
+    if (hipDeviceSynchronize() != hipSuccess) return WS_ERR_HIP;
     return 0;
   }
 
