@@ -1028,7 +1028,7 @@ def test_persistent_fp32_gemm_against_the_tile_kernels(tmp_path):
 
 @pytest.mark.parametrize("switch", ["WS_DIRECT3X3_F32=0", "WS_NO_STD_FROM_SUMS=1", "WS_NO_IM2COL=1", "WS_ASTP_FUSED=0",
                                     "WS_NO_POOL_FUSE=1", "WS_CAM_FUSED=0", "WS_CAM_BLOCK=0", "WS_SE_FUSED=0",
-                                    "WS_STREAM_CONV=0", "WS_STREAM64=0"])
+                                    "WS_STREAM_CONV=0", "WS_STREAM64=0", "WS_STEM_V1=1"])
 def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
     """Every environment A/B switch of DESIGN.md 7.1 that selects another kernel for the same arithmetic: the models
     it touches, full-size batches (so that the shipped side does take the kernel in question), switched against shipped.
@@ -1045,7 +1045,8 @@ def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
               "WS_CAM_BLOCK=0": "(('CAMPPlus', 512, 96, 'fp32'),)",
               "WS_SE_FUSED=0": "(('ECAPA_TDNN_GLOB_c512', 192, 256, 'fp32'), ('ECAPA_TDNN_c1024', 192, 64, 'fp32'))",
               "WS_STREAM_CONV=0": "(('ResNet34', 256, 512, 'fp32'), ('ResNet221', 256, 256, 'fp32'), ('ResNet50', 256, 200, 'fp32'))",
-              "WS_STREAM64=0": "(('ResNet34', 256, 512, 'fp32'), ('ResNet221', 256, 256, 'fp32'), ('ResNet18', 256, 300, 'fp32'))"}[switch]
+              "WS_STREAM64=0": "(('ResNet34', 256, 512, 'fp32'), ('ResNet221', 256, 256, 'fp32'), ('ResNet18', 256, 300, 'fp32'))",
+              "WS_STEM_V1=1": "(('ResNet34', 256, 64, 'fp32'), ('CAMPPlus', 512, 64, 'fp32'), ('ResNet18', 256, 37, 'f16'))"}[switch]
     script = tmp_path / "ab.py"
     script.write_text(
         "import sys, numpy as np, torch\n"
@@ -1064,7 +1065,7 @@ def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
     for tag in ("shipped", "switched"):
         env = dict(os.environ, PYTHONPATH=root)
         for k in ("WS_DIRECT3X3_F32", "WS_NO_STD_FROM_SUMS", "WS_NO_IM2COL", "WS_ASTP_FUSED", "WS_NO_POOL_FUSE",
-                  "WS_CAM_FUSED", "WS_CAM_BLOCK", "WS_SE_FUSED", "WS_STREAM_CONV", "WS_STREAM64"):
+                  "WS_CAM_FUSED", "WS_CAM_BLOCK", "WS_SE_FUSED", "WS_STREAM_CONV", "WS_STREAM64", "WS_STEM_V1"):
             env.pop(k, None)
         if tag == "switched":
             k, v = switch.split("=")
@@ -1079,7 +1080,7 @@ def test_ab_switches_agree_with_the_shipped_path(tmp_path, switch):
         assert np.isfinite(res["switched"][k]).all()
         assert _rel_err(res["switched"][k], res["shipped"][k]).max() < tol, (switch, k)
         # the same arithmetic in more launches / the same k order per accumulator: the same bits
-        if switch in ("WS_CAM_BLOCK=0", "WS_SE_FUSED=0", "WS_STREAM_CONV=0", "WS_STREAM64=0"):
+        if switch in ("WS_CAM_BLOCK=0", "WS_SE_FUSED=0", "WS_STREAM_CONV=0", "WS_STREAM64=0", "WS_STEM_V1=1"):
             assert np.array_equal(res["switched"][k], res["shipped"][k]), (switch, k)
 
 

@@ -7,6 +7,8 @@
 //                   ceil_mode, Linear -> ReLU -> Linear -> sigmoid)
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace wsamd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -86,11 +88,88 @@ __global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __r
   }
 }
 
+// Round 5: the same tile with the roles turned for the STORES.  Above, a store instruction of a wavefront writes 16 B
+// of 64 different pixels (64 cache lines, a quarter of each: the L2 has to merge eight instructions per line) and the
+// kernel runs at 3.1 TB/s.  Here a thread owns 4 channels (8 threads per pixel) of the 8 pixels of one tile COLUMN:
+// lane -> (pixel column tx = lane / 8 of 8 neighbours, channel quad lane % 8), so one store instruction is 1 KB of
+// contiguous memory (8 whole 128-B pixels); its 10 x 3 inputs and 4 x 10 weights live in registers.  The sum of an
+// output is the expression of the kernel above, term for term.
+template <bool OUT16>
+__global__ __launch_bounds__(256) void stem_conv3x3_rows_kernel(const float* __restrict__ feats, int T,
+                                                                int F, const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out,
+                                                                uint16_t* __restrict__ out16,
+                                                                const int* __restrict__ lens) {
+  __shared__ float in_s[ST_FH + 2][ST_TW + 2 + 1];
+  const int t0 = blockIdx.x * ST_TW, f0 = blockIdx.y * ST_FH, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const float* img = feats + (long long)b * T * F;
+  for (int i = tid; i < (ST_FH + 2) * (ST_TW + 2); i += 256) {
+    const int tx = i / (ST_FH + 2), fy = i - tx * (ST_FH + 2);   // f fastest: contiguous in feats
+    const int tt = t0 + tx - 1, ff = f0 + fy - 1;
+    in_s[fy][tx] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? img[(long long)tt * F + ff] : 0.f;
+  }
+  const int c4 = tid & 7, tx = tid >> 3;                          // channels 4 c4 .. +3 of tile column tx
+  float wv[4][9], bv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[q][k] = w[(c4 * 4 + q) * 9 + k];
+    bv[q] = bias[c4 * 4 + q];
+  }
+  __syncthreads();
+  float col[ST_FH + 2][3];
+#pragma unroll
+  for (int r = 0; r < ST_FH + 2; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) col[r][dx] = in_s[r][tx + dx];
+  const int t = t0 + tx;
+  if (t >= T) return;
+  const bool padded = lens && t >= lens[b];     // ragged batch: columns beyond the utterance stay zero
+  typedef _Float16 f16x4c __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int fy = 0; fy < ST_FH; ++fy) {
+    const int f = f0 + fy;
+    if (f >= F) break;
+    const float* in0 = col[fy];
+    const float* in1 = col[fy + 1];
+    const float* in2 = col[fy + 2];
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float sacc = bv[q];                          // bias
+      sacc += wv[q][0] * in0[0] + wv[q][1] * in0[1] + wv[q][2] * in0[2] + wv[q][3] * in1[0];
+      sacc += wv[q][4] * in1[1] + wv[q][5] * in1[2] + wv[q][6] * in2[0] + wv[q][7] * in2[1];
+      sacc += wv[q][8] * in2[2];
+      r[q] = padded ? 0.f : fmaxf(sacc, 0.f);
+    }
+    const long long pix = ((long long)b * F + f) * T + t;
+    if (OUT16) {
+      f16x4c hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = (_Float16)r[q];
+      *reinterpret_cast<f16x4c*>(out16 + pix * 32 + c4 * 4) = hv;
+    } else {
+      *reinterpret_cast<f32x4*>(out + pix * 32 + c4 * 4) = r;
+    }
+  }
+}
+
 hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const float* w,
                                const float* b, int C, float* out, hipStream_t stream,
                                uint16_t* out16, const int* lens) {
   if (C != 32 || B <= 0) return C != 32 ? hipErrorInvalidValue : hipSuccess;
   dim3 grid((T + ST_TW - 1) / ST_TW, (F + ST_FH - 1) / ST_FH, B);
+  static const bool v1 = getenv("WS_STEM_V1") && atoi(getenv("WS_STEM_V1")) != 0;    // (A/B: the pixel-per-thread form)
+  if (!v1) {
+    if (out16)
+      hipLaunchKernelGGL(stem_conv3x3_rows_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16, lens);
+    else
+      hipLaunchKernelGGL(stem_conv3x3_rows_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16,
+                         lens);
+    return hipGetLastError();
+  }
   if (out16)
     hipLaunchKernelGGL(stem_conv3x3_tile_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
                        out16, lens);
