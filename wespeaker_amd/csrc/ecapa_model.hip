@@ -23,7 +23,7 @@ struct EcapaModel : ModelBase {
   int C = 512, w = 64;
   bool glob = false;
   ConvW layer1, blk0[3], res2[3][7], blk2[3], catconv, pool1, pool2, final_lin;
-  size_t se_w1[3], se_b1[3], se_w2[3], se_b2[3];
+  size_t se_w1[3], se_b1[3], se_w2[3], se_b2[3], se_w2t[3];
   float *out1 = nullptr, *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *cat = nullptr, *h = nullptr,
         *att = nullptr, *e = nullptr, *se_s = nullptr, *stats = nullptr, *bias_img = nullptr,
         *pooled = nullptr, *partial = nullptr, *colsum = nullptr, *colsumsq = nullptr;
@@ -63,6 +63,12 @@ struct EcapaModel : ModelBase {
       if ((err = add_vec(sd, p + ".3.linear1.bias", 128, &se_b1[L]))) return err;
       if (!(t = get(sd, p + ".3.linear2.weight", {C, 128}, &err))) return err;
       se_w2[L] = arena.add(t->data);
+      {   // [128][C] copy for the FC kernels that run from the column sums (a wavefront reads 256 contiguous bytes)
+        std::vector<float> w2t((size_t)C * 128);
+        for (int c = 0; c < C; ++c)
+          for (int k = 0; k < 128; ++k) w2t[(size_t)k * C + c] = t->data[(size_t)c * 128 + k];
+        se_w2t[L] = arena.add(w2t);
+      }
       if ((err = add_vec(sd, p + ".3.linear2.bias", C, &se_b2[L]))) return err;
     }
     if ((err = pack_conv1d(sd, "conv", 1536, 3 * C, 1, true, "", "", &catconv))) return err;
@@ -221,7 +227,7 @@ struct EcapaModel : ModelBase {
         WS_LAUNCH(gemm(p3, st));
         WS_LAUNCH(other(3 * mc, st, [&] {
           return launch_se_fc_scale_residual(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                             arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, L0, x, ldx, x_off,
+                                             arena.at(se_w2t[L]), arena.at(se_b2[L]), 128, se_s, L0, x, ldx, x_off,
                                              y3, C, cat, 3 * C, L * C, st, f16io ? cat16 : nullptr);
         }));
         continue;
@@ -232,7 +238,7 @@ struct EcapaModel : ModelBase {
         WS_LAUNCH(gemm(p3, st));
         WS_LAUNCH(other(0.0, st, [&] {
           return launch_se_fc_from_colsum(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
-                                          arena.at(se_w2[L]), arena.at(se_b2[L]), 128, se_s, st, L0);
+                                          arena.at(se_w2t[L]), arena.at(se_b2[L]), 128, se_s, st, L0);
         }));
       } else {
         WS_LAUNCH(gemm(p3, st));

@@ -98,7 +98,7 @@ hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const
 // one-row-at-a-time form was L2-latency bound).  One body for the stand-alone kernel (512 threads) and the fused
 // FC + scale + residual kernel (1024 threads): an output's sum does not depend on the thread count (FC1: one
 // wavefront per row, the lanes split the C columns the same way; FC2: one thread per channel), so both give the same
-// bits.  Leaves s[0..C) in `mean` (the LDS vector is reused) when S_TO_LDS, else in s_out.
+// bits.  `w2` is the TRANSPOSED second matrix, [bott][C].  Leaves s[0..C) in s_lds too when S_TO_LDS.
 template <int NT, bool S_TO_LDS>
 __device__ __forceinline__ void se_fc_body(const float* __restrict__ colsum, int b, int T, int C,
                                            const float* __restrict__ w1, const float* __restrict__ b1,
@@ -159,19 +159,21 @@ __device__ __forceinline__ void se_fc_body(const float* __restrict__ colsum, int
     }
   }
   __syncthreads();
-  // FC2: thread per output channel; its weight row is bott contiguous floats, 8 loads in flight
+  // FC2: thread per output channel.  The weights are read from the TRANSPOSED copy w2t[k][c] (round 5): a wavefront's
+  // load is then 256 contiguous bytes; with the row-major matrix every lane read 16 B of its own 512-B row -- 64 cache
+  // lines per instruction, eight times the bytes through the L1.  32 loads in flight, the sums term for term as before.
   for (int c = tid; c < C; c += NT) {
-    const float* wr = w2 + (long long)c * bott;
+    const float* wc = w2 + c;
     const float bias2 = b2[c];
     float v = 0.f;
     for (int k = 0; k < bott; k += 32) {
-      f32x4 w[8];
+      float w[32];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(wr + k + q * 4);
+      for (int q = 0; q < 32; ++q) w[q] = wc[(long long)(k + q) * C];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const f32x4 h = *reinterpret_cast<const f32x4*>(&hidden[k + q * 4]);
-        v += w[q][0] * h[0] + w[q][1] * h[1] + w[q][2] * h[2] + w[q][3] * h[3];
+        v += w[4 * q] * h[0] + w[4 * q + 1] * h[1] + w[4 * q + 2] * h[2] + w[4 * q + 3] * h[3];
       }
     }
     const float sg = 1.f / (1.f + expf(-(v + bias2)));

@@ -161,8 +161,9 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
 
 // SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 64 rows):
 // mean[b][c] = (sum of the tile partials covering rows [b*T, (b+1)*T)) / T, then the two FCs.
+// w2t: the second matrix TRANSPOSED, [bottleneck][C] (here and in launch_se_fc_scale_residual)
 hipError_t launch_se_fc_from_colsum(const float* colsum, int B, int T, int C, const float* w1,
-                                    const float* b1, const float* w2, const float* b2,
+                                    const float* b1, const float* w2t, const float* b2,
                                     int bottleneck, float* s, hipStream_t stream, const int* lens = nullptr);
 // SE_Connect (ecapa_tdnn.py:120-126): s[b][c] = sigmoid(W2 relu(W1 mean_t(y[b,t,:]) + b1) + b2)
 hipError_t launch_se_pool_fc(const float* y, int ldy, int B, int T, int C, const float* w1,
@@ -179,7 +180,7 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
 // the SE FCs and the scale + residual pass in one launch (one workgroup per utterance; same bits as the two launches)
 bool se_fc_scale_residual_supported(int T, int C, int bottleneck);
 hipError_t launch_se_fc_scale_residual(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
-                                       const float* w2, const float* b2, int bottleneck, float* s,
+                                       const float* w2t, const float* b2, int bottleneck, float* s,
                                        const int* lens, const float* x, int ldx, int x_off, const float* y, int ldy,
                                        float* out, int ldo, int o_off, hipStream_t stream, uint16_t* out16 = nullptr);
 // ASTP global context (pooling_layers.py:128-133): per (b, c) mean and sqrt(unbiased var + 1e-7)
