@@ -176,7 +176,7 @@ struct ResNetModel : ModelBase {
       ConvGemmParams p = conv2d(cw, in, Cin_, 0, out, Cout_, 0, B, Hin_, Win_, s_, s_, 1, 1, pad, pad, act);
       p.row_len = cur_lens[out_lvl];                       // stride level of this launch's OUTPUT width
       for (int i = 0; i < 4; ++i)                          // the zero pad behind the input's buffer
-        if (in == buf[i]) p.a_zero_off = (long long)act_floats * (long long)sizeof(float);
+        if (in == buf[i] && Cin_ <= 512) p.a_zero_off = (long long)act_floats * (long long)sizeof(float);
       if (f16io) {
         p.A16 = reinterpret_cast<const uint16_t*>(in); p.lda16 = Cin_;
         p.D = nullptr; p.D16 = reinterpret_cast<uint16_t*>(out); p.ldd16 = Cout_;
