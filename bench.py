@@ -196,7 +196,7 @@ def cpu_baseline(model_name, embed_dim, sample_utts, budget_s=8.0):
         if best is None or n / dt > best[0]:
             best = (n / dt, threads, n, dt)
     return {"value": best[0], "unit": "embeddings/s", "cores": best[1], "kind": "port",
-            "host_cores": avail,
+            "host_cores": avail, "host_cpu_model": host_cpu_model(),
             "what": "oracle/ (numpy fbank + torch-fp32 functional restatement of the reference forward, "
                     "bit-identical to the reference nn.Module on the golden cases); the reference checkout "
                     "itself is not on the GPU box, so this is a port, not `reference`",
@@ -285,7 +285,7 @@ def plda_leg(args, device, with_cpu_baseline):
     # dense matrices at the size where the MFMA loop matters: 10 000 x 10 000 = 1e8 trials, the
     # per-rank block of parallel.llr_matrix_sharded, at D = 192 (ECAPA) and D = 512 (CAM++); 800 MB of float64 scores
     dense = {}
-    for dd in (D, 512):
+    for dd in ((D, 512) if args.plda_dense else ()):
         pd = synth.synth_plda(dd, seed=7)
         pl = plda if dd == D else TwoCovPLDA.from_params(pd["mu"], pd["transform"], pd["psi"], pd["offset"], False,
                                                           device=device)
@@ -396,7 +396,7 @@ def plda_leg(args, device, with_cpu_baseline):
                                        "comes from L1: one test-row gather per trial)",
                              "bound": "cache-gather", "achieved": grouped_gbs, "peak": gather_peak_gbs, "unit": "GB/s",
                              "frac": grouped_gbs / gather_peak_gbs, "algorithmic_bytes_per_trial": bpt_g},
-        "dense_1e8": dense,
+        "dense_1e8": dense or None,
         "matrix_trials_per_s": 1e6 / mdt, "matrix_ms": mdt * 1e3,
         "matrix_workload": "dense 1000x1000 LLR matrix D=%d" % D,
         "matrix_roofline": {"kernel": "plda_gemm_f64 (v_mfma_f64_16x16x4_f64, 64x64 tiles)", "bound": "mfma",
@@ -441,6 +441,137 @@ def plda_leg(args, device, with_cpu_baseline):
     return plda_info
 
 
+
+# ------------------------------------------------------------------------------------------ the one line
+LINE_LIMIT = 8192            # the contract reads ONE short stdout line; everything else goes to bench_detail.json
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fp:
+            for ln in fp:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _r(x, nd=6):
+    """floats to `nd` significant digits (the full-precision figure stays in the detail file)."""
+    if isinstance(x, float) and math.isfinite(x) and x != 0.0:
+        return float("%.*g" % (nd, x))
+    return x
+
+
+def _round_tree(o):
+    if isinstance(o, dict):
+        return {k: _round_tree(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_round_tree(v) for v in o]
+    return _r(o)
+
+
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches",
+             "avg_launch_ms", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch",
+             "whole_step_frac_of_peak", "pmc_mfma_busy_fraction_of_cycles", "kernel_time_share")
+
+
+def compact_roofline(roof):
+    if not roof:
+        return roof
+    out = _pick(roof, ROOF_KEYS)
+    if isinstance(out.get("kernel"), str) and len(out["kernel"]) > 200:
+        out["kernel"] = out["kernel"][:197] + "..."
+    return out
+
+
+def compact_line(full, detail_name):
+    """The driver's line from the full record: the contract's keys, the headline `roofline` and `cpu_baseline`,
+    one figure per other BASELINE config -- like runtime/core/bin/extract_emb_main.cc:100-117 prints ONE RTF figure.
+    Everything dropped here is in `detail_name` (written beside this script) unchanged."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                        "scaling", "vs_baseline", "dtype", "data", "config", "headline_backend",
+                        "value_one_batch_in_flight", "value_median_over_windows", "value_spread_rel",
+                        "value_sustained", "embedding_checksum", "collective", "collective_backend"))
+    if full.get("roofline") is not None:
+        line["roofline"] = compact_roofline(full["roofline"])
+    sc = full.get("self_check")
+    if sc:
+        line["self_check"] = _pick(sc, ("ok", "max_rel_l2_vs_small_batch_run", "tolerance"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "host_cores", "host_cpu_model", "sample"))
+    fm = full.get("fast_mode")
+    if fm:
+        line["fast_mode"] = fm
+    pl = full.get("plda")
+    if pl:
+        cp = _pick(pl, ("pairs_trials_per_s", "pairs_ms", "pairs_kernel_only_ms", "pairs_grouped_trials_per_s",
+                        "matrix_trials_per_s", "matrix_ms", "dtype"))
+        if pl.get("roofline"):
+            cp["roofline"] = _pick(pl["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                    "algorithmic_bytes_per_trial",
+                                                    "algorithmic_gbs_frac_of_hbm_peak", "l2_hit_rate"))
+        if pl.get("matrix_roofline"):
+            cp["matrix_roofline"] = _pick(pl["matrix_roofline"], ("bound", "achieved", "peak", "unit", "frac"))
+        if pl.get("cpu_baseline"):
+            cp["cpu_baseline"] = _pick(pl["cpu_baseline"], ("value", "unit", "cores", "kind",
+                                                            "vectorised_numpy_trials_per_s"))
+        line["plda_trials_per_s"] = full.get("plda_trials_per_s")
+        line["plda"] = cp
+    cf = full.get("configs")
+    if cf:
+        cc = {}
+        for mname, leg in cf.items():
+            if mname == "fixed_size_sets_n1_fp32":
+                continue
+            e = {"batch": leg.get("batch")}
+            for prec in ("fp32", "f16"):
+                if prec in leg:
+                    b = leg[prec]
+                    e[prec] = {"value": b["value"], "ms_per_step": b["ms_per_step"],
+                               "whole_step_frac": b["roofline"]["whole_step_frac_of_peak"],
+                               "frac": b["roofline"]["frac"]}
+            cc[mname] = e
+        line["configs"] = cc
+        sets = cf.get("fixed_size_sets_n1_fp32")
+        if sets:
+            line["fixed_size_sets"] = {k: _pick(v, ("value", "ms_per_step", "total_utts", "trials_scored_per_step",
+                                                    "embedding_checksum")) for k, v in sets.items()}
+    if full.get("set") is not None:
+        line["set"] = full["set"]
+    line["detail"] = detail_name
+    line = _round_tree(line)
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:          # never lose the contract's keys to size again: shed the optional blocks
+        for key in ("fixed_size_sets", "configs", "fast_mode", "self_check", "plda"):
+            line.pop(key, None)
+            text = json.dumps(line)
+            if len(text) < LINE_LIMIT:
+                break
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(full, detail_path):
+    """Full record -> the detail file (and stderr's last line names it); compact line -> stdout, once."""
+    try:
+        with open(detail_path, "w") as fp:
+            json.dump(full, fp, indent=1)
+            fp.write("\n")
+        name = os.path.relpath(detail_path, ROOT)
+    except OSError as err:                       # read-only checkout: the line still goes out
+        print("bench.py: could not write %s (%s)" % (detail_path, err), file=sys.stderr)
+        name = None
+    print("bench.py: full record in %s" % name, file=sys.stderr, flush=True)
+    print(compact_line(full, name), flush=True)
+
+
 # ------------------------------------------------------------------------------------------ main
 def parse_args(argv):
     ap = argparse.ArgumentParser()
@@ -471,7 +602,15 @@ def parse_args(argv):
     ap.add_argument("--headline-only", action="store_true",
                     help="only the --precision back-end: no other back-ends, no config legs, no PLDA, no CPU "
                          "baseline (for rocprofv3 runs: the kernel statistics then describe one workload)")
-    ap.add_argument("--sustain-s", type=float, default=5.0,
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (per-back-end blocks, windows, shard tables, notes); stdout "
+                         "carries only the compact line (< 8 KB)")
+    ap.add_argument("--plda-dense", action="store_true",
+                    help="also time the 1e8-trial dense LLR matrices (D = 192 / 512) with the shader clock sampled "
+                         "next to them (opt-in: 1.6 GB of scores per launch)")
+    ap.add_argument("--batch-sweep", action="store_true",
+                    help="also time the headline workload at per-GPU batches of 512 and 1024 (opt-in)")
+    ap.add_argument("--sustain-s", type=float, default=0.0,
                     help="length of the sustained window of the headline back-end (same step function, one timed "
                          "region of this many seconds, the shader clock sampled next to it): `value_sustained`; 0 = off")
     ap.add_argument("--lanes", type=int, default=2,
@@ -502,8 +641,8 @@ def main(argv=None):
 
     if args.plda_only:
         info = plda_leg(args, device, not args.no_cpu_baseline)
-        print(json.dumps({"metric": METRIC, "unit": "trials/s", "value": info["pairs_trials_per_s"], "n_gpus": 1,
-                          "plda": info}), flush=True)
+        emit({"metric": METRIC, "unit": "trials/s", "value": info["pairs_trials_per_s"], "n_gpus": 1,
+              "plda_trials_per_s": info["pairs_trials_per_s"], "plda": info}, args.detail_file)
         return
 
     set_mode = args.workload != "default" or args.total_utts > 0
@@ -680,7 +819,7 @@ def main(argv=None):
                 "collective_backend": dist.get_backend() if active else None,
                 "collective": collective_info(),
             }
-            print(json.dumps(line), flush=True)
+            emit(line, args.detail_file)
         if active:
             fence()
             dist.destroy_process_group()
@@ -1024,7 +1163,7 @@ def main(argv=None):
     # ---- the same workload at larger per-GPU batches (fp32 headline back-end): what the fixed per-launch costs (~45
     # launches, the latency-bound SE / pooling kernels, the partial last rounds of tiles) take at batch 256
     batch_sweep = None
-    if rank == 0 and world == 1 and not args.headline_only and not STUB and not args.batch:
+    if rank == 0 and world == 1 and not args.headline_only and not STUB and not args.batch and args.batch_sweep:
         batch_sweep = {}
         for b in (512, 1024):
             bm = make_model(name, E, b, T)
@@ -1116,7 +1255,7 @@ def main(argv=None):
             heavy = name.startswith("ResNet") and name not in ("ResNet18", "ResNet34")
             line["cpu_baseline"] = cpu_baseline(name, E, args.cpu_utts, budget_s=6.0 if heavy else 8.0)
         assert all_emb.shape == (n_total, E) and bool(torch.isfinite(all_emb).all())
-        print(json.dumps(line), flush=True)
+        emit(line, args.detail_file)
     if active:
         fence()
         dist.destroy_process_group()

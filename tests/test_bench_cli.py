@@ -83,3 +83,60 @@ def test_baseline_sets_on_four_and_eight_ranks(workload, world, total, trials):
         assert abs(x - y) <= 1e-9 * abs(x), key
     assert many["collective_backend"] == "gloo" and many["collective"]["ranks"] == world
     assert one["collective"]["ranks"] == 1 and one["collective_backend"] is None
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def test_compact_line_of_a_full_record_stays_under_8k():
+    """round 5's 24-KB line was not parsed by the driver.  The committed full record of that run goes
+    through bench.compact_line: strict JSON, < 8 KB, the contract's keys + `roofline` + `cpu_baseline` + one figure per
+    BASELINE config; the reference prints ONE figure (runtime/core/bin/extract_emb_main.cc:100-117)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")) as fp:
+        full = json.load(fp)
+    assert len(json.dumps(full)) > 20000                     # the record that broke the parser
+    text = bench.compact_line(full, "bench_detail.json")
+    assert len(text) < 8192 and "\n" not in text
+    line = json.loads(text, parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    for k in REQUIRED:
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["config"]["workload"]
+    roof = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+              "algorithmic_flops_per_launch", "whole_step_frac_of_peak", "traffic_source"):
+        assert k in roof, k
+    assert len(roof["kernel"]) <= 200 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert line["plda"]["pairs_trials_per_s"] > 0 and line["plda"]["roofline"]["frac"] > 0
+    assert line["plda"]["cpu_baseline"]["value"] > 0
+    assert set(line["configs"]) == {"ECAPA_TDNN_GLOB_c1024", "ResNet34", "ResNet221", "CAMPPlus"}
+    assert all(line["configs"][m]["fp32"]["value"] > 0 for m in line["configs"])
+    assert len(line["fixed_size_sets"]) == 3
+    assert line["collective"]["ranks"] == 1 and line["detail"] == "bench_detail.json"
+
+
+def test_stub_lines_are_short_and_the_detail_file_is_written(tmp_path):
+    """Every mode's stdout line is one strict-JSON line < 8 KB; the full record lands in --detail-file."""
+    det = str(tmp_path / "detail.json")
+    for argv in (("--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--windows", "2"),
+                 ("--gpus", "8", "--workload", "vox1o", "--batch", "512", "--steps", "1", "--warmup", "1",
+                  "--seconds", "0.1")):
+        env = dict(os.environ, WS_BENCH_STUB="1")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", det] + list(argv),
+                           env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        allout = [l for l in r.stdout.splitlines() if l.strip()]
+        out = [l for l in allout if l.startswith("{")]           # (gloo prints its own connection notes on stdout)
+        assert len(out) == 1 and len(out[0]) < 8192 and allout[-1] == out[0], r.stdout[:500]
+        line = json.loads(out[0])
+        for k in REQUIRED:
+            assert k in line, k
+        with open(det) as fp:
+            full = json.load(fp)
+        assert full["value"] == pytest.approx(line["value"], rel=1e-5)
