@@ -60,9 +60,10 @@ typedef void* ws_stream;                /* hipStream_t */
 
 /* ------------------------------------------------------------------------------------ misc */
 /* Bumped whenever an exported signature changes (101: ws_plda_stats takes `emb_is_f64` and a void* table since
- * round 2 -- a caller built against 100 would pass shifted arguments).  ws_version() returns the library's value:
+ * round 2 -- a caller built against 100 would pass shifted arguments; 104: ws_frontend_set_cmvn / ws_cmvn added, the
+ * `cmn` flags now mean "apply the frontend's CMVN").  ws_version() returns the library's value:
  * compare it with the header's before calling anything else. */
-#define WS_VERSION 103
+#define WS_VERSION 104
 WS_API int ws_version(void);
 WS_API const char* ws_last_error(void);
 /* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):
@@ -92,6 +93,12 @@ WS_API int ws_wav_load_rows(const char* const* paths, int n, int threads, int16_
  * calls.  WS_ERR_INVALID_ARG outside that range. */
 WS_API int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_frontend** out);
 WS_API void ws_frontend_destroy(ws_frontend* fe);
+/* Which apply_cmvn (dataset/dataset_utils.py:19-26) the frontend's CMVN step is: test_conf['cmvn_args'] of
+ * bin/extract.py:124-127.  norm_mean subtracts the per-utterance mean over T from every mel bin; norm_var divides by
+ * sqrt(var + 1e-7), var = the unbiased estimate over T (torch.var).  Default (1, 0) = cli/speaker.py:98-99.
+ * (0, 0) = `cmvn: False`: no normalisation anywhere.  Applies wherever a call of this frontend normalises:
+ * ws_fbank / ws_fbank_ragged with cmn != 0 and the fused ws_extract / ws_extract_ragged. */
+WS_API int ws_frontend_set_cmvn(ws_frontend* fe, int norm_mean, int norm_var);
 /* wav: DEVICE (B, wav_stride) samples, the first num_samples of each row are used.
  * scale multiplies samples on load (1.0 for int16-range input; 32768.0 reproduces
  * processor.py:516 `waveform * (1 << 15)` for [-1,1] floats).
@@ -189,6 +196,9 @@ WS_API int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, 
  * Speaker.extract_embedding_from_feats(..., subseg_cmn=True), cli/speaker.py:108-112, and
  * diar/extract_emb.py:88-90).  feats DEVICE float32 (batch, num_frames, feat_dim). */
 WS_API int ws_cmn(float* feats, int batch, int num_frames, int feat_dim, ws_stream stream);
+/* apply_cmvn(feats, norm_mean, norm_var) (dataset/dataset_utils.py:19-26) in place on device features. */
+WS_API int ws_cmvn(float* feats, int batch, int num_frames, int feat_dim, int norm_mean, int norm_var,
+            ws_stream stream);
 
 /* Diarization sub-segment extraction of ONE speech segment in one call: the loop body of Speaker.diarize
  * (cli/speaker.py:232-251) = compute_features(cmn=False) -> subsegment() (diar/extract_emb.py:55-83) ->

@@ -134,3 +134,17 @@ def speaker_features(pcm_int16, window_type="hamming", sample_rate=16000, cmn=Tr
     x = np.asarray(pcm_int16).astype(np.float32)
     return kaldi_fbank(x, num_mel_bins=80, frame_length=25, frame_shift=10,
                        sample_frequency=sample_rate, window_type=window_type, cmn=cmn)
+
+
+def apply_cmvn(feats, norm_mean=True, norm_var=False):
+    """The reference's test-time CMVN (wespeaker/dataset/dataset_utils.py:19-26, called at bin/extract.py:124-127):
+    feats (B, T, F) float32; mean over T subtracted, then divided by sqrt(unbiased var over T + 1e-7) -- the variance
+    is taken of the already mean-subtracted tensor.  numpy float32 restatement (pinned to the reference function on
+    tests/golden/cmvn_ref.npz)."""
+    x = np.asarray(feats, dtype=np.float32)
+    if norm_mean:
+        x = x - x.mean(axis=1, keepdims=True, dtype=np.float32)
+    if norm_var:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            x = x / np.sqrt(x.var(axis=1, keepdims=True, ddof=1, dtype=np.float32) + np.float32(1e-7))
+    return x.astype(np.float32)

@@ -10,6 +10,9 @@ What is recorded (all seeds live in fixtures/synth.py, inputs are regenerated fr
                        ECAPA constructors on synthetic utterances 0..1, weights = synth seed 42.
   * resnet_ref.npz / campplus_ref.npz -- the same for the reference's ResNet18/34/50/221 and
                        CAMPPlus modules (wespeaker/models/resnet.py, campplus.py).
+  * resnet_deep_ref.npz -- ResNet101 / ResNet152 / ResNet293 (resnet.py:231-260), same inputs, 198 and 57 frames.
+  * cmvn_ref.npz    -- the reference's own apply_cmvn (dataset/dataset_utils.py:19-26) for the four
+                       (norm_mean, norm_var) settings + ECAPA-512 embeddings of the (1,1) and (0,0) features.
   * plda_ref.npz    -- outputs of the reference's own TwoCovPLDA.transform_embedding /
                        log_likelihood_ratio (wespeaker/utils/plda/two_cov_plda.py:156-184).
   * score_ref.npz   -- outputs of the reference's own bin/score.py (trials_cosine_score) and
@@ -152,6 +155,42 @@ def make_resnet_campplus():
                                    pooling_func="TSTP")}
     np.savez_compressed(os.path.join(GOLD, "campplus_ref.npz"), **cam)
     print("CAMPPlus", float(np.abs(cam["emb"]).mean()))
+
+
+def make_resnet_deep():
+    """The three remaining constructors of wespeaker/models/resnet.py:231-260 (ResNet101 / 152 / 293: Bottleneck
+    [3,4,23,3] / [3,8,36,3] / [10,20,64,3]) through the reference's own nn.Module: one 2-s and one T = 57 case each."""
+    feats = np.stack([speaker_features(synth.synth_wav(i)) for i in range(2)])
+    out = {}
+    for name in ("ResNet101", "ResNet152", "ResNet293"):
+        sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42)
+        out[name + "/emb"] = _ref_forward(name, sd, feats, feat_dim=80, embed_dim=256, pooling_func="TSTP")
+        out[name + "/emb_T57"] = _ref_forward(name, sd, feats[:, :57].copy(), feat_dim=80, embed_dim=256,
+                                              pooling_func="TSTP")
+        print(name, float(np.abs(out[name + "/emb"]).mean()))
+    np.savez_compressed(os.path.join(GOLD, "resnet_deep_ref.npz"), **out)
+
+
+def make_cmvn():
+    """The reference's own apply_cmvn (wespeaker/dataset/dataset_utils.py:19-26) on un-normalised fbank features of
+    synthetic utterances 0..2 (198 frames) and a 57-frame cut, for the four (norm_mean, norm_var) settings, plus the
+    ECAPA-512 embedding of the (True, True) features through the reference module (the path bin/extract.py:124-135
+    takes with `cmvn_args: {norm_var: True}`)."""
+    du = ref_shim.ref_module("wespeaker.dataset.dataset_utils")
+    raw = np.stack([speaker_features(synth.synth_wav(i), cmn=False) for i in range(3)])
+    out = {}
+    for nm in (False, True):
+        for nv in (False, True):
+            tag = "m%dv%d" % (nm, nv)
+            out[tag] = du.apply_cmvn(torch.from_numpy(raw), norm_mean=nm, norm_var=nv).numpy()
+            out[tag + "_T57"] = du.apply_cmvn(torch.from_numpy(raw[:, :57].copy()), norm_mean=nm, norm_var=nv).numpy()
+    sd = synth.synth_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    out["ecapa512_m1v1/emb"] = _ref_forward("ECAPA_TDNN_GLOB_c512", sd, out["m1v1"], feat_dim=80, embed_dim=192,
+                                            pooling_func="ASTP")
+    out["ecapa512_m0v0/emb"] = _ref_forward("ECAPA_TDNN_GLOB_c512", sd, out["m0v0"], feat_dim=80, embed_dim=192,
+                                            pooling_func="ASTP")
+    np.savez_compressed(os.path.join(GOLD, "cmvn_ref.npz"), **out)
+    print("cmvn", {k: float(np.abs(v).mean()) for k, v in out.items() if not k.endswith("T57")})
 
 
 def make_plda():
@@ -361,6 +400,7 @@ def make_subsegment():
 
 
 SECTIONS = {"fbank": make_fbank, "fbank_rates": make_fbank_rates, "subsegment": make_subsegment, "ecapa": make_ecapa, "resnet_campplus": make_resnet_campplus,
+            "resnet_deep": make_resnet_deep, "cmvn": make_cmvn,
             "plda": make_plda, "score": make_score, "plda_train": make_plda_train,
             "embd_proc": make_embd_proc, "kaldi_plda": make_kaldi_plda, "chunked": make_chunked}
 

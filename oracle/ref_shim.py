@@ -19,7 +19,7 @@ def _seed_packages():
         return
     for name, sub in (("wespeaker", ""), ("wespeaker.models", "models"),
                       ("wespeaker.utils", "utils"), ("wespeaker.utils.plda", "utils/plda"),
-                      ("wespeaker.bin", "bin")):
+                      ("wespeaker.bin", "bin"), ("wespeaker.dataset", "dataset")):
         m = types.ModuleType(name)
         m.__path__ = [os.path.join(REF_ROOT, "wespeaker", sub)]
         m._oracle_shim = True

@@ -120,11 +120,20 @@ def test_random_chunk_cohort_mode(tmp_path):
 def test_frontend_config_is_checked_loudly():
     ok = {"model": "ECAPA_TDNN_GLOB_c512", "dataset_args": {"resample_rate": 16000, "fbank_args":
           {"num_mel_bins": 80, "frame_shift": 10, "frame_length": 25, "dither": 1.0}}}
-    assert wx.check_frontend_config(ok) == {"resample_rate": 16000, "num_mel_bins": 80, "num_frms": 200}
-    for bad in ({"frontend": "s3prl"}, {"fbank_args": {"frame_shift": 20}}, {"cmvn": False},
-                {"cmvn_args": {"norm_var": True}}):
+    assert wx.check_frontend_config(ok) == {"resample_rate": 16000, "num_mel_bins": 80, "num_frms": 200,
+                                            "norm_mean": True, "norm_var": False}
+    for bad in ({"frontend": "s3prl"}, {"fbank_args": {"frame_shift": 20}}):
         with pytest.raises(NotImplementedError):
             wx.check_frontend_config({"dataset_args": bad})
+    # test_conf['cmvn'] / ['cmvn_args'] (bin/extract.py:124-127 -> apply_cmvn, dataset_utils.py:19-26)
+    for ds, want in (({"cmvn": False}, (False, False)), ({"cmvn_args": {"norm_var": True}}, (True, True)),
+                     ({"cmvn_args": {"norm_mean": False, "norm_var": True}}, (False, True)),
+                     ({"cmvn": False, "cmvn_args": {"norm_var": True}}, (False, False)),
+                     ({"cmvn_args": {"norm_mean": False}}, (False, False))):
+        fc = wx.check_frontend_config({"dataset_args": ds})
+        assert (fc["norm_mean"], fc["norm_var"]) == want, ds
+    with pytest.raises(TypeError):                       # apply_cmvn(**{'norm_std': ...}) is a TypeError there too
+        wx.check_frontend_config({"dataset_args": {"cmvn_args": {"norm_std": True}}})
 
 
 def _job_worker(rank, world, port, embed_dir, lines, q):

@@ -152,6 +152,41 @@ def test_resnet_restatement_vs_reference_golden(golden_dir, name, kw):
     assert np.abs(emb_s - g[tag + "/emb_T57"]).max() <= 2e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("name", ["ResNet101", "ResNet152", "ResNet293"])
+def test_resnet_deep_restatement_vs_reference_golden(golden_dir, name):
+    """wespeaker/models/resnet.py:231-260: the constructors the first golden file left out."""
+    from oracle import resnet as oresnet
+    g = np.load(os.path.join(golden_dir, "resnet_deep_ref.npz"))
+    sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42)
+    feats = np.stack([ofbank.speaker_features(synth.synth_wav(i)) for i in range(2)])
+    ref = g[name + "/emb"]
+    emb = oresnet.resnet_forward(sd, feats, name).numpy()
+    assert emb.shape == ref.shape == (2, 256)
+    assert np.abs(emb - ref).max() <= 2e-4 * np.abs(ref).max()
+    emb_s = oresnet.resnet_forward(sd, feats[:, :57], name).numpy()
+    assert np.abs(emb_s - g[name + "/emb_T57"]).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_apply_cmvn_restatement_vs_reference_golden(golden_dir):
+    """oracle.fbank.apply_cmvn vs the reference's own function (dataset/dataset_utils.py:19-26) for the four
+    (norm_mean, norm_var) settings at 198 and 57 frames; live against the reference when it is here."""
+    g = np.load(os.path.join(golden_dir, "cmvn_ref.npz"))
+    raw = g["m0v0"]
+    for nm in (False, True):
+        for nv in (False, True):
+            for suffix, x in (("", raw), ("_T57", raw[:, :57])):
+                want = g["m%dv%d%s" % (nm, nv, suffix)]
+                got = ofbank.apply_cmvn(x, nm, nv)
+                assert got.dtype == np.float32 and got.shape == want.shape
+                assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (nm, nv, suffix)
+    assert np.isnan(ofbank.apply_cmvn(raw[:, :1], True, True)).all()      # torch.var of one frame is NaN
+    if ref_shim.available():
+        du = ref_shim.ref_module("wespeaker.dataset.dataset_utils")
+        live = du.apply_cmvn(torch.from_numpy(raw), norm_mean=True, norm_var=True).numpy()
+        assert np.array_equal(live, g["m1v1"])
+        assert bool(torch.isnan(du.apply_cmvn(torch.from_numpy(raw[:, :1].copy()), True, True)).all())
+
+
 def test_campplus_restatement_vs_reference_golden(golden_dir):
     from oracle import campplus as ocam
     g = np.load(os.path.join(golden_dir, "campplus_ref.npz"))

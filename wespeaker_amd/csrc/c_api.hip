@@ -26,6 +26,7 @@ using namespace wsamd;
 struct ws_frontend {
   int sample_rate = 16000, num_bins = 80, device = 0;
   int frame_len = 400, frame_shift = 160, fft_n = 512;
+  int cmvn_mode = 1;                 // bit 0 norm_mean, bit 1 norm_var (ws_frontend_set_cmvn); 0 = cmvn: False
   DevBuf window_h, window_p, twiddle, mel_start, mel_len, mel_off, mel_w;
   FbankTables tables;
   // ws_fbank_ragged: per-utterance frame counts (device) + their pinned staging, in a ring of slots.  A slot's `done`
@@ -176,6 +177,12 @@ int ws_frontend_create(int sample_rate, int num_mel_bins, int device_id, ws_fron
 
 void ws_frontend_destroy(ws_frontend* fe) { delete fe; }
 
+int ws_frontend_set_cmvn(ws_frontend* fe, int norm_mean, int norm_var) {
+  if (!fe) { set_error("ws_frontend_set_cmvn: invalid argument"); return WS_ERR_INVALID_ARG; }
+  fe->cmvn_mode = (norm_mean ? 1 : 0) | (norm_var ? 2 : 0);
+  return WS_OK;
+}
+
 int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num_samples,
              int64_t wav_stride, float scale, int window_type, int cmn, float* feats,
              ws_stream stream) {
@@ -191,7 +198,7 @@ int ws_fbank(ws_frontend* fe, const void* wav, int wav_dtype, int batch, int num
   WS_HIP_CHECK(hipSetDevice(fe->device));
   WS_HIP_CHECK(launch_fbank(fe->tables, wav, wav_dtype, batch, num_samples, wav_stride, scale,
                             window_type, T, feats, st));
-  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st));
+  if (cmn) WS_HIP_CHECK(launch_cmn(feats, batch, T, fe->num_bins, st, nullptr, fe->cmvn_mode));
   return WS_OK;
 }
 
@@ -235,7 +242,7 @@ int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int batch, 
   if (he == hipSuccess)
     he = launch_fbank(fe->tables, wav, wav_dtype, batch, max_samples, wav_stride, scale, window_type, T, feats, st,
                       sl.dev.as<int>());
-  if (he == hipSuccess && cmn) he = launch_cmn(feats, batch, T, fe->num_bins, st, sl.dev.as<int>());
+  if (he == hipSuccess && cmn) he = launch_cmn(feats, batch, T, fe->num_bins, st, sl.dev.as<int>(), fe->cmvn_mode);
   const hipError_t re = hipEventRecord(sl.done, st);
   sl.used = true;
   if (re != hipSuccess) (void)hipStreamSynchronize(st);        // no event to wait for: drain the stream instead
@@ -489,7 +496,7 @@ int ws_extract_ragged(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_
     const char* w = reinterpret_cast<const char*>(wav) + (size_t)b0 * wav_stride * esz;
     WS_HIP_CHECK(launch_fbank(fe->tables, w, wav_dtype, nb, max_samples, wav_stride, scale, window_type, T, fw,
                               st, lens + b0));
-    WS_HIP_CHECK(launch_cmn(fw, nb, T, fe->num_bins, st, lens + b0));
+    WS_HIP_CHECK(launch_cmn(fw, nb, T, fe->num_bins, st, lens + b0, fe->cmvn_mode));
     int r = eng->model->forward_chunk_ragged(fw, nb, T, lens, batch, b0, emb + (size_t)b0 * eng->embed_dim, st);
     if (r) return r;
   }
@@ -565,6 +572,14 @@ int ws_extract_chunked(ws_engine* eng, ws_frontend* fe, const void* wav, int wav
   if (r) return r;
   WS_HIP_CHECK(launch_chunk_average(cemb, n_chunks, E, emb, st));
   return n_chunks;
+}
+
+int ws_cmvn(float* feats, int batch, int num_frames, int feat_dim, int norm_mean, int norm_var, ws_stream stream) {
+  if (!feats || batch < 0 || num_frames < 0 || feat_dim <= 0) { set_error("ws_cmvn: invalid argument"); return WS_ERR_INVALID_ARG; }
+  if (batch == 0 || num_frames == 0) return WS_OK;
+  WS_HIP_CHECK(launch_cmn(feats, batch, num_frames, feat_dim, (hipStream_t)stream, nullptr,
+                          (norm_mean ? 1 : 0) | (norm_var ? 2 : 0)));
+  return WS_OK;
 }
 
 int ws_cmn(float* feats, int batch, int num_frames, int feat_dim, ws_stream stream) {

@@ -246,19 +246,22 @@ hipError_t launch_fbank(const FbankTables& t, const void* wav, int wav_dtype, in
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------ CMN
-// feats[b, t, :] -= mean_t feats[b, :, :]   (cli/speaker.py:98-99).  grid = B, block = 1024: one workgroup per
-// utterance (the mean needs all of its frames, the update is in place), so its speed is the number of loads it
-// keeps in flight -- 1024 / F row groups, four independent partial sums each (a 256-thread block with two took
-// 74 us for 64 x 8 s utterances: 133 dependent round trips per thread).
+// ------------------------------------------------------------------------------------------ CMVN
+// apply_cmvn (dataset/dataset_utils.py:19-26; the mean-only form is cli/speaker.py:98-99):
+//   mode & 1 (norm_mean): feats[b, t, :] -= mean_t feats[b, :, :]
+//   mode & 2 (norm_var):  feats[b, t, :] /= sqrt(var_t feats[b, :, :] + 1e-7), var = torch.var's unbiased estimate
+//                         (sum of squared deviations / (T - 1): T = 1 gives 0 / 0 = NaN there and here)
+// grid = B, block = 1024: one workgroup per utterance (the statistics need all of its frames, the update is in
+// place), so its speed is the number of loads it keeps in flight -- 1024 / F row groups, four independent partial sums
+// each (a 256-thread block with two took 74 us for 64 x 8 s utterances: 133 dependent round trips per thread).
 constexpr int CMN_THREADS = 1024;
 __global__ __launch_bounds__(CMN_THREADS) void cmn_kernel(float* __restrict__ feats, int T, int F,
-                                                          const int* __restrict__ lens) {
-  extern __shared__ float sm[];      // [groups][F]
+                                                          const int* __restrict__ lens, int mode) {
+  extern __shared__ float sm[];      // [groups][F], then [F] means (+ [F] divisors behind them with norm_var)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int groups = CMN_THREADS / F > 0 ? CMN_THREADS / F : 1;
   float* base = feats + (long long)b * T * F;
-  if (lens) T = lens[b];             // ragged batch: mean over (and subtracted from) the valid frames only
+  if (lens) T = lens[b];             // ragged batch: statistics over (and applied to) the valid frames only
   const int col = tid % F, grp = tid / F;
   if (grp < groups) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -273,14 +276,56 @@ __global__ __launch_bounds__(CMN_THREADS) void cmn_kernel(float* __restrict__ fe
     sm[grp * F + col] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
+  float mean = 0.f;
   if (tid < F) {
     float s = 0.f;
     for (int g = 0; g < groups; ++g) s += sm[g * F + tid];
-    sm[tid] = s / (float)T;
+    mean = s / (float)T;
   }
   __syncthreads();
+  if (tid < F) sm[tid] = mean;
+  __syncthreads();
+  float* sdiv = sm + (size_t)groups * F;          // [F] divisors (norm_var only; the launch sizes the LDS for it)
+  if (mode & 2) {
+    // second pass over the (cache-resident) utterance: squared deviations from the mean just formed -- the reference
+    // takes torch.var of the already mean-subtracted features, i.e. the two-pass form, not E[x^2] - E[x]^2
+    float q0 = 0.f, q1 = 0.f;
+    if (grp < groups) {
+      const float m = sm[col];
+      int t = grp;
+      for (; t + groups < T; t += 2 * groups) {
+        const float d0 = base[(long long)t * F + col] - m, d1 = base[(long long)(t + groups) * F + col] - m;
+        q0 += d0 * d0; q1 += d1 * d1;
+      }
+      for (; t < T; t += groups) { const float d0 = base[(long long)t * F + col] - m; q0 += d0 * d0; }
+    }
+    __syncthreads();                               // (the means are in registers `m`; sm[F ..) is reused below)
+    const float keep = tid < F ? sm[tid] : 0.f;
+    __syncthreads();
+    if (grp < groups) sm[grp * F + col] = q0 + q1;
+    __syncthreads();
+    float dv = 0.f;
+    if (tid < F) {
+      float s = 0.f;
+      for (int g = 0; g < groups; ++g) s += sm[g * F + tid];
+      dv = sqrtf(s / (float)(T - 1) + 1e-7f);
+    }
+    __syncthreads();
+    if (tid < F) { sm[tid] = keep; sdiv[tid] = dv; }
+    __syncthreads();
+  }
+  if (!(mode & 1)) {                               // norm_mean = False: nothing is subtracted
+    __syncthreads();
+    if (tid < F) sm[tid] = 0.f;
+    __syncthreads();
+  }
   const long long total = (long long)T * F;
-  if ((F & 3) == 0 && (reinterpret_cast<unsigned long long>(base) & 15) == 0) {   // 16-B read-modify-write;
+  if (mode & 2) {
+    for (long long i = tid; i < total; i += CMN_THREADS) {
+      const int c = (int)(i % F);
+      base[i] = (base[i] - sm[c]) / sdiv[c];
+    }
+  } else if ((F & 3) == 0 && (reinterpret_cast<unsigned long long>(base) & 15) == 0) {   // 16-B read-modify-write;
                                      // F % 4 == 0 keeps a lane inside one row
     typedef float f32x4e __attribute__((ext_vector_type(4)));
     f32x4e* b4 = reinterpret_cast<f32x4e*>(base);
@@ -295,11 +340,12 @@ __global__ __launch_bounds__(CMN_THREADS) void cmn_kernel(float* __restrict__ fe
   }
 }
 
-hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens) {
-  if (F > CMN_THREADS || F <= 0) return hipErrorInvalidValue;
+hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens, int mode) {
+  if (F > CMN_THREADS || F <= 0 || mode < 0 || mode > 3) return hipErrorInvalidValue;
+  if (mode == 0) return hipSuccess;                // cmvn: False
   const int groups = CMN_THREADS / F;
-  hipLaunchKernelGGL(cmn_kernel, dim3(B), dim3(CMN_THREADS), (size_t)groups * F * sizeof(float), stream,
-                     feats, T, F, lens);
+  hipLaunchKernelGGL(cmn_kernel, dim3(B), dim3(CMN_THREADS), ((size_t)groups * F + F) * sizeof(float), stream,
+                     feats, T, F, lens, mode);
   return hipGetLastError();
 }
 

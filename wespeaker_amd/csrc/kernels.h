@@ -296,7 +296,8 @@ bool fbank_fast_kernel_fits(const FbankTables& t);   // the specialised 512-poin
 void set_fbank_debug_mode(int mode);   // ws_debug_fbank_mode (0 shipped kernels, 1 packed-fp32 reproducer, 2 any-length kernel for all)
 // lens (optional, [B]): valid frames per utterance of a ragged batch -- fbank writes zero rows beyond
 // them, CMN averages over / subtracts from the valid rows only
-hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr);
+hipError_t launch_cmn(float* feats, int B, int T, int F, hipStream_t stream, const int* lens = nullptr,
+                      int mode = 1);   // mode: bit 0 norm_mean, bit 1 norm_var (apply_cmvn, dataset_utils.py:19-26)
 hipError_t launch_copy_rows_masked(const float* src, float* dst, int B, int T, int F, const int* lens,
                                    hipStream_t stream);
 // diarization sub-segment windows of one segment's fbank (diar/extract_emb.py:55-83): dst [n_windows][window][F]

@@ -54,6 +54,14 @@ class Frontend:
     def num_frames(self, num_samples: int) -> int:
         return _lib.lib().ws_num_frames(int(num_samples), self.sample_rate)
 
+    def set_cmvn(self, norm_mean=True, norm_var=False):
+        """Which apply_cmvn (dataset/dataset_utils.py:19-26) this frontend's normalisation step is -- the `cmn=True`
+        of fbank / fbank_ragged and the fused extract calls; (False, False) = the config's `cmvn: False`."""
+        _lib.check(_lib.lib().ws_frontend_set_cmvn(self._h, int(bool(norm_mean)), int(bool(norm_var))),
+                   "ws_frontend_set_cmvn")
+        self.norm_mean, self.norm_var = bool(norm_mean), bool(norm_var)
+        return self
+
     def fbank_ragged(self, wav: torch.Tensor, num_samples, window_type="hamming", cmn=True, scale=1.0):
         """Padded (B, Nmax) waveforms + per-utterance sample counts -> (B, Tmax, bins) features whose rows
         beyond an utterance's own frames are zero; CMN over the utterance's own frames (ws_fbank_ragged)."""

@@ -509,14 +509,18 @@ def check_frontend_config(configs):
     fb = dict(ds.get("fbank_args") or {})
     if fb.get("frame_length", 25) != 25 or fb.get("frame_shift", 10) != 10:
         raise NotImplementedError("fbank frame_length/frame_shift other than 25/10 ms")
-    if not ds.get("cmvn", True):
-        raise NotImplementedError("cmvn: False (the fused ws_extract path always subtracts the mean)")
+    # test_conf.get('cmvn', True) / apply_cmvn(features, **test_conf.get('cmvn_args', {})): bin/extract.py:124-127,
+    # dataset_utils.py:19-26 (defaults norm_mean=True, norm_var=False); `cmvn: False` = neither
     cm = dict(ds.get("cmvn_args") or {})
-    if not cm.get("norm_mean", True) or cm.get("norm_var", False):
-        raise NotImplementedError("cmvn_args other than norm_mean=True, norm_var=False")
+    unknown = set(cm) - {"norm_mean", "norm_var"}
+    if unknown:
+        raise TypeError("apply_cmvn() got an unexpected keyword argument %r" % sorted(unknown)[0])
+    on = bool(ds.get("cmvn", True))
     return {"resample_rate": int(ds.get("resample_rate", 16000)),
             "num_mel_bins": int(fb.get("num_mel_bins", 80)),
-            "num_frms": int(ds.get("num_frms", 200))}
+            "num_frms": int(ds.get("num_frms", 200)),
+            "norm_mean": on and bool(cm.get("norm_mean", True)),
+            "norm_var": on and bool(cm.get("norm_var", False))}
 
 
 def chunk_samples(num_frms, resample_rate, frame_shift=10, frame_length=25):
@@ -546,6 +550,7 @@ def build_gpu_extractor(configs, model_path, device=None, max_batch=256, max_fra
                                    max_batch=max_batch, max_frames=max_frames)
     model.set_precision(precision)
     fe = Frontend(fc["resample_rate"], feat_dim, device=model.device)
+    fe.set_cmvn(fc["norm_mean"], fc["norm_var"])
     return GpuExtractor(model, fe), fc
 
 
