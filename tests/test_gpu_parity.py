@@ -2109,6 +2109,42 @@ def test_ragged_forward_rows_equal_the_batch1_oracle(name, E, lens, prec):
         model.embed_ragged(torch.from_numpy(pad), [0] + lens[1:])                   # shorter than the model minimum
 
 
+def test_res2_chain_four_wavefront_kernel_sizes():
+    """res2_chain4_kernel (csrc/res2_chain4.hip; ecapa_tdnn.py:58-78): the fp32 chain of ECAPA-512 takes it when the
+    batch fills the chip (> 64 utterances) and 129 <= T <= 208 -- one instantiation per number of 16-row tiles (9 .. 13).
+    Each of them, uniform and as a ragged batch whose shorter utterances end inside other tiles (down to T = 70: most
+    tiles are past the end, dropped by the buffer bounds), against the batch-1 oracle on spot rows and against the
+    engine's own small-batch path (the eight-wavefront kernel: same k order, so the rows must agree to fp32 noise)."""
+    sd = synth.synth_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    B = 72
+    model = _native("ECAPA_TDNN_GLOB_c512", sd, 192, max_batch=B, max_frames=208)
+    small = _native("ECAPA_TDNN_GLOB_c512", sd, 192, max_batch=4, max_frames=208)
+    for T in (129, 145, 170, 190, 198, 208):
+        f = np.random.RandomState(T).randn(B, T, 80).astype(np.float32)
+        got = model(torch.from_numpy(f))[-1].cpu().numpy()
+        rows = [0, 17, B - 1]
+        ref = oecapa.ecapa_forward(sd, f[rows]).numpy()
+        assert _cos_err(got[rows], ref).max() < COS_TOL and _rel_err(got[rows], ref).max() < REL_TOL, T
+        other = small(torch.from_numpy(f[:4]))[-1].cpu().numpy()
+        assert _rel_err(got[:4], other).max() < 1e-5, T
+        assert np.isfinite(got).all()
+    T = 200
+    lens = [200 - (i * 37) % 131 for i in range(B)]                 # 70 .. 200, every tile count from 5 to 13
+    assert min(lens) == 70 and max(lens) == 200
+    feats = [np.random.RandomState(500 + i).randn(n, 80).astype(np.float32) for i, n in enumerate(lens)]
+    pad = np.full((B, T, 80), np.nan, dtype=np.float32)
+    for i, x in enumerate(feats):
+        pad[i, :lens[i]] = x
+    got = model.embed_ragged(torch.from_numpy(pad), lens).cpu().numpy()
+    assert np.isfinite(got).all()
+    rows = [0, 1, 2, 3, 40, B - 1]
+    ref = _oracle_rows(lambda x: oecapa.ecapa_forward(sd, x).numpy(), [feats[i] for i in rows])
+    assert _cos_err(got[rows], ref).max() < COS_TOL and _rel_err(got[rows], ref).max() < REL_TOL
+    for i in rows[:4]:
+        one = small(torch.from_numpy(feats[i][None]))[-1].cpu().numpy()
+        assert _rel_err(got[i:i + 1], one).max() < 1e-5, i
+
+
 @pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 192), ("ResNet34", 256), ("CAMPPlus", 512)])
 def test_ragged_extract_from_waveforms(frontend, name, E):
     """ws_extract_ragged (wav -> fbank -> CMN -> forward on a padded batch) against the oracle run on every

@@ -33,6 +33,16 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _extra_flags(src):
+    """Per-file compiler flags: a `// WS_BUILD_FLAGS: ...` line among the first lines of the source."""
+    with open(src) as f:
+        for _ in range(5):
+            line = f.readline()
+            if line.startswith("// WS_BUILD_FLAGS:"):
+                return line.split(":", 1)[1].split()
+    return []
+
+
 def _newest_header():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "wespeaker_amd.h"))
@@ -51,7 +61,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if (force or not os.path.exists(obj)
                 or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + _extra_flags(src) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -66,7 +76,10 @@ def build(force=False, verbose=True):
             print(out)
         if rc != 0:
             raise RuntimeError("compile failed: %s\n%s" % (" ".join(cmd), out))
-    need_link = bool(jobs) or not os.path.exists(LIB) or force
+    # (after a build whose ISA check failed the objects are up to date and the OLD library is still in
+    # place -- "no jobs" must not mean "nothing to link": any object newer than the library forces the link + check)
+    need_link = (bool(jobs) or not os.path.exists(LIB) or force
+                 or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs))
     if need_link:
         # only the C-ABI of include/wespeaker_amd.h leaves the library (kernel handles and every internal
         # C++ symbol stay local)

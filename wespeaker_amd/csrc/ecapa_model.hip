@@ -192,7 +192,7 @@ struct EcapaModel : ModelBase {
       WS_LAUNCH(gemm(p, st));
       // Res2: sp_i = BN(ReLU(conv_k3_dil(sp_{i-1} + split_i)))
       if (res2_chain_supported(w, T, d)) {       // one launch, running activation kept in LDS
-        Res2ChainParams r;
+        Res2ChainParams r = {};
         r.y1 = y1; r.ldy1 = C; r.y2 = y2; r.ldy2 = C; r.ldw = res2[L][0].ldw;
         for (int i = 0; i < 7; ++i) {
           r.w[i] = arena.at(res2[L][i].w); r.bias[i] = arena.at(res2[L][i].b);

@@ -151,6 +151,7 @@ struct Res2ChainParams {
   int y2h_direct;                           // set by launch_res2_chain: the binary16 rows go to y2h as 8-byte
                                             // stores from the accumulators (no LDS staging: it does not fit
                                             // beside the w = 128 activation planes)
+  int force_wave8;                          // probes / tests: keep the eight-wavefront kernel (res2_chain4_kernel's A/B)
   int tiles, tile_rows;                     // set by launch_res2_chain: time tiles per utterance (1 = the whole
                                             // utterance in one workgroup) and the rows each tile OWNS; a tile
                                             // also recomputes a halo of 7 * dil rows on each side
@@ -158,6 +159,7 @@ struct Res2ChainParams {
 bool res2_chain_supported(int W, int T, int dil);
 bool res2_half_out_supported(int W, int T, int dil);   // Res2ChainParams::y2h allowed
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream);
+hipError_t launch_res2_chain4(Res2ChainParams p, hipStream_t stream);   // res2_chain4.hip (called by launch_res2_chain)
 
 // SE FCs from the GEMM's per-tile column sums (ConvGemmParams::colsum, row tile = 64 rows):
 // mean[b][c] = (sum of the tile partials covering rows [b*T, (b+1)*T)) / T, then the two FCs.

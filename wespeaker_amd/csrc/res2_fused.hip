@@ -429,6 +429,11 @@ static hipError_t launch_res2_f16_variant(Res2ChainParams p, hipStream_t stream)
   return hipGetLastError();
 }
 
+// the four-wavefront kernel (res2_chain4.hip): fp32, w = 64, every utterance whole in one workgroup of 9 .. 13 row tiles
+static bool chain4_takes(const Res2ChainParams& p) {
+  return p.prec == 0 && p.W == 64 && p.T <= 13 * 16 && p.T > chain_cap(64, chain_mtw(64, true)) && !p.force_wave8;
+}
+
 template <int W, int MTW>
 static hipError_t launch_res2_variant(Res2ChainParams p, hipStream_t stream) {
   chain_tiling_for(chain_cap(W, MTW), p.T, p.dil, &p.tiles, &p.tile_rows);
@@ -467,6 +472,7 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
     if (p.W == 64) return small ? launch_res2_f16_variant<64, 4>(p, stream) : launch_res2_f16_variant<64, 7>(p, stream);
     return small ? launch_res2_f16_variant<128, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
   }
+  if (!small && chain4_takes(p)) return launch_res2_chain4(p, stream);
   if (p.W == 64) return small ? launch_res2_variant<64, 4>(p, stream) : launch_res2_variant<64, 7>(p, stream);
   return small ? launch_res2_variant<128, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
 }
