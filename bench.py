@@ -149,6 +149,13 @@ class StubExtractor:
         self.w = torch.randn(num_samples, embed_dim, generator=g) / num_samples ** 0.5
 
     def extract(self, fe, wav):
+        # (tests: WS_BENCH_STUB_SLOW="rank:seconds" makes ONE rank slow, to prove that `value` is priced on the
+        # max-over-ranks time and not on rank 0's own clock)
+        slow = os.environ.get("WS_BENCH_STUB_SLOW")
+        if slow:
+            r, sec = slow.split(":")
+            if int(r) == int(os.environ.get("RANK", "0")):
+                time.sleep(float(sec))
         return wav.to(torch.float32) @ self.w
 
     def set_precision(self, prec):
@@ -743,6 +750,8 @@ def main(argv=None):
             ie_s, it_s = synth.synth_trial_pairs(n_trials, n_utts, n_utts, seed=99)
 
             def scorer(emb):
+                # (tests: WS_BENCH_STUB_SCORE_SLEEP seconds inside rank 0's scoring step -- it must show in ms_per_step)
+                time.sleep(float(os.environ.get("WS_BENCH_STUB_SCORE_SLEEP", "0")))
                 u = torch.nn.functional.normalize(emb.double(), dim=1)
                 cos = (u[torch.from_numpy(ie_s).long()] * u[torch.from_numpy(it_s).long()]).sum(1)
                 return cos, cos

@@ -140,3 +140,31 @@ def test_stub_lines_are_short_and_the_detail_file_is_written(tmp_path):
         with open(det) as fp:
             full = json.load(fp)
         assert full["value"] == pytest.approx(line["value"], rel=1e-5)
+
+
+def test_eight_ranks_value_is_priced_on_the_slowest_rank_and_scoring_is_inside_the_step():
+    """What the driver's 8-GPU node will rely on, with the host stand-in on gloo at world size 8:
+    (a) `value` = all ranks' utterances / the MAX-over-ranks time -- rank 5 is made 1 s slower per extract call, rank 0
+    (which prints the line) is not, and ms_per_step must carry those seconds; (b) rank 0's scoring of the VoxCeleb1-O
+    trial list lies INSIDE the timed region of `--workload vox1o` -- a 2-s sleep inside the scoring step shows in
+    ms_per_step; (c) the compact line of an N > 1 run keeps `collective{backend, ranks, library_version}` and the
+    shard table."""
+    args = ("--gpus", "8", "--workload", "vox1o", "--batch", "512", "--steps", "1", "--warmup", "1", "--seconds", "0.1")
+    base = run_bench(*args)
+    slow = run_bench(*args, env_extra={"WS_BENCH_STUB_SLOW": "5:1.0"})
+    # one pass of a rank = 2 batches of 305 utterances -> two extract calls -> >= 2 s on rank 5 only
+    assert slow["ms_per_step"] >= 2000.0 and slow["ms_per_step"] > base["ms_per_step"] + 1000.0, \
+        (slow["ms_per_step"], base["ms_per_step"])
+    assert slow["value"] == pytest.approx(4874 / (slow["ms_per_step"] * 1e-3), rel=1e-3)
+    scored = run_bench(*args, env_extra={"WS_BENCH_STUB_SCORE_SLEEP": "2.0"})
+    assert scored["ms_per_step"] >= 2000.0 and scored["set"]["trials_scored_on_rank0"] == 37611
+    for d in (base, slow, scored):
+        assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+        assert d["collective"] == {"backend": "gloo", "ranks": 8, "library_version": None}
+        assert len(d["set"]["shards"]) == 8 and d["set"]["shards"][-1] == [4270, 4874]
+    # weak-scaling default mode: the same pricing
+    w = run_bench("--gpus", "8", "--batch", "8", "--steps", "2", "--warmup", "1", "--windows", "1",
+                  env_extra={"WS_BENCH_STUB_SLOW": "3:0.5"})
+    assert w["n_gpus"] == 8 and w["scaling"] == "weak" and w["config"]["global_batch"] == 64
+    assert w["ms_per_step"] >= 500.0 and w["value"] == pytest.approx(64 / (w["ms_per_step"] * 1e-3), rel=1e-3)
+    assert w["collective"]["ranks"] == 8

@@ -678,9 +678,12 @@ int ws_debug_row_gather(const double* table, int row_len, const int32_t* idx, in
 }
 
 int ws_debug_clock_probe(uint64_t* out, int samples, int64_t period_ticks, ws_stream stream) {
-  // bounded: at most 4096 samples and 2^24 ticks (0.17 s at 100 MHz) between two of them
-  if (!out || samples <= 0 || samples > 4096 || period_ticks <= 0 || period_ticks > (1LL << 24)) {
-    set_error("ws_debug_clock_probe: invalid argument (1..4096 samples, period 1..2^24 ticks)");
+  // bounded: at most 4096 samples, 2^24 ticks between two of them, and 2^30 ticks (10.7 s at the counter's 100 MHz)
+  // in total -- the probe is one spinning wavefront that nothing can cancel and that hipDeviceSynchronize and
+  // ws_engine_reserve wait for (the two bounds alone allowed eleven minutes)
+  if (!out || samples <= 0 || samples > 4096 || period_ticks <= 0 || period_ticks > (1LL << 24) ||
+      (int64_t)samples * period_ticks > (1LL << 30)) {
+    set_error("ws_debug_clock_probe: invalid argument (1..4096 samples, period 1..2^24 ticks, samples * period <= 2^30)");
     return WS_ERR_INVALID_ARG;
   }
   WS_HIP_CHECK(launch_clock_probe(reinterpret_cast<unsigned long long*>(out), samples,

@@ -571,13 +571,7 @@ unsigned long long* cam_trace_buffer_address() {
 #endif
 
 bool cam_dense_fused_applies(int Tp, int cin, int dil) {
-  static const int off = [] { const char* e = getenv("WS_CAM_FUSED"); return e && atoi(e) == 0 ? 1 : 0; }();
-  return !off && Tp >= 1 && Tp <= 128 && cin >= CD_BK && cin % CD_BK == 0 && dil >= 1 && dil <= CD_HALO;
-}
-
-bool cam_dense_block_enabled() {
-  static const int off = [] { const char* e = getenv("WS_CAM_BLOCK"); return e && atoi(e) == 0 ? 1 : 0; }();
-  return !off;
+  return Tp >= 1 && Tp <= 128 && cin >= CD_BK && cin % CD_BK == 0 && dil >= 1 && dil <= CD_HALO;
 }
 
 hipError_t launch_cam_dense_block(const CamDenseBlockParams& bp, int B, hipStream_t stream) {

@@ -237,9 +237,10 @@ struct CamppModel : ModelBase {
     int ch = 128;
     for (int k = 0; k < 3; ++k) {
       // fp32, utterances of <= 128 trunk frames: the whole dense block is one launch, one workgroup per utterance
-      // (cam_dense_block_kernel); WS_CAM_BLOCK=0: one launch per layer
+      // (cam_dense_block_kernel); a block the launch cannot take (more layers than its argument block holds, an
+      // unaligned trunk buffer) falls back to one launch per layer below
       bool block_done = false;
-      if (gemm_precision == 0 && cam_dense_block_enabled() && (int)layers[k].size() <= WS_CAM_MAX_LAYERS &&
+      if (gemm_precision == 0 && (int)layers[k].size() <= WS_CAM_MAX_LAYERS &&
           !layers[k].empty() && (reinterpret_cast<uintptr_t>(X) & 127) == 0 && (ldx & 31) == 0) {
         bool ok = true;
         for (size_t j = 0; j < layers[k].size(); ++j)

@@ -29,65 +29,6 @@ __device__ __forceinline__ float wave_sum32(float v) {
 // The tensor it writes (B*F*T*32 values) is 40x the size of what it reads: store-bound.
 constexpr int ST_FH = 8, ST_TW = 32;
 
-template <bool OUT16>
-__global__ __launch_bounds__(256) void stem_conv3x3_tile_kernel(const float* __restrict__ feats, int T,
-                                                                int F, const float* __restrict__ w,
-                                                                const float* __restrict__ bias,
-                                                                float* __restrict__ out,
-                                                                uint16_t* __restrict__ out16,
-                                                                const int* __restrict__ lens) {
-  __shared__ float in_s[ST_FH + 2][ST_TW + 2 + 1];
-  __shared__ __attribute__((aligned(16))) float w_s[32 * 12];     // [c][12]: 9 taps + bias + pad
-  const int t0 = blockIdx.x * ST_TW, f0 = blockIdx.y * ST_FH, b = blockIdx.z;
-  const int tid = threadIdx.x;
-  const float* img = feats + (long long)b * T * F;
-  for (int i = tid; i < (ST_FH + 2) * (ST_TW + 2); i += 256) {
-    const int tx = i / (ST_FH + 2), fy = i - tx * (ST_FH + 2);   // f fastest: contiguous in feats
-    const int tt = t0 + tx - 1, ff = f0 + fy - 1;
-    in_s[fy][tx] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? img[(long long)tt * F + ff] : 0.f;
-  }
-  for (int i = tid; i < 32 * 12; i += 256) {
-    const int c = i / 12, k = i - c * 12;
-    w_s[i] = k < 9 ? w[c * 9 + k] : (k == 9 ? bias[c] : 0.f);
-  }
-  __syncthreads();
-  const int tx = tid & (ST_TW - 1), fy = tid / ST_TW;
-  const int t = t0 + tx, f = f0 + fy;
-  float in[9];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) in[dy * 3 + dx] = in_s[fy + dy][tx + dx];
-  if (t >= T || f >= F) return;
-  const long long pix = ((long long)b * F + f) * T + t;
-  typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
-  const bool padded = lens && t >= lens[b];     // ragged batch: columns beyond the utterance stay zero
-#pragma unroll
-  for (int c0 = 0; c0 < 32; c0 += 8) {
-    float r[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12]);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12 + 4]);
-      const f32x4 wc = *reinterpret_cast<const f32x4*>(&w_s[(c0 + q) * 12 + 8]);
-      float sacc = wc[1];                          // bias
-      sacc += wa[0] * in[0] + wa[1] * in[1] + wa[2] * in[2] + wa[3] * in[3];
-      sacc += wb[0] * in[4] + wb[1] * in[5] + wb[2] * in[6] + wb[3] * in[7];
-      sacc += wc[0] * in[8];
-      r[q] = padded ? 0.f : fmaxf(sacc, 0.f);
-    }
-    if (OUT16) {
-      f16x8c hv;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) hv[q] = (_Float16)r[q];
-      *reinterpret_cast<f16x8c*>(out16 + pix * 32 + c0) = hv;
-    } else {
-      *reinterpret_cast<f32x4*>(out + pix * 32 + c0) = (f32x4){r[0], r[1], r[2], r[3]};
-      *reinterpret_cast<f32x4*>(out + pix * 32 + c0 + 4) = (f32x4){r[4], r[5], r[6], r[7]};
-    }
-  }
-}
-
 // Round 5: the same tile with the roles turned for the STORES.  Above, a store instruction of a wavefront writes 16 B
 // of 64 different pixels (64 cache lines, a quarter of each: the L2 has to merge eight instructions per line) and the
 // kernel runs at 3.1 TB/s.  Here a thread owns 4 channels (8 threads per pixel) of the 8 pixels of one tile COLUMN:
@@ -161,21 +102,10 @@ hipError_t launch_stem_conv3x3(const float* feats, int B, int T, int F, const fl
                                uint16_t* out16, const int* lens) {
   if (C != 32 || B <= 0) return C != 32 ? hipErrorInvalidValue : hipSuccess;
   dim3 grid((T + ST_TW - 1) / ST_TW, (F + ST_FH - 1) / ST_FH, B);
-  static const bool v1 = getenv("WS_STEM_V1") && atoi(getenv("WS_STEM_V1")) != 0;    // (A/B: the pixel-per-thread form)
-  if (!v1) {
-    if (out16)
-      hipLaunchKernelGGL(stem_conv3x3_rows_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16, lens);
-    else
-      hipLaunchKernelGGL(stem_conv3x3_rows_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16,
-                         lens);
-    return hipGetLastError();
-  }
   if (out16)
-    hipLaunchKernelGGL(stem_conv3x3_tile_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
-                       out16, lens);
+    hipLaunchKernelGGL(stem_conv3x3_rows_kernel<true>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16, lens);
   else
-    hipLaunchKernelGGL(stem_conv3x3_tile_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out,
-                       out16, lens);
+    hipLaunchKernelGGL(stem_conv3x3_rows_kernel<false>, grid, dim3(256), 0, stream, feats, T, F, w, b, out, out16, lens);
   return hipGetLastError();
 }
 

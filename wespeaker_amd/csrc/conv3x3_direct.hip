@@ -372,8 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_f32_kernel(const ConvGe
 // twice, i.e. half of the 144 weight registers moved to LDS fragments.)
 
 bool conv3x3_direct_f32_supported(const ConvGemmParams& p) {
-  static const int off = [] { const char* e = getenv("WS_DIRECT3X3_F32"); return e && atoi(e) == 0 ? 1 : 0; }();
-  return !off && p.prec == 0 && p.A && p.D && !p.A16 && !p.D16 && !p.A2 && !p.pre_scale && p.Cin == 32 && p.N == 32 &&
+  return p.prec == 0 && p.A && p.D && !p.A16 && !p.D16 && !p.A2 && !p.pre_scale && p.Cin == 32 && p.N == 32 &&
          p.K == 288 && p.kh == 3 && p.kw == 3 && p.dil_h == 1 && p.dil_w == 1 && p.pad_h == 1 && p.pad_w == 1 &&
          p.lda == 32 && p.a_off == 0 && (p.ldd & 3) == 0 && (p.d_off & 3) == 0 && p.ldw >= p.K &&
          // stride (1,1), and CAM++'s frequency-only stride (2,1) (campplus.py:245-330: three FCM convolutions; the

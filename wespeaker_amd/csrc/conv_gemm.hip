@@ -1864,8 +1864,8 @@ static hipError_t launch_mode(const ConvGemmParams& p, int mode, hipStream_t str
 
 // tile-shape switch for the big f16 GEMMs (env WS_BIG_TILES at first use; tools/gemm_probe flips it)
 int g_ws_big_tiles = -1;
-int g_ws_big_conv = -1;       // the same for the convolution form (env WS_BIG_CONV)
-int g_ws_epi16 = -1;          // binary16 one-phase epilogue of the 256x256 kernel (env WS_EPI16)
+int g_ws_big_conv = -1;       // the same for the convolution form (tools/gemm_probe's A/B)
+int g_ws_epi16 = -1;          // binary16 one-phase epilogue of the 256x256 kernel (tools/gemm_probe's A/B)
 
 template <int PREC>
 static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
@@ -1909,8 +1909,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // them -- then the fp32 tensor may not even exist, so every tile size must take this route)
   const bool fast16 = PREC == 2 && mode == 3 && p.splitk <= 1 && p.K % FBK == 0 && p.N > 64 &&
                       (!p.A16 || (p.lda16 & 7) == 0) && (p.a_off & 7) == 0 && (p.lda & 7) == 0;
-  static int dma = -1;
-  if (dma < 0) { const char* ev = getenv("WS_DMA"); dma = ev ? atoi(ev) : 1; }
+  constexpr int dma = 1;
   // (the DMA kernel addresses its operands with 32-bit element offsets)
   const bool use_dma = fast16 && p.A16 && dma && (long long)p.M * p.lda16 < (1LL << 31) &&
                        (long long)p.N * p.ldw < (1LL << 31);
@@ -1931,7 +1930,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
     // 256-wide layers whose K-tiles lie inside one filter tap: whole rounds on the phase-staggered 256x256
     // kernel (ResNet stage 4 / the 256-plane bottlenecks), the rest re-enters with m_begin set
     int& bigc = g_ws_big_conv;
-    if (bigc < 0) { const char* ev = getenv("WS_BIG_CONV"); bigc = ev ? atoi(ev) : 1; }
+    if (bigc < 0) bigc = 1;                                   // (tools/gemm_probe sets it to 0 for its A/B)
     if (bigc && p.N % 256 == 0 && p.Cin % 64 == 0 && p.K % 64 == 0 && !p.bias_img && !p.residual &&
         !p.seg_scale && !p.colsum && !p.D2) {
       const long long cus = slots / 2, tiles_n = p.N / 256, tiles_m = (rows + 255) / 256;
@@ -1973,8 +1972,8 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
   // -17 % at N = K = 512 (one workgroup per CU quantises badly); inside the model, where the wide
   // layer also emits column sums and a binary16 copy through the quadrant epilogue, -3 % end to end.
   if (big < 0) { const char* ev = getenv("WS_BIG_TILES"); big = ev ? atoi(ev) : 3; }
-  if (g_ws_epi16 < 0) { const char* ev = getenv("WS_EPI16"); g_ws_epi16 = ev ? atoi(ev) : 1; }
-  // D16-only layers finish through the binary16 one-phase epilogue (WS_EPI16=0: the fp32 two-phase one)
+  if (g_ws_epi16 < 0) g_ws_epi16 = 1;                         // (tools/gemm_probe sets it to 0 for its A/B)
+  // D16-only layers finish through the binary16 one-phase epilogue (g_ws_epi16 = 0: the fp32 two-phase one)
   const bool epi16_ok = g_ws_epi16 && big >= 2 && p.D16 && !p.D && !p.D2 && p.act != ACT_TANH && (p.ldd16 & 7) == 0 &&
                         (p.d_off & 7) == 0 && (!p.colsum || p.Hout * p.Wout >= 64);
   // (the row mask of ragged batches lives in that binary16 epilogue only -- the fp32 quadrant epilogue has no row
@@ -2031,9 +2030,7 @@ static hipError_t launch_prec(const ConvGemmParams& p, hipStream_t stream) {
       }
     }
   }
-  static int dual = -1;
-  if (dual < 0) { const char* ev = getenv("WS_DUAL"); dual = ev ? atoi(ev) : 1; }
-  if (peel && dual && !use_dma && !fast16 && (mode == 0 || mode == 3)) {
+  if (peel && !use_dma && !fast16 && (mode == 0 || mode == 3)) {
     // both tile classes in one grid (conv_gemm_dual_kernel)
     return mode == 3 ? launch_dual<false, false, true, PREC>(p, main.M, stream)
                      : launch_dual<false, false, false, PREC>(p, main.M, stream);
@@ -2075,9 +2072,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
   }
   if (p.prec == 2) {
     if (!p.Wh) return hipErrorInvalidValue;
-    static int direct = -1;
-    if (direct < 0) { const char* ev = getenv("WS_DIRECT3X3"); direct = ev ? atoi(ev) : 1; }
-    if (direct && conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
+    if (conv3x3_direct_supported(p)) return launch_conv3x3_direct(p, stream);
     return launch_prec<2>(p, stream);
   }
   if (p.colsumsq && (!p.colsum || !p.D)) return hipErrorInvalidValue;

@@ -152,8 +152,7 @@ struct EcapaModel : ModelBase {
       ConvGemmParams p0 = conv1d(layer1, feats, feat_dim, 0, out1, C, 0, B, T, 1, ACT_RELU);
       if (f16io) { p0.D16 = out1_16; p0.ldd16 = C; }
       if (allf16) p0.D = nullptr;
-      static const bool no_im2col = getenv("WS_NO_IM2COL") != nullptr;
-      if (f16io && !no_im2col && layer1.ldw <= 512 && feat_dim % 4 == 0) {
+      if (f16io && layer1.ldw <= 512 && feat_dim % 4 == 0) {
         // k5 conv as a plain GEMM over a binary16 im2col image (K = ldw = taps*F rounded up to 64)
         WS_LAUNCH(other(2.0 * B * (double)T * layer1.ldw, st, [&] {
           return launch_im2col_f16(feats, B, T, feat_dim, 5, 2, col16, layer1.ldw, st);
@@ -165,7 +164,7 @@ struct EcapaModel : ModelBase {
       // columns: 13 K-tiles for 5 x 80) lives in the not-yet-used h buffer and the layer becomes a plain 1x1 GEMM of
       // the persistent kernel (the implicit-GEMM form stays for ragged and small batches: same k order, same bits)
       const int kcol = (5 * feat_dim + 31) & ~31;
-      if (gemm_precision == 0 && !no_im2col && !L0 && feat_dim % 4 == 0 && kcol <= layer1.ldw && kcol <= 1536 &&
+      if (gemm_precision == 0 && !L0 && feat_dim % 4 == 0 && kcol <= layer1.ldw && kcol <= 1536 &&
           (long long)B * T >= 16384) {
         WS_LAUNCH(other(4.0 * B * (double)T * (kcol + feat_dim), st, [&] {
           return launch_im2col_f32(feats, B, T, feat_dim, 5, 2, h, kcol, st);
@@ -220,9 +219,8 @@ struct EcapaModel : ModelBase {
       if (allf16) { p3.D = nullptr; p3.D16 = y3_16; p3.ldd16 = C; }
       p3.row_len = L0;
       // fp32 activations, T >= 64: the SE FCs, the scale and the block residual are ONE launch (a workgroup per
-      // utterance; WS_SE_FUSED=0: the two launches, same bits)
-      static const bool se_fused_off = getenv("WS_SE_FUSED") && atoi(getenv("WS_SE_FUSED")) == 0;
-      if (T >= 64 && !allf16 && !se_fused_off && se_fc_scale_residual_supported(T, C, 128)) {
+      // utterance; the two-launch form below gives the same bits)
+      if (T >= 64 && !allf16 && se_fc_scale_residual_supported(T, C, 128)) {
         p3.colsum = colsum;
         WS_LAUNCH(gemm(p3, st));
         WS_LAUNCH(other(3 * mc, st, [&] {
@@ -258,10 +256,8 @@ struct EcapaModel : ModelBase {
     // cat -> Conv1d(3C -> 1536, k1) -> ReLU
     // (GLOB, T >= 64: the epilogue also leaves per-tile column sums of h for the context statistics)
     const bool stats_from_colsum = glob && T >= 64;
-    static const bool no_sums = getenv("WS_NO_STD_FROM_SUMS") != nullptr;
-    const bool stats_from_sums = stats_from_colsum && gemm_precision == 0 && !L0 && !no_sums;
-    static const bool no_fuse = getenv("WS_NO_POOL_FUSE") != nullptr;
-    const bool h_half = allf16 && !no_fuse;
+    const bool stats_from_sums = stats_from_colsum && gemm_precision == 0 && !L0;
+    const bool h_half = allf16;
     {
       ConvGemmParams pc = conv1d(catconv, cat, 3 * C, 0, h, 1536, 0, B, T, 1, ACT_RELU);
       if (stats_from_colsum) pc.colsum = colsum;
@@ -293,7 +289,7 @@ struct EcapaModel : ModelBase {
       a1.bias_img = bias_img;
     }
     a1.row_len = L0;
-    if (gemm_precision == 0 && !no_fuse && astp_fused_supported(T, 1536, 128) && astp_fused_pays(B, T)) {
+    if (gemm_precision == 0 && astp_fused_supported(T, 1536, 128) && astp_fused_pays(B, T)) {
       // linear1 -> tanh -> linear2 -> softmax over time -> weighted mean / std: one workgroup per utterance,
       // neither the bottleneck activations nor the logits leave the chip (astp_fused.hip)
       if (prof.enabled) {
@@ -311,7 +307,7 @@ struct EcapaModel : ModelBase {
       WS_LAUNCH(fe);
     } else {
     WS_LAUNCH(gemm(a1, st));
-    if (T >= 64 && !no_fuse) {
+    if (T >= 64) {
       // logits never leave the chip: the GEMM epilogue reduces them to online-softmax partials
       ConvGemmParams l2 = conv1d(pool2, att, 128, 0, nullptr, 1536, 0, B, T, 1, ACT_NONE);
       l2.pool_h = h; l2.ldh = 1536; l2.pool_partial = e;      // e doubles as the partials buffer

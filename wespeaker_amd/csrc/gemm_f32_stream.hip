@@ -762,21 +762,18 @@ StreamPlan plan(const ConvGemmParams& p, int cus) {
 }
 }  // namespace
 
-// env WS_STREAM_CONV=0: the 3x3 layers stay on the implicit-GEMM tile kernels; WS_STREAM64=0: the 64-channel layers
-int g_ws_stream_conv = -1;
-int g_ws_stream64 = -1;
+// (probe hooks, tools/conv_stream_probe: 0 keeps the 3x3 layers / the 64-channel layers on the implicit-GEMM tile kernels)
+int g_ws_stream_conv = 1;
+int g_ws_stream64 = 1;
 
 // a 3x3 / stride 1 / pad 1 / dilation 1 convolution over channels-last images whose K-tiles lie inside one tap
 bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
-  if (g_ws_stream_conv < 0) {
-    const char* ev = getenv("WS_STREAM_CONV");
-    g_ws_stream_conv = ev ? atoi(ev) : 1;
-  }
-  return g_ws_stream_conv > 0 && p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 3 && p.kw == 3 &&
+  return g_ws_stream_conv != 0 && p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 3 && p.kw == 3 &&
          p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 1 && p.pad_w == 1 && p.dil_h == 1 && p.dil_w == 1 &&
          p.Hin == p.Hout && p.Win == p.Wout && p.Cin % S_BK == 0 && p.K == 9 * p.Cin && p.D && !p.D16 && !p.D2_16 &&
          !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
          (p.act == ACT_NONE || p.act == ACT_RELU) && p.a_zero_off > 0 &&
+         p.Cin <= 512 &&     // (the zero pad behind an activation buffer is 512 floats: resnet_model.hip reserve())
          (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32) &&
          p.a_zero_off + ((long long)p.Win + 2) * p.lda * 4 + 4LL * p.Cin + 16 < (1LL << 32);
 }
@@ -789,10 +786,6 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
     g_ws_stream = ev ? atoi(ev) : 4;
   }
   if (g_ws_stream <= 0) return 0;
-  if (g_ws_stream64 < 0) {
-    const char* ev = getenv("WS_STREAM64");
-    g_ws_stream64 = ev ? atoi(ev) : 1;
-  }
   const bool conv3 = gemm_f32_stream_is_conv3(p);
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&

@@ -126,7 +126,7 @@ void dispatch_log_clear();
 // the caller sends the remaining rows through the tile kernels with m_begin advanced.
 int gemm_f32_stream_rows(const ConvGemmParams& p, int cus);
 // ... and of the 3x3 / stride 1 / pad 1 convolutions whose K-tiles lie inside one filter tap (Cin % 32 == 0,
-// N % 128 == 0): the same kernel with the A pieces addressed per tap (CONV form; env WS_STREAM_CONV=0 turns it off)
+// N % 128 == 0): the same kernel with the A pieces addressed per tap (CONV form)
 bool gemm_f32_stream_is_conv3(const ConvGemmParams& p);
 hipError_t launch_gemm_f32_stream(const ConvGemmParams& p, int rows, int cus, hipStream_t stream);
 
@@ -253,7 +253,7 @@ struct CamDenseParams {
   const float *cw1, *cb1, *cw2, *cb2;                     // cam_layer.linear1 [64][128], linear2 [32][64]
   int dil;
 };
-bool cam_dense_fused_applies(int Tp, int cin, int dil);  // (WS_CAM_FUSED=0 switches it off)
+bool cam_dense_fused_applies(int Tp, int cin, int dil);
 hipError_t launch_cam_dense_layer(const CamDenseParams& p, int B, hipStream_t stream);
 // A whole CAMDenseTDNNBlock (campplus.py:173-205) as ONE launch: layer l reads x[:, 0 : cin0 + 32 l) and appends its 32
 // channels, and nothing but the utterance's own rows is read or written -- the workgroup that owns the utterance runs
@@ -268,7 +268,6 @@ struct CamDenseBlockParams {
   int n_layers;
   CamDenseLayerW layers[WS_CAM_MAX_LAYERS];
 };
-bool cam_dense_block_enabled();                           // (WS_CAM_BLOCK=0: one launch per layer)
 hipError_t launch_cam_dense_block(const CamDenseBlockParams& bp, int B, hipStream_t stream);
 
 // ---- frontend
@@ -357,7 +356,7 @@ hipError_t launch_row_gather_probe(const double* T, int K, const int32_t* idx, i
 // -------- direct 3x3, 32 -> 32 channel convolution on binary16 maps (conv3x3_direct.hip)
 bool conv3x3_direct_supported(const ConvGemmParams& p);
 hipError_t launch_conv3x3_direct(const ConvGemmParams& p, hipStream_t stream);
-// the 32 -> 32 channel layers on the fp32 back-end (exact fp32 MFMA, weights in registers); env WS_DIRECT3X3_F32=0: off
+// the 32 -> 32 channel layers on the fp32 back-end (exact fp32 MFMA, weights in registers)
 bool conv3x3_direct_f32_supported(const ConvGemmParams& p);
 hipError_t launch_conv3x3_direct_f32(const ConvGemmParams& p, hipStream_t stream);
 

@@ -202,7 +202,13 @@ class Speaker:
         `pcm[0, begin_idx:end_idx]`); [begin_ms, end_ms) its position in the recording (end_ms None = begin_ms + its
         duration): the reference lays the windows out from (end_ms - begin_ms) // frame_shift, not from the frame
         count, and names them "{begin_ms:08d}-{end_ms:08d}-{first:08d}-{last:08d}".  (The VAD that produces the segments
-        and the clustering behind them stay out of scope: SURVEY.md s.2.)"""
+        and the clustering behind them stay out of scope: SURVEY.md s.2.)
+
+        One deviation (stated in INTEGRATION.md too): a segment whose `sample_rate` differs from `resample_rate` is
+        resampled first, like `extract_embedding_from_pcm` does (cli/speaker.py:157-160); the reference's `diarize`
+        computes its features at the file's own rate (cli/speaker.py:232-237).  For 16 kHz input -- every recipe
+        of the reference -- the two are the same; the window NAMES are the same at any rate (they come from the
+        millisecond time stamps)."""
         pcm = pcm.reshape(-1)
         if sample_rate != self.resample_rate:
             from .audio import resample
