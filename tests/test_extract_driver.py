@@ -318,3 +318,55 @@ def test_file_fast_path_equals_the_general_path(tmp_path):
     assert wx.extract_files(kp[0], kp[1], ex, resample_rate=8000) is None                  # other sample rate
     k3, e3 = wx.extract_list("scp", lines_scp, ex, batch_size=16, chunk_len=30000, seed=1)  # ... general path: tiled
     assert len(k3) == 21 and e3.shape == (21, 6) and (e3[:, 4] == 30000).all()
+
+
+def test_plan_batches_and_path_table(tmp_path):
+    """The file path's batch plan (longest first, consecutive files of the sorted list, cut at max_batch rows and at
+    the length tolerance) and the one-pass path table the C++ loaders read names from."""
+    rng = np.random.RandomState(0)
+    for tol, draw in ((0.0, lambda n: rng.choice([32000, 16000, 24000], size=n)),
+                      (0.12, lambda n: rng.randint(24000, 40001, size=n))):
+        for n in (1, 5, 300, 4096):
+            c = draw(n).astype(np.int32)
+            bs = wx.plan_batches(c, 256, tol)
+            assert sorted(np.concatenate(bs).tolist()) == list(range(n))            # every file once
+            tops = [int(c[b].max()) for b in bs]
+            assert tops == sorted(tops, reverse=True)                               # longest first
+            for b in bs:
+                assert 1 <= len(b) <= 256
+                assert c[b].min() * (1 + tol) >= c[b].max() if tol else c[b].min() == c[b].max()
+    assert len(wx.plan_batches(np.full(4096, 32000, np.int32), 256, 0.12)) == 16
+    # 1.5 .. 2.5 s lengths: 16 full batches (the geometric classes of round 5 made 20, five of them part-filled)
+    assert [len(b) for b in wx.plan_batches(rng.randint(24000, 40001, size=4096).astype(np.int32), 256, 0.12)] == [256] * 16
+    paths = []
+    for i, nsamp in enumerate((32000, 1234, 16000)):
+        p = str(tmp_path / ("f%d é.wav" % i))                                  # (a non-ASCII name too)
+        synth.write_wav(p, synth.synth_wav(i, nsamp))
+        paths.append(p)
+    tab = wx.PathTable(paths)
+    ns, sr = wx.probe_wavs(tab, 2)
+    assert ns.tolist() == [32000, 1234, 16000] and sr.tolist() == [16000] * 3
+    dst = np.zeros((2, 16000), np.int16)
+    wx.load_wav_rows(tab, dst, np.array([16000, 1234], np.int32), None, 2, idx=np.array([2, 1]))
+    assert np.array_equal(dst[0], synth.synth_wav(2, 16000)) and np.array_equal(dst[1, :1234], synth.synth_wav(1, 1234))
+    assert wx.decode_threads(3) == 6 and 8 <= wx.decode_threads(0) <= 32
+
+
+def test_bulk_ark_writer_equals_the_record_writer(tmp_path):
+    """kaldi_io.write_vectors (one pass over the table) writes VectorWriter's bytes: float32 / float64, keys of equal and
+    of different lengths, the scp offsets, an empty table."""
+    from wespeaker_amd import kaldi_io
+    for keys in (["utt%05d" % i for i in range(300)], ["u%d" % i for i in range(300)]):
+        for dt in (np.float32, np.float64):
+            m = np.random.RandomState(1).randn(300, 19).astype(dt)
+            a, b = str(tmp_path / "a.ark"), str(tmp_path / "b.ark")
+            with kaldi_io.VectorWriter(a, a[:-3] + "scp") as w:
+                for k, e in zip(keys, m):
+                    w(k, e)
+            kaldi_io.write_vectors(keys, m, b, b[:-3] + "scp")
+            assert open(a, "rb").read() == open(b, "rb").read()
+            assert open(a[:-3] + "scp").read().replace("a.ark", "X") == open(b[:-3] + "scp").read().replace("b.ark", "X")
+            back = kaldi_io.read_vec_scp(b[:-3] + "scp")
+            assert np.array_equal(back[keys[7]], m[7].astype(np.float32) if dt is np.float32 else m[7])
+    kaldi_io.write_vectors([], np.zeros((0, 4), np.float32), str(tmp_path / "e.ark"), str(tmp_path / "e.scp"))
+    assert os.path.getsize(str(tmp_path / "e.ark")) == 0

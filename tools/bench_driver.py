@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--model", default="ECAPA_TDNN_GLOB_c512")
-    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=0, help="0 = scaled with the host (extract.decode_threads)")
     ap.add_argument("--max_batch", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=7)
     ap.add_argument("--python_loader", action="store_true", help="the Python thread-pool decode path instead of "
@@ -43,7 +43,7 @@ def main():
         fe = Frontend(16000, 80, device=dev)
         model = NativeSpeakerModel(args.model, synth.synth_state_dict(args.model, 80, E, seed=42), feat_dim=80,
                                    embed_dim=E, device=dev, max_batch=args.max_batch, max_frames=250)
-        rec = {"model": args.model, "files": args.n, "decode_threads": args.workers, "max_batch": args.max_batch,
+        rec = {"model": args.model, "files": args.n, "decode_threads": wx.decode_threads(args.workers), "max_batch": args.max_batch,
                "loader": "python threads" if args.python_loader else "native (ws_wav_load_rows)",
                "host_cores": os.cpu_count()}
         from wespeaker_amd import SpeakerModelLanes

@@ -29,7 +29,7 @@ int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
   double* out; unsigned long long* clk;
-  for (int wpc = 1; wpc <= 2; ++wpc) {                     // workgroups of 4 wavefronts per CU: 1 and 2 wavefronts per SIMD
+  for (int wpc = 1; wpc <= 8; wpc *= 2) {                     // workgroups of 4 wavefronts per CU: 1, 2, 4, 8 wavefronts per SIMD
     const int blocks = cus * wpc, iters = 200000;
     CK(hipMalloc(&out, (size_t)blocks * 256 * 8)); CK(hipMalloc(&clk, 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -30,6 +30,7 @@ unseeded global `random` in DataLoader workers, i.e. is not reproducible; the cr
 """
 import json
 import os
+import time
 import subprocess
 import tarfile
 import zlib
@@ -41,7 +42,7 @@ import yaml
 
 from . import _lib, parallel
 from .audio import load_pcm16_fast
-from .kaldi_io import VectorWriter
+from .kaldi_io import VectorWriter, write_vectors
 
 AUDIO_SUFFIXES = ("flac", "mp3", "m4a", "ogg", "opus", "wav", "wma")     # dataset/processor.py:33
 
@@ -114,33 +115,57 @@ def random_chunk(pcm, key, chunk_len, seed):
 
 
 # --------------------------------------------------------------------------- native wave-file loader
-def _c_paths(paths):
-    import ctypes
-    arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-    return arr
+class PathTable:
+    """`const char* const*` views of a list of file names for the C-ABI loaders: ONE encode pass, the NUL-terminated
+    names in one buffer, the pointers as a numpy array -- `take(idx)` is the table of any sub-list without touching a
+    Python string again (round 5 built a ctypes array of c_char_p per batch and one for the probe: 1.4 us per file
+    each time, 5 ms of an 80-ms pass over 4 096 files)."""
+
+    def __init__(self, paths):
+        import ctypes
+        enc = [os.fsencode(p) for p in paths]
+        self.n = len(enc)
+        blob = b"\0".join(enc) + b"\0"
+        self._buf = ctypes.create_string_buffer(blob, len(blob))
+        lens = np.fromiter((len(e) + 1 for e in enc), dtype=np.int64, count=self.n)
+        offs = np.concatenate(([0], np.cumsum(lens)[:-1])) if self.n else np.zeros(0, np.int64)
+        self.ptrs = (offs + ctypes.addressof(self._buf)).astype(np.uint64)
+
+    def take(self, idx):
+        """(pointer table of paths[idx] as a contiguous uint64 array, its length); keep the array alive over the call."""
+        t = np.ascontiguousarray(self.ptrs[idx])
+        return t, int(t.shape[0])
+
+
+def _path_table(paths):
+    return paths if isinstance(paths, PathTable) else PathTable(paths)
 
 
 def probe_wavs(paths, threads=16):
-    """ws_wav_probe: (num_samples int32[n] (-1 = not a PCM16 RIFF file), sample_rate int32[n]) read by C++ threads."""
-    n = len(paths)
+    """ws_wav_probe: (num_samples int32[n] (-1 = not a PCM16 RIFF file), sample_rate int32[n]) read by C++ threads.
+    paths: a list of names or a PathTable."""
+    tab = _path_table(paths)
+    n = tab.n
     ns, sr = np.empty(n, np.int32), np.empty(n, np.int32)
     if n:
-        rc = _lib.lib().ws_wav_probe(_c_paths(paths), n, int(threads), _lib.ptr(ns), _lib.ptr(sr))
+        rc = _lib.lib().ws_wav_probe(_lib.ptr(tab.ptrs), n, int(threads), _lib.ptr(ns), _lib.ptr(sr))
         if rc < 0:
             _lib.check(rc, "ws_wav_probe")
     return ns, sr
 
 
-def load_wav_rows(paths, dst, counts, starts=None, threads=16):
+def load_wav_rows(paths, dst, counts, starts=None, threads=16, idx=None):
     """ws_wav_load_rows: samples [starts[i], starts[i] + counts[i]) of file i into row i of the int16 host array /
-    tensor `dst` (n, stride), decoded by C++ threads (the call releases the GIL)."""
-    n = len(paths)
+    tensor `dst` (n, stride), decoded by C++ threads (the call releases the GIL).  paths: a list of names, or a
+    PathTable with `idx` = the rows of the table this batch holds."""
+    table = _path_table(paths)                 # (kept alive over the call: the pointers point into its buffer)
+    ptrs, n = table.take(slice(None) if idx is None else idx)
     if not n:
         return
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     st = None if starts is None else np.ascontiguousarray(starts, dtype=np.int32)
     stride = int(dst.stride(0)) if isinstance(dst, torch.Tensor) else int(dst.strides[0] // 2)
-    _lib.check(_lib.lib().ws_wav_load_rows(_c_paths(paths), n, int(threads), _lib.ptr(dst), stride,
+    _lib.check(_lib.lib().ws_wav_load_rows(_lib.ptr(ptrs), n, int(threads), _lib.ptr(dst), stride,
                                            _lib.ptr(st) if st is not None else None, _lib.ptr(counts)),
                "ws_wav_load_rows")
 
@@ -168,58 +193,91 @@ class GpuExtractor:
         self._slots = [dict(pin=None, dev=None, out=None, handle=None, free=None) for _ in range(depth)]
         self._turn = 0
         self.embed_dim = model.embed_dim
+        # where the submitting thread's time goes (seconds, cumulative): tools/driver_phases.py reads it
+        self.timing = {"wait_device_slot_s": 0.0, "submit_s": 0.0, "batches": 0, "wait_decode_s": 0.0,
+                       "wait_result_s": 0.0, "probe_plan_s": 0.0}
 
     supports_ragged = True
 
     def submit_files(self, paths, counts, starts=None, threads=16):
         """Enqueue one batch of PCM16 files: C++ threads (ws_wav_load_rows) decode samples
-        [starts[i], starts[i] + counts[i]) of file i straight into the pinned staging buffer."""
-        return self.submit(None, files=(paths, np.asarray(counts, dtype=np.int32), starts, threads))
+        [starts[i], starts[i] + counts[i]) of file i straight into a pinned staging buffer."""
+        counts = np.asarray(counts, dtype=np.int32)
+        stage = self.stage(len(paths), int(counts.max()) if len(paths) else 0, torch.int16)
+        load_wav_rows(paths, stage.view, counts, starts, threads)
+        return self.submit_staged(stage, [int(c) for c in counts])
 
-    def submit(self, utts, files=None):
+    # -- pinned staging: a ring of STAGES buffers that is independent of the device slots.  A buffer is free again as
+    # soon as its upload has left it (an event on the copy stream), not when the forward that consumed the batch has
+    # finished -- so a decode thread can fill buffer i + 2 while batch i computes and batch i + 1 uploads.
+    STAGES = 4
+
+    class _Stage:
+        __slots__ = ("pin", "view", "uploaded")
+
+        def __init__(self):
+            self.pin, self.view, self.uploaded = None, None, None
+
+    def stage(self, B, N, dtype=torch.int16):
+        """The next pinned staging buffer as a (B, N) view (blocks until its previous upload has completed).
+        Safe to call from ONE decode thread while another thread calls submit_staged."""
+        if not hasattr(self, "_stages"):
+            self._stages, self._stage_turn = [self._Stage() for _ in range(self.STAGES)], 0
+        st = self._stages[self._stage_turn % self.STAGES]
+        self._stage_turn += 1
+        if st.uploaded is not None:
+            st.uploaded.synchronize()
+            st.uploaded = None
+        nbytes = B * N * (2 if dtype == torch.int16 else 4)
+        if st.pin is None or st.pin.numel() < nbytes:
+            st.pin = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        st.view = st.pin[:nbytes].view(dtype).view(B, N)
+        return st
+
+    def submit(self, utts):
         """Enqueue one batch (a list of 1-D waveforms, or a stacked (B, N) tensor); returns a handle whose
         .result() is the (B, E) numpy array.  Different lengths -> one padded ragged batch."""
+        if isinstance(utts, torch.Tensor):
+            utts = list(utts.numpy())
+        utts = [u.numpy() if isinstance(u, torch.Tensor) else u for u in utts]
+        lens = [int(u.shape[0]) for u in utts]
+        npdt = np.int16 if all(u.dtype == np.int16 for u in utts) else np.float32
+        # (8- / 32-bit files arrive as int16-range floats)
+        stage = self.stage(len(lens), max(lens), torch.int16 if npdt is np.int16 else torch.float32)
+        pin_np = stage.view.numpy()                          # numpy row copies: ~10 us each (torch's: ~60)
+        for b, u in enumerate(utts):                         # (padding bytes are never read by the kernels)
+            pin_np[b, :lens[b]] = u
+        return self.submit_staged(stage, lens)
+
+    def submit_staged(self, stage, lens):
+        """Upload a filled staging buffer (copy stream), run the fused extract on the next lane, download the rows."""
         lane = self._turn % self.depth
         slot = self._slots[lane]
         engine = self._engines[lane]
         self._turn += 1
-        if files is not None:
-            lens = [int(c) for c in files[1]]
-            utts = None
-            npdt = np.int16
-        else:
-            if isinstance(utts, torch.Tensor):
-                utts = list(utts.numpy())
-            utts = [u.numpy() if isinstance(u, torch.Tensor) else u for u in utts]
-            lens = [int(u.shape[0]) for u in utts]
-            npdt = np.int16 if all(u.dtype == np.int16 for u in utts) else np.float32
-        B, N = len(lens), max(lens)
+        pin = stage.view
+        B, N = pin.shape
         ragged = min(lens) != N
-        dtype = torch.int16 if npdt is np.int16 else torch.float32
-        nbytes = B * N * (2 if dtype == torch.int16 else 4)   # 8- / 32-bit files arrive as int16-range floats
+        dtype = pin.dtype
+        nbytes = B * N * pin.element_size()
+        t_w = time.perf_counter()
         if slot["free"] is not None:
-            slot["free"].synchronize()                       # the forward that read this slot has finished
+            slot["free"].synchronize()                       # the forward that read this slot's DEVICE buffer has finished
+        self.timing["wait_device_slot_s"] += time.perf_counter() - t_w
         main = self._streams[lane] or torch.cuda.current_stream(self.device)
-        if slot["pin"] is None or slot["pin"].numel() < nbytes:
-            slot["pin"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        if slot["dev"] is None or slot["dev"].numel() < nbytes:
             # The device staging buffer is written by the COPY stream: it must come from that stream's
             # allocator pool.  A block taken from the main stream's pool may be memory a still-pending
             # main-stream kernel (e.g. the previous batch's embedding store) is about to write -- legal for
             # same-stream reuse, a race for the copy stream (seen as a corrupted first utterance).
             with torch.cuda.stream(self.copy_stream):
-                slot["dev"] = torch.empty(slot["pin"].numel(), dtype=torch.uint8, device=self.device)
-        pin = slot["pin"][:nbytes].view(dtype).view(B, N)
-        if files is not None:
-            load_wav_rows(files[0], pin, files[1], files[2], files[3])
-        else:
-            pin_np = pin.numpy()                             # numpy row copies: ~10 us each (torch's: ~60)
-            for b, u in enumerate(utts):                     # (padding bytes are never read by the kernels)
-                pin_np[b, :lens[b]] = u
+                slot["dev"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         dev = slot["dev"][:nbytes].view(dtype).view(B, N)
         with torch.cuda.stream(self.copy_stream):
             dev.copy_(pin, non_blocking=True)
             uploaded = torch.cuda.Event()
             uploaded.record(self.copy_stream)
+        stage.uploaded = uploaded
         main.wait_event(uploaded)
         dev.record_stream(main)
         # pinned result buffer of the slot (pin_memory() costs ~10 ms per call: never per batch).  The previous
@@ -240,6 +298,8 @@ class GpuExtractor:
             done = torch.cuda.Event()
             done.record(main)
         slot["handle"] = _Pending(out, done)
+        self.timing["submit_s"] += time.perf_counter() - t_w
+        self.timing["batches"] += 1
         return slot["handle"]
 
     def finish(self):
@@ -397,54 +457,158 @@ def extract_entries(entries, extractor, batch_size=1, whole_utt=None, chunk_len=
     return keys, emb
 
 
+def plan_batches(counts, max_batch, tolerance):
+    """Index batches over `counts` (samples per file): longest first, consecutive files of the SORTED list share a
+    batch of at most max_batch rows, cut where the shortest would fall below longest / (1 + tolerance)
+    (tolerance 0: equal lengths only).  One numpy search per batch, nothing per file."""
+    n = len(counts)
+    c64 = counts.astype(np.int64)
+    order = np.argsort(-c64, kind="stable")
+    neg = -c64[order]                                    # ascending
+    batches, b0 = [], 0
+    while b0 < n:
+        top = -int(neg[b0])
+        lim = top / (1.0 + tolerance) if tolerance > 0 else top
+        b1 = int(np.searchsorted(neg, -lim, side="right"))          # first index whose count is < lim
+        b1 = max(b0 + 1, min(b1, b0 + max_batch))
+        batches.append(order[b0:b1])
+        b0 = b1
+    return batches
+
+
 def extract_files(keys, paths, extractor, batch_size=1, whole_utt=None, chunk_len=32240, max_batch=256,
                   resample_rate=16000, threads=16, seed=0, length_tolerance=0.12):
     """The same result as extract_entries for a list of wave FILES, with no per-file Python work: C++ threads
     probe every header (ws_wav_probe), the batches are planned on the length array (numpy), and every batch is
-    decoded by C++ threads straight into the pinned staging buffer (ws_wav_load_rows) while the previous batch
-    computes.  Returns None when the list needs the general path (files that are not 16-bit PCM, another sample
-    rate, or -- in the random-crop mode -- files shorter than the crop, which are tiled there)."""
+    decoded by C++ threads straight into the pinned staging ring (ws_wav_load_rows) while earlier batches upload and
+    compute.  Returns None when the list needs the general path (files that are not 16-bit PCM, another sample
+    rate, or -- in the random-crop mode -- files shorter than the crop, which are tiled there).
+
+    Batches.  The rows come back by index, so the list may be walked in ANY order: longest first (the pinned / device
+    staging buffers and the engine workspace are then sized once), and -- with a ragged extractor -- consecutive files
+    of the SORTED list share a batch: 4 096 files of 1.5 .. 2.5 s are 16 batches whose lengths differ by 3 % each (1.6 %
+    of padding rows), where round 5's geometric 12 % length classes gave five classes with 6 % padding and a
+    part-filled last batch apiece.  A batch is still cut where the spread would pass length_tolerance.
+
+    Start-up.  Encoding, probing and planning 4 096 names costs ~7 ms during which the GPU would idle (a tenth of the
+    pass): the first 2 * max_batch files (the HEAD: ~8 ms of GPU work) are probed and planned alone and go to the GPU
+    at once; the rest of the list is encoded, probed and planned by the decode thread behind the head's batches."""
     if whole_utt is None:
         whole_utt = batch_size == 1
     n = len(paths)
     if n == 0:
         return [], np.zeros((0, extractor.embed_dim), np.float32)
-    ns, sr = probe_wavs(paths, threads)
-    if (ns <= 0).any() or (sr != resample_rate).any():
-        return None
-    starts = None
-    if whole_utt:
-        counts = ns
-    else:
-        if (ns < chunk_len).any():
-            return None
-        counts = np.full(n, chunk_len, np.int32)
-        starts = np.array([crop_start(k, int(m), chunk_len, seed) for k, m in zip(keys, ns)], dtype=np.int32)
+    t_begin = time.perf_counter()
     ragged_ok = whole_utt and getattr(extractor, "supports_ragged", False) and length_tolerance > 0
-    cls = (np.floor(np.log(np.maximum(counts, 1)) / np.log1p(length_tolerance)).astype(np.int64)
-           if ragged_ok else counts.astype(np.int64))
+    tol = length_tolerance if ragged_ok else 0.0
+    staged = hasattr(extractor, "stage") and hasattr(extractor, "submit_staged")
+    n_head = 2 * max_batch if (staged and n >= 6 * max_batch) else n
+
+    class _Unfit(Exception):
+        pass
+
+    def prepare(lo, hi):
+        """(path table, counts, starts, batches of LIST indices) of paths[lo:hi]; _Unfit when the general path is needed."""
+        table = PathTable(paths[lo:hi])
+        ns, sr = probe_wavs(table, threads)
+        if (ns <= 0).any() or (sr != resample_rate).any():
+            raise _Unfit()
+        starts = None
+        if whole_utt:
+            counts = ns
+        else:
+            if (ns < chunk_len).any():
+                raise _Unfit()
+            counts = np.full(hi - lo, chunk_len, np.int32)
+            starts = np.array([crop_start(k, int(m), chunk_len, seed) for k, m in zip(keys[lo:hi], ns)], dtype=np.int32)
+        return table, counts, starts, plan_batches(counts, max_batch, tol)
+
+    try:
+        head = prepare(0, n_head)
+    except _Unfit:
+        return None
     emb = np.zeros((n, extractor.embed_dim), np.float32)
     pending = []
+    timing = getattr(extractor, "timing", None) or {}
 
     def drain(keep):
+        t_d = time.perf_counter()
         while len(pending) > keep:
             idx, handle = pending.pop(0)
             emb[idx] = handle.result()
+        timing["wait_result_s"] = timing.get("wait_result_s", 0.0) + time.perf_counter() - t_d
 
-    order = np.argsort(cls, kind="stable")              # classes together, list order inside a class
-    bounds = np.flatnonzero(np.diff(cls[order])) + 1
-    # longest class first: the pinned / device staging buffers and the engine workspace are sized once, by the
-    # first batches, instead of being re-allocated (pin_memory: ~10 ms) every time a longer class arrives
-    for group in reversed(np.split(order, bounds)):
-        for b0 in range(0, len(group), max_batch):
-            idx = group[b0:b0 + max_batch]
-            handle = extractor.submit_files([paths[i] for i in idx], counts[idx],
-                                            None if starts is None else starts[idx], threads)
-            pending.append((idx, handle))
+    timing["probe_plan_s"] = timing.get("probe_plan_s", 0.0) + time.perf_counter() - t_begin
+    if not staged:                                       # (HostExtractor and other stand-ins: decode inside submit_files)
+        table, counts, starts, batches = head
+        for idx in batches:
+            pending.append((idx, extractor.submit_files([paths[i] for i in idx], counts[idx],
+                                                        None if starts is None else starts[idx], threads)))
             drain(keep=2)
+        drain(keep=0)
+        extractor.finish()
+        return list(keys), emb
+    # decode-ahead: ONE Python thread walks the plan and has the C++ pool (ws_wav_load_rows, GIL released) fill the
+    # staging ring, up to two batches ahead of the submitting thread
+    import queue
+    import threading
+    ready = queue.Queue(maxsize=max(1, extractor.STAGES - 2))
+    failure = []
+
+    def decode_segment(lo, seg):
+        table, counts, starts, batches = seg
+        for idx in batches:
+            c = counts[idx]
+            st = extractor.stage(len(idx), int(c.max()), torch.int16)
+            load_wav_rows(table, st.view, c, None if starts is None else starts[idx], threads, idx=idx)
+            ready.put((idx + lo, st, [int(x) for x in c]))
+
+    def decode_all():
+        try:
+            decode_segment(0, head)
+            if n_head < n:
+                decode_segment(n_head, prepare(n_head, n))
+        except BaseException as err:  # noqa: BLE001  (re-raised / acted on by the submitting thread)
+            failure.append(err)
+        finally:
+            ready.put(None)
+
+    th = threading.Thread(target=decode_all, name="ws-decode-ahead", daemon=True)
+    th.start()
+    try:
+        while True:
+            t_q = time.perf_counter()
+            item = ready.get()
+            timing["wait_decode_s"] = timing.get("wait_decode_s", 0.0) + time.perf_counter() - t_q
+            if item is None:
+                break
+            idx, st, lens = item
+            pending.append((idx, extractor.submit_staged(st, lens)))
+            drain(keep=2)
+    finally:
+        while th.is_alive():                              # (an exception on this side: let the decode thread finish)
+            try:
+                ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        th.join()
     drain(keep=0)
     extractor.finish()
+    if failure:
+        if isinstance(failure[0], _Unfit):               # a file behind the head needs the general path: start over there
+            return None
+        raise failure[0]
     return list(keys), emb
+
+
+def decode_threads(num_workers=0):
+    """C++ decode threads of the file path: 2 per requested worker (bin/extract.py's `num_workers`), or -- 0 / None,
+    the default -- scaled with the host: an eighth of its cores, between 8 and 32.  tools/probe_threads.py on the
+    256-core GPU box, 4 096 two-second files in /dev/shm: 35 / 8.4 / 6.6 / 6.6 / 24 / 89 ms with 1 / 8 / 16 / 32 /
+    64 / 128 threads -- past 32 the open() / pread() calls of one directory contend."""
+    if num_workers:
+        return max(4, 2 * int(num_workers))
+    return int(min(32, max(8, (os.cpu_count() or 8) // 8)))
 
 
 def split_path_list(data_type, lines):
@@ -474,7 +638,7 @@ def extract_list(data_type, lines, extractor, **kw):
     if kp is not None and hasattr(extractor, "submit_files"):
         fast = {k: v for k, v in kw.items() if k in ("batch_size", "whole_utt", "chunk_len", "max_batch",
                                                        "resample_rate", "seed", "length_tolerance")}
-        out = extract_files(kp[0], kp[1], extractor, threads=max(4, 2 * int(kw.get("num_workers", 8))), **fast)
+        out = extract_files(kp[0], kp[1], extractor, threads=decode_threads(kw.get("num_workers", 0)), **fast)
         if out is not None:
             return out
     return extract_entries(iter_entries(data_type, lines), extractor, **kw)
@@ -487,9 +651,12 @@ def write_ark_scp(keys, emb, embed_ark):
         os.makedirs(d, exist_ok=True)
     embed_ark = os.path.abspath(embed_ark)
     embed_scp = embed_ark[:-3] + "scp"
-    with VectorWriter(embed_ark, embed_scp) as w:
-        for k, e in zip(keys, emb):
-            w(k, e)
+    if isinstance(emb, np.ndarray) and emb.ndim == 2:
+        write_vectors(list(keys), emb, embed_ark, embed_scp)     # one pass over the whole table
+    else:
+        with VectorWriter(embed_ark, embed_scp) as w:
+            for k, e in zip(keys, emb):
+                w(k, e)
     return embed_scp
 
 
