@@ -61,9 +61,9 @@ typedef void* ws_stream;                /* hipStream_t */
 /* ------------------------------------------------------------------------------------ misc */
 /* Bumped whenever an exported signature changes (101: ws_plda_stats takes `emb_is_f64` and a void* table since
  * round 2 -- a caller built against 100 would pass shifted arguments; 104: ws_frontend_set_cmvn / ws_cmvn added, the
- * `cmn` flags now mean "apply the frontend's CMVN").  ws_version() returns the library's value:
+ * `cmn` flags now mean "apply the frontend's CMVN"; 105: ws_forward_ragged_cmvn added).  ws_version() returns the library's value:
  * compare it with the header's before calling anything else. */
-#define WS_VERSION 104
+#define WS_VERSION 105
 WS_API int ws_version(void);
 WS_API const char* ws_last_error(void);
 /* Number of fbank frames for num_samples at snip_edges=True (25 ms / 10 ms):
@@ -166,6 +166,12 @@ WS_API int ws_fbank_ragged(ws_frontend* fe, const void* wav, int wav_dtype, int 
                     ws_stream stream);   /* feats (batch, ws_num_frames(max_samples), bins); rows beyond an utterance's frames = 0 */
 WS_API int ws_forward_ragged(ws_engine* eng, const float* feats, int batch, int max_frames, const int32_t* num_frames,
                       float* emb, ws_stream stream);   /* feats (batch, max_frames, feat_dim); padding rows are ignored */
+/* ws_forward_ragged on features that are NOT normalised yet: apply_cmvn(norm_mean, norm_var) over every utterance's own
+ * frames first (dataset/dataset_utils.py:19-26), on the engine's masked copy -- the caller's tensor is left as it is.
+ * The path of `data_type: feat` lists (dataset/processor.py:171-196 parse_feat -> bin/extract.py:112-127): Kaldi
+ * feature matrices come from disk, CMVN and the forward run here. */
+WS_API int ws_forward_ragged_cmvn(ws_engine* eng, const float* feats, int batch, int max_frames,
+                           const int32_t* num_frames, int norm_mean, int norm_var, float* emb, ws_stream stream);
 WS_API int ws_extract_ragged(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                       const int32_t* num_samples, int max_samples, int64_t wav_stride, float scale,
                       int window_type, float* emb, ws_stream stream);

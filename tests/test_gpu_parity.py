@@ -2132,6 +2132,47 @@ def test_res2_chain_four_wavefront_kernel_sizes():
         assert _rel_err(got[i:i + 1], one).max() < 1e-5, i
 
 
+def test_feat_lists_of_precomputed_kaldi_features(tmp_path, golden_dir):
+    """`data_type: feat` (dataset/dataset.py:136-273, processor.parse_feat :171-196, bin/extract.py:112-139): json lines
+    {key, feat: ark:offset, spk} of RAW Kaldi fbank matrices; CMVN (test_conf cmvn / cmvn_args) and the forward on the
+    GPU.  Whole-utterance mode on utterances of different lengths == the batch-1 oracle on apply_cmvn'd features, with
+    the default CMVN and with norm_var; the random-chunk mode (batch_size > 1) crops / tiles to num_frms frames; the
+    (True, True) embeddings of the first three utterances equal the reference module's golden."""
+    import json
+    from wespeaker_amd import kaldi_io
+    from wespeaker_amd import extract as wx
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, feat_dim=80, embed_dim=192, max_batch=8, max_frames=260)
+    ex = wx.GpuExtractor(model, Frontend(16000, 80, device=model.device))
+    ns = [32000, 32000, 32000, 24000, 41000, 9000, 32000, 30000, 16160, 28000]
+    raws = [ofbank.speaker_features(synth.synth_wav(i, n), cmn=False) for i, n in enumerate(ns)]
+    ark = str(tmp_path / "feats.ark")
+    lines = []
+    with open(ark, "wb") as f:
+        for i, m in enumerate(raws):
+            lines.append(json.dumps({"key": "utt%d" % i, "feat": "%s:%d" % (ark, kaldi_io.write_mat(f, "utt%d" % i, m)),
+                                     "spk": "s%d" % (i % 3)}))
+    fwd = lambda x: oecapa.ecapa_forward(sd, x).numpy()          # noqa: E731
+    for cmvn in ((True, False), (True, True), (False, False)):
+        keys, emb = wx.extract_list("feat", lines, ex, batch_size=1, max_batch=8, cmvn=cmvn)
+        assert keys == ["utt%d" % i for i in range(len(ns))]
+        ref = _oracle_rows(fwd, [ofbank.apply_cmvn(m[None], *cmvn)[0] for m in raws])
+        assert _cos_err(emb, ref).max() < COS_TOL and _rel_err(emb, ref).max() < 5e-4, cmvn
+    g = np.load(os.path.join(golden_dir, "cmvn_ref.npz"))
+    keys, emb = wx.extract_list("feat", lines[:3], ex, batch_size=1, cmvn=(True, True))
+    assert _rel_err(emb, g["ecapa512_m1v1/emb"]).max() < 5e-4
+    # random-chunk mode: 100 frames per utterance, cropped at the seeded start (long) or tiled (the 55-frame one)
+    keys, emb = wx.extract_list("feat", lines, ex, batch_size=4, num_frms=100, seed=5, cmvn=(True, False))
+    chunks = []
+    for i, m in enumerate(raws):
+        c = wx.random_chunk(m, "utt%d" % i, 100, 5) if m.shape[0] >= 100 else np.tile(m, (100 // m.shape[0] + 1, 1))[:100]
+        chunks.append(ofbank.apply_cmvn(c[None], True, False)[0])
+    assert raws[5].shape[0] < 100 and all(c.shape == (100, 80) for c in chunks)
+    ref = _oracle_rows(fwd, chunks)
+    assert _cos_err(emb, ref).max() < COS_TOL and _rel_err(emb, ref).max() < 5e-4
+
+
 @pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 192), ("ResNet34", 256), ("CAMPPlus", 512)])
 def test_ragged_extract_from_waveforms(frontend, name, E):
     """ws_extract_ragged (wav -> fbank -> CMN -> forward on a padded batch) against the oracle run on every

@@ -356,3 +356,35 @@ def test_subsegment_mirror_matches_reference_golden():
         assert subsegment_ids(seg_id, seg_len, win, per) == names
         assert _lib.lib().ws_num_windows(seg_len, win, per) == len(names)
     assert _lib.lib().ws_num_windows(0, 150, 75) == 0 and _lib.lib().ws_num_windows(10, 0, 75) == 0
+
+
+def test_kaldi_matrix_reader_formats(tmp_path):
+    """kaldi_io.read_mat / read_mat_scp (what kaldiio.load_mat is to processor.parse_feat, dataset/processor.py:171-196):
+    binary float / double records at scp offsets, the text form, and the three compressed layouts of Kaldi's
+    compressed-matrix.h (round trip through this package's own writer: kaldiio is not in the image)."""
+    import io
+    from wespeaker_amd import kaldi_io
+    rs = np.random.RandomState(3)
+    mats = {"a": rs.randn(57, 80).astype(np.float32) * 4 + 2, "b": rs.randn(3, 23).astype(np.float32),
+            "c": rs.randn(200, 80).astype(np.float64)}
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    with open(ark, "wb") as f, open(scp, "w") as g:
+        for k, m in mats.items():
+            g.write("%s %s:%d\n" % (k, ark, kaldi_io.write_mat(f, k, m)))
+    back = kaldi_io.read_mat_scp(scp)
+    for k, m in mats.items():
+        assert back[k].dtype == np.float32 and np.array_equal(back[k], m.astype(np.float32))
+    txt = str(tmp_path / "t.txt")
+    with open(txt, "w") as f:
+        f.write(" [\n  1 2 3\n  4 5.5 -6 ]\n")
+    assert np.array_equal(kaldi_io.read_mat(txt), np.array([[1, 2, 3], [4, 5.5, -6]], np.float32))
+    m = mats["a"]
+    span = float(m.max() - m.min())
+    for fmt, tol in ((2, span / 65535.0), (3, span / 255.0), (1, span / 60.0)):
+        f = io.BytesIO()
+        off = kaldi_io.write_mat(f, "x", m, compress=fmt)
+        f.seek(off)
+        r = kaldi_io._read_matrix_at(f)
+        assert r.shape == m.shape and np.abs(r - m).max() <= tol, (fmt, np.abs(r - m).max())
+    with pytest.raises(ValueError):
+        kaldi_io._read_matrix_at(io.BytesIO(b"\0BXX 1234"))

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("WS_LIB_PATH") or os.path.join(_HERE, "lib", "libwespe
 
 _lib = None
 
-ABI_VERSION = 104      # = WS_VERSION of include/wespeaker_amd.h
+ABI_VERSION = 105      # = WS_VERSION of include/wespeaker_amd.h
 
 # name -> (restype, argtypes); also used by the ABI test to check every header symbol is exported
 SIGNATURES = {
@@ -49,6 +49,7 @@ SIGNATURES = {
     "ws_extract_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                    c_void_p, c_void_p]),
     "ws_cmn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ws_forward_ragged_cmvn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ws_cmvn": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ws_frontend_set_cmvn": (c_int, [c_void_p, c_int, c_int]),
     "ws_num_windows": (c_int, [c_int, c_int, c_int]),

@@ -453,6 +453,19 @@ int ws_forward_ragged(ws_engine* eng, const float* feats, int batch, int max_fra
   return eng->model->forward_ragged(feats, batch, max_frames, num_frames, emb, (hipStream_t)stream);
 }
 
+int ws_forward_ragged_cmvn(ws_engine* eng, const float* feats, int batch, int max_frames, const int32_t* num_frames,
+                           int norm_mean, int norm_var, float* emb, ws_stream stream) {
+  if (!eng || !feats || !emb || !num_frames || batch < 0 || max_frames <= 0) {
+    set_error("ws_forward_ragged_cmvn: invalid argument");
+    return WS_ERR_INVALID_ARG;
+  }
+  if (!eng->finalized) { set_error("ws_forward_ragged_cmvn: engine not finalized"); return WS_ERR_STATE; }
+  if (batch == 0) return WS_OK;
+  WS_HIP_CHECK(hipSetDevice(eng->device));
+  return eng->model->forward_ragged(feats, batch, max_frames, num_frames, emb, (hipStream_t)stream,
+                                    (norm_mean ? 1 : 0) | (norm_var ? 2 : 0));
+}
+
 int ws_extract_ragged(ws_engine* eng, ws_frontend* fe, const void* wav, int wav_dtype, int batch,
                       const int32_t* num_samples, int max_samples, int64_t wav_stride, float scale,
                       int window_type, float* emb, ws_stream stream) {

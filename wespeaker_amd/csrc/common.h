@@ -185,8 +185,10 @@ struct Model {
                       hipStream_t stream) = 0;
   // Ragged batch: utterance b has lens_host[b] <= frames valid rows (HOST array); the rows beyond are
   // padding (their content is ignored).
+  // cmvn_mode (bit 0 norm_mean, bit 1 norm_var; 0 = the features are already normalised): apply_cmvn over every
+  // utterance's own frames, applied to the masked copy in the workspace (the caller's tensor is not modified)
   virtual int forward_ragged(const float* feats, int batch, int frames, const int32_t* lens_host,
-                             float* emb, hipStream_t stream) = 0;
+                             float* emb, hipStream_t stream, int cmvn_mode = 0) = 0;
   // Building blocks of the fused ragged extract (c_api.hip: fbank -> CMN -> forward per chunk):
   // upload_lens validates and copies the table, returns its device address (level-major, `batch` entries
   // per time-stride level; level 0 first) or null; forward_chunk_ragged runs rows [b0, b0 + nb) whose

@@ -148,7 +148,7 @@ struct ModelBase : Model {
   int finish_forward(const float* emb, int batch, hipStream_t st) override { return range_guard(emb, batch, st); }
 
   int forward_ragged(const float* feats, int batch, int frames, const int32_t* lens_host, float* emb,
-                     hipStream_t st) override {
+                     hipStream_t st, int cmvn_mode = 0) override {
     if (int r = check_frames(frames)) return r;
     const int* dev = upload_lens(lens_host, batch, frames, st);
     if (!dev) return WS_ERR_INVALID_ARG;
@@ -160,6 +160,13 @@ struct ModelBase : Model {
       if (he != hipSuccess) {
         set_error("masked feature copy failed: %s", hipGetErrorString(he));
         return WS_ERR_HIP;
+      }
+      if (cmvn_mode) {
+        he = launch_cmn(feats_ws, nb, frames, feat_dim, st, dev + b0, cmvn_mode);
+        if (he != hipSuccess) {
+          set_error("feature CMVN failed: %s", hipGetErrorString(he));
+          return WS_ERR_HIP;
+        }
       }
       int r = forward_chunk_ragged(feats_ws, nb, frames, dev, batch, b0, emb + (size_t)b0 * embed_dim, st);
       if (r) return r;

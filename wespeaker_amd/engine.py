@@ -335,10 +335,11 @@ class NativeSpeakerModel:
                                                  _lib.current_stream_ptr(self.device)), "ws_extract")
         return emb
 
-    def embed_ragged(self, feats: torch.Tensor, num_frames) -> torch.Tensor:
+    def embed_ragged(self, feats: torch.Tensor, num_frames, cmvn=None) -> torch.Tensor:
         """(B, Tmax, F) float32 features of utterances of different lengths + their frame counts ->
         (B, E): row b equals embed(feats[b:b+1, :num_frames[b]]) (ws_forward_ragged); the content of the
-        padding rows is ignored."""
+        padding rows is ignored.  cmvn=(norm_mean, norm_var): the features are raw -- apply_cmvn over every
+        utterance's own frames first (ws_forward_ragged_cmvn; `data_type: feat` lists)."""
         if feats.dim() != 3 or feats.shape[2] != self.feat_dim:
             raise ValueError("expected (B, T, %d) features, got %s" % (self.feat_dim, tuple(feats.shape)))
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
@@ -350,9 +351,15 @@ class NativeSpeakerModel:
         emb = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
         if B:
             with torch.cuda.device(self.device):
-                _lib.check(_lib.lib().ws_forward_ragged(self._h, _lib.ptr(feats), B, T, _lib.ptr(lens),
-                                                        _lib.ptr(emb), _lib.current_stream_ptr(self.device)),
-                           "ws_forward_ragged")
+                if cmvn is not None and (cmvn[0] or cmvn[1]):
+                    _lib.check(_lib.lib().ws_forward_ragged_cmvn(self._h, _lib.ptr(feats), B, T, _lib.ptr(lens),
+                                                                 int(bool(cmvn[0])), int(bool(cmvn[1])), _lib.ptr(emb),
+                                                                 _lib.current_stream_ptr(self.device)),
+                               "ws_forward_ragged_cmvn")
+                else:
+                    _lib.check(_lib.lib().ws_forward_ragged(self._h, _lib.ptr(feats), B, T, _lib.ptr(lens),
+                                                            _lib.ptr(emb), _lib.current_stream_ptr(self.device)),
+                               "ws_forward_ragged")
         return emb
 
     def extract_ragged(self, frontend: Frontend, wav: torch.Tensor, num_samples, window_type="hamming",

@@ -91,8 +91,8 @@ def iter_entries(data_type, lines):
                     data = tar.extractfile(info).read()
                     yield info.name[:pos], (lambda d=data: load_pcm16_fast(d))
     else:
-        raise NotImplementedError("data_type %r (raw / scp / shard are on the MI355X path; 'feat' lists of "
-                                  "precomputed Kaldi features are not)" % data_type)
+        raise NotImplementedError("data_type %r (raw / scp / shard entries are waveforms; 'feat' lists of precomputed "
+                                  "Kaldi features go through extract_feats)" % data_type)
 
 
 def crop_start(key, data_len, chunk_len, seed):
@@ -632,8 +632,60 @@ def split_path_list(data_type, lines):
     return keys, paths
 
 
+def extract_feats(lines, extractor, batch_size=1, whole_utt=None, num_frms=200, max_batch=256, num_workers=4, seed=0,
+                  cmvn=(True, False), length_tolerance=0.12, load_block=2048):
+    """`data_type: feat` lists (dataset/dataset.py:136-273 with processor.parse_feat :171-196): json lines
+    {key, feat, spk} whose `feat` is a Kaldi matrix (`file.ark:offset`, what kaldiio.load_mat reads) -> (keys, (n, E)).
+
+    The features come from disk; CMVN (test_conf['cmvn'] / ['cmvn_args'], bin/extract.py:124-127) and the forward run
+    on the GPU in one call per batch (ws_forward_ragged_cmvn: statistics over every utterance's own frames).
+    whole_utt (default: batch_size == 1, bin/extract.py:95): every utterance on all of its frames, utterances within
+    length_tolerance share a padded batch; otherwise each is cut / tiled to num_frms frames
+    (processor.random_chunk(chunk_len=num_frms, 'feat')).  Matrices are read `load_block` utterances at a time by a
+    thread pool, so host memory holds one block."""
+    from .kaldi_io import read_mat
+    if whole_utt is None:
+        whole_utt = batch_size == 1
+    model = extractor.model
+    engine = getattr(model, "engines", [model])[0]
+    entries = []
+    for line in lines:
+        obj = json.loads(line)
+        entries.append((obj["key"], obj["feat"]))
+    keys = [k for k, _ in entries]
+    emb = np.zeros((len(entries), extractor.embed_dim), np.float32)
+
+    def load(item):
+        key, spec = item
+        m = read_mat(spec)
+        if not whole_utt:
+            m = random_chunk(m, key, num_frms, seed) if m.shape[0] >= num_frms else \
+                np.tile(m, (num_frms // m.shape[0] + 1, 1))[:num_frms]
+        return np.ascontiguousarray(m, dtype=np.float32)
+
+    with ThreadPoolExecutor(max_workers=max(1, num_workers)) as pool:
+        for lo in range(0, len(entries), load_block):
+            mats = list(pool.map(load, entries[lo:lo + load_block]))
+            frames = np.array([m.shape[0] for m in mats], dtype=np.int32)
+            for idx in plan_batches(frames, max_batch, length_tolerance):
+                T = int(frames[idx].max())
+                pad = torch.zeros((len(idx), T, mats[idx[0]].shape[1]), dtype=torch.float32)
+                for r, i in enumerate(idx):
+                    pad[r, :frames[i]] = torch.from_numpy(mats[i])
+                out = engine.embed_ragged(pad, frames[idx], cmvn=cmvn)
+                emb[lo + idx] = out.cpu().numpy()
+    extractor.finish()
+    return keys, emb
+
+
 def extract_list(data_type, lines, extractor, **kw):
-    """extract_files when the list allows it, extract_entries otherwise (same result either way)."""
+    """extract_files when the list allows it, extract_entries otherwise (same result either way); `feat` lists of
+    precomputed Kaldi features go through extract_feats."""
+    if data_type == "feat":
+        fk = {k: v for k, v in kw.items() if k in ("batch_size", "whole_utt", "num_frms", "max_batch", "num_workers",
+                                                     "seed", "cmvn", "length_tolerance")}
+        return extract_feats(lines, extractor, **fk)
+    kw = {k: v for k, v in kw.items() if k not in ("num_frms", "cmvn")}         # (the feat path's own arguments)
     kp = split_path_list(data_type, lines)
     if kp is not None and hasattr(extractor, "submit_files"):
         fast = {k: v for k, v in kw.items() if k in ("batch_size", "whole_utt", "chunk_len", "max_batch",
@@ -744,14 +796,15 @@ def extract(config="conf/config.yaml", **kwargs):
         chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
         max_batch=int(configs.get("max_batch", 256)), resample_rate=fc["resample_rate"],
         num_workers=int(configs.get("num_workers", 4)), seed=int(configs.get("seed", 0)),
-        resample_fn=_gpu_resampler(extractor.device))
+        resample_fn=_gpu_resampler(extractor.device), num_frms=fc["num_frms"],
+        cmvn=(fc["norm_mean"], fc["norm_var"]))
     write_ark_scp(keys, emb, configs["embed_ark"])
     return keys, emb
 
 
 def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, batch_size=1, chunk_len=32240,
              max_batch=256, resample_rate=16000, num_workers=4, seed=0, resample_fn=None, gather=False,
-             wavs_num=None, store_dir=""):
+             wavs_num=None, store_dir="", num_frms=200, cmvn=(True, False)):
     """tools/extract_embedding.sh on `world` ranks: job j of the nj contiguous sub-lists runs on rank
     j % world and writes embed_dir/xvector_{j:03d}.ark/.scp (+ log/split_{j:03d}); after a barrier rank 0
     concatenates the scp files in job order into xvector.scp, compares the count with wavs_num and writes
@@ -774,7 +827,8 @@ def run_jobs(lines, data_type, embed_dir, make_extractor, nj, rank=0, world=1, b
             extractor = make_extractor()
         keys, emb = extract_list(data_type, lines[lo:hi], extractor, batch_size=batch_size,
                                  chunk_len=chunk_len, max_batch=max_batch, resample_rate=resample_rate,
-                                 num_workers=num_workers, seed=seed, resample_fn=resample_fn)
+                                 num_workers=num_workers, seed=seed, resample_fn=resample_fn, num_frms=num_frms,
+                                 cmvn=cmvn)
         write_ark_scp(keys, emb, os.path.join(embed_dir, "xvector_%03d.ark" % j))
         my_keys.append((j, keys))
         my_emb.append((j, emb))
@@ -845,7 +899,7 @@ def main(argv=None):
     ap.add_argument("--exp_dir", default="exp/XVEC")
     ap.add_argument("--config", default=None, help="default: <exp_dir>/config.yaml")
     ap.add_argument("--model_path", default="avg_model.pt")
-    ap.add_argument("--data_type", default="shard", choices=["shard", "raw", "scp"])
+    ap.add_argument("--data_type", default="shard", choices=["shard", "raw", "scp", "feat"])
     ap.add_argument("--data_list", default="shard.list")
     ap.add_argument("--wavs_num", type=int, default=None)
     ap.add_argument("--store_dir", default="")
@@ -879,7 +933,8 @@ def main(argv=None):
                    batch_size=args.batch_size, chunk_len=chunk_samples(fc["num_frms"], fc["resample_rate"]),
                    max_batch=args.max_batch, resample_rate=fc["resample_rate"], num_workers=args.num_workers,
                    seed=args.seed, resample_fn=_gpu_resampler(device), wavs_num=args.wavs_num,
-                   store_dir=args.store_dir, gather=bool(args.gather_npz))
+                   store_dir=args.store_dir, gather=bool(args.gather_npz), num_frms=fc["num_frms"],
+                   cmvn=(fc["norm_mean"], fc["norm_var"]))
     if args.gather_npz and rank == 0:
         keys, emb = out
         np.savez(args.gather_npz, keys=np.asarray(keys), emb=emb)

@@ -149,3 +149,116 @@ def read_vec_ark(ark_path):
                     break
                 key += c
             out[key.decode()] = _read_vector_at(f)
+
+
+# ------------------------------------------------------------------------------------- matrices
+# Kaldi feature matrices (feats.scp / feats.ark): what kaldiio.load_mat returns for the `feat` entries of a
+# `data_type: feat` list (wespeaker/dataset/processor.py:171-196).  Binary "FM " / "DM " records, the three
+# compressed layouts of Kaldi's compressed-matrix.h ("CM " per-column percentiles + bytes, "CM2" uint16, "CM3" uint8)
+# and the text form.  kaldiio is not in this image: the compressed layouts follow the published Kaldi format and are
+# covered by a round trip through this file's own writer only.
+def write_mat(f, key, mat, compress=0):
+    """One record `key <matrix>` to the binary file object f; returns the offset a scp line points at.
+    compress: 0 "FM "/"DM ", 2 "CM2" (uint16), 3 "CM3" (uint8), 1 "CM " (per-column percentiles)."""
+    mat = np.ascontiguousarray(mat)
+    f.write(key.encode() + b" ")
+    off = f.tell()
+    rows, cols = mat.shape
+    if not compress:
+        tag = b"DM " if mat.dtype == np.float64 else b"FM "
+        data = mat.astype("<f8" if mat.dtype == np.float64 else "<f4").tobytes()
+        f.write(b"\0B" + tag + b"\x04" + struct.pack("<i", rows) + b"\x04" + struct.pack("<i", cols) + data)
+        return off
+    m = mat.astype(np.float32)
+    lo, hi = float(m.min()) if m.size else 0.0, float(m.max()) if m.size else 0.0
+    rng = hi - lo if hi > lo else 1.0
+    head = struct.pack("<ffii", lo, rng, rows, cols)
+    if compress == 2:
+        q = np.clip(np.rint((m - lo) / rng * 65535.0), 0, 65535).astype("<u2")
+        f.write(b"\0BCM2 " + head + q.tobytes())
+    elif compress == 3:
+        q = np.clip(np.rint((m - lo) / rng * 255.0), 0, 255).astype(np.uint8)
+        f.write(b"\0BCM3 " + head + q.tobytes())
+    else:
+        pct = np.percentile(m, [0, 25, 75, 100], axis=0) if rows else np.zeros((4, cols))
+        pq = np.clip(np.rint((pct - lo) / rng * 65535.0), 0, 65535).astype("<u2")          # (4, cols)
+        # strictly increasing percentiles, as Kaldi enforces, so that every segment has a width
+        for k in range(1, 4):
+            pq[k] = np.maximum(pq[k], pq[k - 1] + 1)
+        p = lo + rng * pq.astype(np.float64) / 65535.0
+        x = m.astype(np.float64)
+        b = np.where(x < p[1], (x - p[0]) / (p[1] - p[0]) * 64.0,
+                     np.where(x < p[2], 64.0 + (x - p[1]) / (p[2] - p[1]) * 128.0,
+                              192.0 + (x - p[2]) / (p[3] - p[2]) * 63.0))
+        bq = np.clip(np.rint(b), 0, 255).astype(np.uint8)
+        f.write(b"\0BCM " + head + np.ascontiguousarray(pq.T).tobytes() + np.ascontiguousarray(bq.T).tobytes())
+    return off
+
+
+def _read_matrix_at(f):
+    marker = f.read(2)
+    if marker != b"\0B":                                   # text form: " [\n 1 2 3\n 4 5 6 ]"
+        rows, cur = [], (marker + f.readline()).decode().replace("[", " ")
+        while True:
+            done = "]" in cur
+            toks = cur.replace("]", " ").split()
+            if toks:
+                rows.append([float(t) for t in toks])
+            if done:
+                break
+            cur = f.readline().decode()
+            if not cur:
+                raise ValueError("unterminated text matrix")
+        return np.asarray(rows, dtype=np.float32)
+    tag = f.read(3)
+    if tag in (b"FM ", b"DM "):
+        dt = "<f4" if tag == b"FM " else "<f8"
+        assert f.read(1) == b"\x04"
+        rows = struct.unpack("<i", f.read(4))[0]
+        assert f.read(1) == b"\x04"
+        cols = struct.unpack("<i", f.read(4))[0]
+        return np.frombuffer(f.read(rows * cols * int(dt[2])), dtype=dt).reshape(rows, cols).astype(np.float32)
+    if tag == b"CM ":
+        fmt = 1
+    elif tag == b"CM2" or tag == b"CM3":
+        fmt = int(tag[2:3])
+        assert f.read(1) == b" "
+    else:
+        raise ValueError("not a Kaldi matrix record (tag %r)" % tag)
+    lo, rng, rows, cols = struct.unpack("<ffii", f.read(16))
+    if fmt == 2:
+        q = np.frombuffer(f.read(rows * cols * 2), dtype="<u2").reshape(rows, cols)
+        return (lo + rng * (1.0 / 65535.0) * q.astype(np.float32)).astype(np.float32)
+    if fmt == 3:
+        q = np.frombuffer(f.read(rows * cols), dtype=np.uint8).reshape(rows, cols)
+        return (lo + rng * (1.0 / 255.0) * q.astype(np.float32)).astype(np.float32)
+    pq = np.frombuffer(f.read(cols * 8), dtype="<u2").reshape(cols, 4).astype(np.float32)
+    p = lo + rng * (1.0 / 65535.0) * pq                                             # (cols, 4): 0 / 25 / 75 / 100 %
+    b = np.frombuffer(f.read(rows * cols), dtype=np.uint8).reshape(cols, rows).astype(np.float32)
+    p0, p25, p75, p100 = (p[:, k:k + 1] for k in range(4))
+    out = np.where(b <= 64, p0 + (p25 - p0) * b * (1.0 / 64.0),
+                   np.where(b <= 192, p25 + (p75 - p25) * (b - 64.0) * (1.0 / 128.0),
+                            p75 + (p100 - p75) * (b - 192.0) * (1.0 / 63.0)))
+    return np.ascontiguousarray(out.T).astype(np.float32)
+
+
+def read_mat(spec):
+    """kaldiio.load_mat: `path:offset` (a scp entry) or a path that holds ONE bare matrix -> (rows, cols) float32."""
+    path, off = spec, 0
+    pos = spec.rfind(":")
+    if pos > 0 and spec[pos + 1:].isdigit():
+        path, off = spec[:pos], int(spec[pos + 1:])
+    with open(path, "rb") as f:
+        f.seek(off)
+        return _read_matrix_at(f)
+
+
+def read_mat_scp(scp_path):
+    """{key: matrix} of a feats.scp."""
+    out = {}
+    with open(scp_path) as f:
+        for line in f:
+            if line.strip():
+                key, spec = line.strip().split(None, 1)
+                out[key] = read_mat(spec)
+    return out
