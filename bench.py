@@ -426,8 +426,9 @@ def plda_leg(args, device, with_cpu_baseline):
     # summary: tools/pmc_cmd.sh + tools/pmc_plda_summary.py).  The guide's counters see what leaves the L2 -- Infinity
     # Cache hits included -- so `traffic` is fabric-side bytes per launch, and the rate is quoted against the HBM peak
     # next to the measured gather yardstick
-    pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_plda.json")
-    if os.path.exists(pmc_path) and args.trials == 1000000:
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_plda.json" % r) for r in ("r06", "r05"))
+                     if os.path.exists(q)), "")
+    if pmc_path and args.trials == 1000000:
         with open(pmc_path) as fp:
             pmc = json.load(fp)
         for key, roof, dev_s, algo in (("plda_llr_pairs_random_list", "roofline", pair_dev, bpt),
@@ -436,7 +437,7 @@ def plda_leg(args, device, with_cpu_baseline):
             r = plda_info[roof]
             r["traffic"] = c["traffic_bytes_per_launch"]
             r["traffic_unit"] = "bytes per launch that left the L2 (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC; Infinity-Cache hits are counted)"
-            r["traffic_source"] = "profiles/r05_pmc_plda.json"
+            r["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
             r["l2_hit_rate"] = c["l2_hit_rate"]
             r["l2_request_bytes_per_launch"] = c["l2_requests_x128B_bytes"]
             r["fabric_gbs"] = c["traffic_bytes_per_launch"] / dev_s / 1e9
@@ -630,7 +631,7 @@ def parse_args(argv):
     ap.add_argument("--sustain-s", type=float, default=0.0,
                     help="length of the sustained window of the headline back-end (same step function, one timed "
                          "region of this many seconds, the shader clock sampled next to it): `value_sustained`; 0 = off")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="batches in flight per GPU (wespeaker_amd.SpeakerModelLanes: one engine + HIP stream per "
                          "lane, step i runs on lane i %% lanes); 1 = one stream, every launch behind the previous one")
     ap.add_argument("--precision", default="fp32", choices=list(BACKENDS),
@@ -939,7 +940,7 @@ def main(argv=None):
         # HBM traffic of the dominant kernel class: separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed aggregate of the newest round
         tag = "" if model_name == "ECAPA_TDNN_GLOB_c512" else "_" + model_name
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_dominant_kernel_%s%s.json" % (rnd, prec, tag))
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fpmc:

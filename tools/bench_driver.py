@@ -49,11 +49,13 @@ def main():
         from wespeaker_amd import SpeakerModelLanes
         lanes2 = SpeakerModelLanes(args.model, synth.synth_state_dict(args.model, 80, E, seed=42), lanes=2, feat_dim=80,
                                    embed_dim=E, device=dev, max_batch=args.max_batch, max_frames=250)
-        for prec in ("fp32", "fp32_2lanes", "f16"):
-            if prec != "fp32_2lanes":
+        lanes3 = SpeakerModelLanes(args.model, synth.synth_state_dict(args.model, 80, E, seed=42), lanes=3, feat_dim=80,
+                                   embed_dim=E, device=dev, max_batch=args.max_batch, max_frames=250)
+        for prec in ("fp32", "fp32_2lanes", "fp32_3lanes", "f16"):
+            if not prec.endswith("lanes"):
                 model.set_precision(prec)
             for tag, lines in lists.items():
-                ex = wx.GpuExtractor(lanes2 if prec == "fp32_2lanes" else model, fe)
+                ex = wx.GpuExtractor({"fp32_2lanes": lanes2, "fp32_3lanes": lanes3}.get(prec, model), fe)
                 run = (lambda ls: wx.extract_entries(wx.iter_entries("scp", ls), ex, batch_size=1,
                                                      max_batch=args.max_batch, num_workers=args.workers)) \
                     if args.python_loader else \
