@@ -1429,8 +1429,9 @@ def test_attentive_pooling_kernel_forced_on_small_batches(tmp_path):
 
 
 def test_bench_two_ranks_with_lanes_on_one_gpu():
-    """bench.py --gpus 2 (self-launching) with two batches in flight per rank, both ranks on this one GPU
-    (WS_SHARE_GPU=1, gloo): the per-step gathers are issued under the lane's stream and joined two steps later."""
+    """bench.py --gpus 2 (self-launching) with its default number of batches in flight per rank (three since round 6),
+    both ranks on this one GPU (WS_SHARE_GPU=1, gloo): the per-step gathers are issued under the lane's stream and
+    joined `lanes` steps later."""
     import json
     import subprocess
     import sys
@@ -1442,7 +1443,7 @@ def test_bench_two_ranks_with_lanes_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128
-    assert line["config"]["batches_in_flight_per_gpu"] == 2 and line["value"] > 0
+    assert line["config"]["batches_in_flight_per_gpu"] == 3 and line["value"] > 0
     assert line["roofline"]["frac"] > 0
 
 
