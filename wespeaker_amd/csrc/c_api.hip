@@ -671,7 +671,7 @@ int ws_engine_check_range(ws_engine* eng, ws_stream stream) {
               "activation passed 65504 in the f16 / f16x3 back-end; use WS_PREC_FP32 for this model)", n);
     return WS_ERR_RANGE;
   }
-  return WS_OK;
+  return eng->model->check_invariants();
 }
 
 int ws_debug_dispatch_log(int mode) {

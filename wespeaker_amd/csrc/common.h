@@ -201,6 +201,9 @@ struct Model {
   // non-finite embedding values produced by the binary16 back-ends since the last call (reads and
   // clears the host-mapped counter; the caller has synchronised the stream)
   virtual int take_nonfinite() = 0;
+  // Engine-internal invariants that a kernel bug could break silently (ws_engine_check_range calls it behind its
+  // stream synchronisation): 0, or a WS_ERR_* with the message set.  ResNet: the zero pads behind its activation buffers.
+  virtual int check_invariants() { return 0; }
   virtual int set_precision(int mode) = 0;   // 0 exact fp32 MFMA, 1 split-f16 x3 MFMA
   virtual float* feats_workspace() = 0;      // (max_batch, max_frames, feat_dim) floats
   virtual int max_batch() const = 0;

@@ -157,6 +157,27 @@ struct ResNetModel : ModelBase {
 
   int min_frames() const override { return 2; }
 
+  //  The CONV form of the persistent GEMM reads border taps from the 512 zero floats behind each activation
+  // buffer.  Nothing may ever store there -- a whole-tile store without a row guard would, and every later image
+  // border would be silently wrong: ws_engine_check_range looks (8 KB device -> host, behind its synchronisation).
+  int check_invariants() override {
+    if (!act_floats) return 0;
+    std::vector<float> pad(512);
+    for (int i = 0; i < 4; ++i) {
+      if (hipMemcpy(pad.data(), buf[i] + act_floats, 512 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("%s: reading the zero pad of activation buffer %d failed", name.c_str(), i);
+        return WS_ERR_HIP;
+      }
+      for (int k = 0; k < 512; ++k)
+        if (pad[k] != 0.f) {
+          set_error("%s: the zero pad behind activation buffer %d was overwritten (float %d = %g): a kernel stored "
+                    "past its tensor; convolution borders of later forwards are wrong", name.c_str(), i, k, pad[k]);
+          return WS_ERR_STATE;
+        }
+    }
+    return 0;
+  }
+
   int forward_chunk(const float* feats, int B, int T, float* emb, hipStream_t st) override {
     int H = feat_dim, W = T;
     // ragged chunk: the time axis of utterance b holds cur_lens[level][b] valid columns at stride level
