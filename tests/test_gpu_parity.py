@@ -2097,6 +2097,27 @@ def test_ragged_forward_rows_equal_the_batch1_oracle(name, E, lens, prec):
         model.embed_ragged(torch.from_numpy(pad), [0] + lens[1:])                   # shorter than the model minimum
 
 
+@pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 100), ("ResNet18", 37), ("CAMPPlus", 200)])
+def test_small_m_gemm_edges(name, E):
+    """small_m_gemm_f32_kernel (csrc/small_m_gemm.hip): the M = batch linear layers of the fp32 back-end in one launch
+    -- ECAPA's final BN + Linear and global-context bias (ecapa_tdnn.py:214-218, pooling_layers.py:128-133), the ResNets'
+    seg_1 (resnet.py:196-202), CAM++'s dense layer (campplus.py:322-330).  Embedding sizes that are NOT multiples of its
+    16-column tile and batches that are not multiples of its 16-row tile (1, 3, 17, 33), against the oracle."""
+    from oracle import campplus as ocam, resnet as oresnet
+    sd = synth.synth_state_dict(name, 80, E, seed=42)
+    model = _native(name, sd, E, max_batch=33, max_frames=120)
+    fwd = {"ECAPA": lambda f: oecapa.ecapa_forward(sd, f).numpy(),
+           "ResNe": lambda f: oresnet.resnet_forward(sd, f, name).numpy(),
+           "CAMPP": lambda f: ocam.campplus_forward(sd, f).numpy()}[name[:5]]
+    for B in (1, 3, 17, 33):
+        f = np.random.RandomState(B).randn(B, 100, 80).astype(np.float32)
+        out = model(torch.from_numpy(f))
+        got = (out[-1] if isinstance(out, tuple) else out).cpu().numpy()
+        ref = fwd(f)
+        assert got.shape == ref.shape == (B, E)
+        assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL, (name, B)
+
+
 def test_res2_chain_four_wavefront_kernel_sizes():
     """res2_chain4_kernel (csrc/res2_chain4.hip; ecapa_tdnn.py:58-78): the fp32 chain of ECAPA-512 takes it when the
     batch fills the chip (> 64 utterances) and 129 <= T <= 208 -- one instantiation per number of 16-row tiles (9 .. 13).

@@ -132,6 +132,9 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p, int rows, int cus, hi
 
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
+// The "M = batch" linear layers of the fp32 back-end in ONE launch instead of split-K GEMM + reduce (small_m_gemm.hip)
+bool small_m_gemm_f32_applies(const ConvGemmParams& p);
+hipError_t launch_small_m_gemm_f32(const ConvGemmParams& p, hipStream_t stream);
 
 // Fused Res2 chain (ecapa_tdnn.py:58-78): 7 serial k=3 dilated convs of width W, one workgroup per
 // utterance, running activation kept in LDS.  y1: output of the block's first 1x1 conv [B*T][ldy1]

@@ -401,6 +401,12 @@ struct ModelBase : Model {
   }
   // split-K GEMM + reduce (M small, K large: the embedding layers)
   hipError_t gemm_splitk(ConvGemmParams p, float* partial, int splitk, hipStream_t st) {
+    if (small_m_gemm_f32_applies(p)) {          // fp32, plain epilogue: one launch, no partial sums through HBM
+      if (prof.enabled) prof.begin(3, 2.0 * p.M * (double)p.N * p.K, 4.0 * (p.M * (double)p.K + p.N * (double)p.K), st);
+      hipError_t e = launch_small_m_gemm_f32(p, st);
+      prof.end(st);
+      return e;
+    }
     p.splitk = splitk;
     p.partial = partial;
     hipError_t e = gemm(p, st);
