@@ -27,10 +27,11 @@ WS_PREC_FP32 (exact fp32 products on v_mfma_f32_32x32x2_f32) and `value` / `dtyp
 process and reported under `backends`, each with its own `roofline` block (dominant kernel class measured live with
 HIP events on the launch stream).
 
-The default N = 1 line also carries: `configs` (ECAPA-1024, ResNet34, ResNet221, CAM++: value, ms/step, dominant
-fraction, and the two fixed-size sets at N = 1), `plda` (pair list + dense matrix, each with `roofline` and
-`cpu_baseline`), `self_check` (rows of the timed output against a small-batch run of the same utterances) and
-`cpu_baseline` (the oracle on the host cores; /root/reference cannot travel to the GPU box, hence kind "port").
+What goes where.  Rank 0 prints ONE compact JSON line (< 8 KB; `compact_line`: the contract's keys, the headline
+`roofline` and `cpu_baseline`, `plda`, one figure per other BASELINE config, the fixed-size sets) and writes the full
+record -- per-back-end blocks with their windows, notes, shard tables, per-class event times -- to `bench_detail.json`
+beside this script (`--detail-file`).  Round 5's 24-KB line was dropped by the driver's parser.  Three batches are in
+flight per GPU by default (`--lanes`); the sustained leg, the 1e8-trial PLDA matrices and the batch sweep are opt-in.
 
 WS_BENCH_STUB=1 (tests only): a host stand-in for the extractor (no GPU, gloo) so that the launch / sharding /
 gather / JSON logic of THIS file can run on CPU at world size 2.
