@@ -2272,6 +2272,47 @@ def test_driver_with_two_lanes_equals_one_engine(tmp_path):
             assert np.array_equal(e1, e2), (prec, tag)
 
 
+def test_driver_head_first_pipeline_and_its_fallback(tmp_path):
+    """extract_files on a list long enough for its head-first start-up (>= 6 x max_batch files: the first 2 x max_batch
+    are probed, planned and sent to the GPU alone, the decode thread prepares the rest behind them): uniform and
+    all-different lengths equal the general path (extract_entries) row for row, in list order.  A file BEHIND the head
+    that the native loader cannot take (8-bit PCM) makes the call start over on the general path -- same rows again."""
+    import struct
+    from wespeaker_amd import extract as wx
+    from wespeaker_amd.engine import Frontend, NativeSpeakerModel
+    sd = synth.synth_ecapa_state_dict("ECAPA_TDNN_GLOB_c512", 80, 192, seed=42)
+    fe = Frontend(16000, 80)
+    model = NativeSpeakerModel("ECAPA_TDNN_GLOB_c512", sd, max_batch=8, max_frames=260)
+    n = 70                                                   # head = 16 files, rest = 54
+    for tag in ("uniform", "varied"):
+        lines = []
+        for i in range(n):
+            p = str(tmp_path / ("%s%02d.wav" % (tag[0], i)))
+            synth.write_wav(p, synth.synth_wav(700 + i, 32000 if tag == "uniform" else 24000 + 229 * ((i * 37) % n)))
+            lines.append("utt%02d %s" % (i, p))
+        kp = wx.split_path_list("scp", lines)
+        k1, e1 = wx.extract_files(kp[0], kp[1], wx.GpuExtractor(model, fe), batch_size=1, max_batch=8, threads=4)
+        k2, e2 = wx.extract_entries(wx.iter_entries("scp", lines), wx.GpuExtractor(model, fe), batch_size=1,
+                                    max_batch=8, num_workers=2)
+        assert k1 == k2 == ["utt%02d" % i for i in range(n)]
+        assert _rel_err(e1, e2).max() < 1e-5, tag              # (other batch compositions: fp32 summation order only)
+        rows = [0, 15, 16, 40, n - 1]                          # head, the head / rest seam, rest
+        ref = _oracle_rows(lambda f: oecapa.ecapa_forward(sd, f).numpy(),
+                           [ofbank.speaker_features(wx.load_pcm16_fast(kp[1][i])[0]) for i in rows])
+        assert _cos_err(e1[rows], ref).max() < COS_TOL and _rel_err(e1[rows], ref).max() < 5e-4, tag
+    # an 8-bit PCM file at position 50: the head's batches are already on the GPU when the rest is probed
+    bad = str(tmp_path / "u50.wav")
+    pcm8 = ((synth.synth_wav(750, 32000).astype(np.int32) >> 8) + 128).astype(np.uint8)
+    with open(bad, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + pcm8.size) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 16000, 1, 8)
+                + b"data" + struct.pack("<I", pcm8.size) + pcm8.tobytes())
+    assert wx.extract_files(kp[0], kp[1][:50] + [bad] + kp[1][51:], wx.GpuExtractor(model, fe), batch_size=1, max_batch=8,
+                            threads=4) is None
+    lines[50] = "utt50 " + bad
+    k3, e3 = wx.extract_list("scp", lines, wx.GpuExtractor(model, fe), batch_size=1, max_batch=8, num_workers=2)
+    assert k3 == k1 and np.isfinite(e3).all() and _rel_err(np.delete(e3, 50, 0), np.delete(e1, 50, 0)).max() < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ dispatch tables
 def _dispatch_cases():
     import sys
