@@ -2118,6 +2118,27 @@ def test_small_m_gemm_edges(name, E):
         assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL, (name, B)
 
 
+@pytest.mark.parametrize("name", ["ResNet50", "ResNet101"])
+def test_bottleneck_conv3_conv1_fusion_partial_pixel_blocks(name):
+    """bneck_c3c1_kernel (csrc/bneck_fuse.hip; resnet.py:72-107): conv3 + residual + ReLU of a Bottleneck block and conv1 +
+    ReLU of the next block in one launch (fp32, stages 1 - 2, incl. the stage 1 -> 2 transition).  A wavefront owns 32
+    pixels; ONE utterance of an odd number of frames makes the pixel count 16 (mod 32) in both stages, so the last
+    block of pixels is half empty (dropped by the buffer bounds).  Against the oracle; and a ragged batch -- which
+    stays on the unfused kernels -- gives the same rows."""
+    from oracle import resnet as oresnet
+    sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42)
+    model = _native(name, sd, 256, max_batch=4, max_frames=200)
+    for B, T in ((1, 131), (1, 57), (3, 99), (4, 198)):
+        assert (B * 80 * T) % 32 in (0, 16)
+        f = np.random.RandomState(T).randn(B, T, 80).astype(np.float32)
+        got = model(torch.from_numpy(f))[-1].cpu().numpy()
+        ref = oresnet.resnet_forward(sd, f, name).numpy()
+        assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL, (B, T)
+        rag = model.embed_ragged(torch.from_numpy(f), [T] * B).cpu().numpy()      # per-utterance lengths: unfused path
+        assert _rel_err(rag, got).max() < 1e-5, (B, T)
+    model.check_range()
+
+
 def test_res2_chain_four_wavefront_kernel_sizes():
     """res2_chain4_kernel (csrc/res2_chain4.hip; ecapa_tdnn.py:58-78): the fp32 chain of ECAPA-512 takes it when the
     batch fills the chip (> 64 utterances) and 129 <= T <= 208 -- one instantiation per number of 16-row tiles (9 .. 13).

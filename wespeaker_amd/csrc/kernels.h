@@ -132,6 +132,19 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p, int rows, int cus, hi
 
 // out[m][n] = epilogue(sum_z partial[z][m][n]) with the same epilogue fields as ConvGemmParams.
 hipError_t launch_splitk_reduce(const ConvGemmParams& p, hipStream_t stream);
+// conv3 (+ residual, ReLU) of a Bottleneck block and conv1 (+ ReLU) of the next block in one pass over the block output
+// (bneck_fuse.hip; fp32, planes P = 32): the block output is stored once and not read again by conv1
+struct BneckFuseParams {
+  const float* y2;                            // (M, P): conv2's output rows
+  const float* W3; int ldw3; const float* b3; // conv3 + bn3 folded: [4P][ldw3], [4P]
+  const float* res; int ldr;                  // (M, ldr >= 4P): the block's residual (its input, or the shortcut conv's output)
+  float* out;                                 // (M, 4P): the block output
+  const float* W1; int ldw1; const float* b1; // the NEXT block's conv1 + bn1 folded: [PN][ldw1], [PN]
+  float* y1;                                  // (M, PN): the next block's conv1 output
+  int M, P, PN;                               // PN: the next block's planes (P, or 2 P at the stage 1 -> 2 transition)
+};
+bool bneck_fuse_supported(const BneckFuseParams& p);
+hipError_t launch_bneck_fuse(const BneckFuseParams& p, hipStream_t stream);
 // The "M = batch" linear layers of the fp32 back-end in ONE launch instead of split-K GEMM + reduce (small_m_gemm.hip)
 bool small_m_gemm_f32_applies(const ConvGemmParams& p);
 hipError_t launch_small_m_gemm_f32(const ConvGemmParams& p, hipStream_t stream);

@@ -208,7 +208,9 @@ struct ResNetModel : ModelBase {
       return gemm(p, st);
     };
     int cur = 0;          // index of the buffer holding x
-    for (const Block& blk : blocks) {
+    bool have_y1 = false; // the current block's conv1 output already lies in its t1 (written by the previous block)
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+      const Block& blk = blocks[bi];
       float* t1 = buf[(cur + 1) & 3];
       float* t2 = buf[(cur + 2) & 3];
       float* out = buf[(cur + 3) & 3];
@@ -224,9 +226,32 @@ struct ResNetModel : ModelBase {
         ldr = Co;
       }
       if (lay.bottleneck) {
-        WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0, lvl));
+        if (!have_y1) WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0, lvl));
+        have_y1 = false;                // (else: the previous block's fused launch left this block's y1 in t1)
         WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
-        WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr, lo));
+        // conv3 (+ residual, ReLU) of this block and conv1 (+ ReLU) of the next one in ONE pass over the block output
+        // (bneck_fuse.hip): fp32, uniform batches, 32 / 64 planes, the next block of the same stage (same planes, no
+        // stride in ITS conv1: a block's stride sits in conv2), no shortcut convolution in THIS block -- its output would sit in t2, where the next block's y1 goes
+        const Block* nb = bi + 1 < blocks.size() ? &blocks[bi + 1] : nullptr;
+        BneckFuseParams fp = {};
+        if (gemm_precision == 0 && !ragged() && !blk.has_sc && nb && (nb->planes == P || nb->planes == 2 * P) && nb->in_planes == Co &&
+            blk.c3.has_b && nb->c1.has_b && !blk.c3.has_post && !nb->c1.has_post) {
+          fp.y2 = out; fp.W3 = arena.at(blk.c3.w); fp.ldw3 = blk.c3.ldw; fp.b3 = arena.at(blk.c3.b);
+          fp.res = res; fp.ldr = ldr; fp.out = t1;
+          fp.W1 = arena.at(nb->c1.w); fp.ldw1 = nb->c1.ldw; fp.b1 = arena.at(nb->c1.b);
+          fp.y1 = t2;                   // = the next block's t1
+          fp.M = B * Ho * Wo; fp.P = P; fp.PN = nb->planes;
+        }
+        if (fp.y2 && bneck_fuse_supported(fp)) {
+          const double M_ = (double)fp.M;
+          if (prof.enabled) prof.begin(0, 2.0 * M_ * (P * (double)Co + Co * (double)P), 4.0 * M_ * (P + 2.0 * Co + P), st);
+          hipError_t fe = launch_bneck_fuse(fp, st);
+          prof.end(st);
+          WS_LAUNCH(fe);
+          have_y1 = true;
+        } else {
+          WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr, lo));
+        }
         cur = (cur + 1) & 3;            // result in t1
       } else {
         WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
