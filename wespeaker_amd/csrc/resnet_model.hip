@@ -208,12 +208,21 @@ struct ResNetModel : ModelBase {
       return gemm(p, st);
     };
     int cur = 0;          // index of the buffer holding x
-    bool have_y1 = false; // the current block's conv1 output already lies in its t1 (written by the previous block)
+    bool have_y1 = false; // the current block's conv1 output already lies in buf[y1_idx] (written by the previous block)
+    int y1_idx = 0;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       const Block& blk = blocks[bi];
-      float* t1 = buf[(cur + 1) & 3];
-      float* t2 = buf[(cur + 2) & 3];
-      float* out = buf[(cur + 3) & 3];
+      // buffer roles of this block: x = buf[cur]; y1 (conv1's output, later the block's result) = buf[ia]; the spare
+      // one (shortcut output, or the NEXT block's y1 when conv3 is fused with its conv1) = buf[ic]; y2 = buf[ib].
+      // Without a y1 handed over by the previous block this is the plain rotation cur + 1 / + 2 / + 3.
+      const int ia = (lay.bottleneck && have_y1) ? y1_idx : (cur + 1) & 3;
+      int rest[2], nrest = 0;
+      for (int k = 1; k <= 3; ++k)
+        if (((cur + k) & 3) != ia) rest[nrest++] = (cur + k) & 3;
+      const int ic = rest[0], ib = rest[1];
+      float* t1 = buf[ia];
+      float* t2 = buf[ic];
+      float* out = buf[ib];
       const int s = blk.stride;
       const int Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
       const int Cx = blk.in_planes, P = blk.planes, Co = P * exp;
@@ -227,19 +236,21 @@ struct ResNetModel : ModelBase {
       }
       if (lay.bottleneck) {
         if (!have_y1) WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, 1, 0, ACT_RELU, nullptr, 0, lvl));
-        have_y1 = false;                // (else: the previous block's fused launch left this block's y1 in t1)
+        have_y1 = false;                // (else: the previous block's fused launch left this block's y1 in buf[ia])
         WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
         // conv3 (+ residual, ReLU) of this block and conv1 (+ ReLU) of the next one in ONE pass over the block output
-        // (bneck_fuse.hip): fp32, uniform batches, 32 / 64 planes, the next block of the same stage (same planes, no
-        // stride in ITS conv1: a block's stride sits in conv2), no shortcut convolution in THIS block -- its output would sit in t2, where the next block's y1 goes
+        // (bneck_fuse.hip): fp32, uniform batches, 32 / 64 planes, the next block with the same or twice the planes
+        // (its conv1 has no stride: a block's stride sits in conv2).  The next block's y1 goes into the one buffer that
+        // is dead by now: the spare one, or -- when this block has a shortcut convolution, whose output IS the spare
+        // one -- the block's own input x (read by conv1 and the shortcut only)
         const Block* nb = bi + 1 < blocks.size() ? &blocks[bi + 1] : nullptr;
         BneckFuseParams fp = {};
-        if (gemm_precision == 0 && !ragged() && !blk.has_sc && nb && (nb->planes == P || nb->planes == 2 * P) && nb->in_planes == Co &&
+        if (gemm_precision == 0 && !ragged() && nb && (nb->planes == P || nb->planes == 2 * P) && nb->in_planes == Co &&
             blk.c3.has_b && nb->c1.has_b && !blk.c3.has_post && !nb->c1.has_post) {
           fp.y2 = out; fp.W3 = arena.at(blk.c3.w); fp.ldw3 = blk.c3.ldw; fp.b3 = arena.at(blk.c3.b);
           fp.res = res; fp.ldr = ldr; fp.out = t1;
           fp.W1 = arena.at(nb->c1.w); fp.ldw1 = nb->c1.ldw; fp.b1 = arena.at(nb->c1.b);
-          fp.y1 = t2;                   // = the next block's t1
+          fp.y1 = blk.has_sc ? buf[cur] : t2;
           fp.M = B * Ho * Wo; fp.P = P; fp.PN = nb->planes;
         }
         if (fp.y2 && bneck_fuse_supported(fp)) {
@@ -249,10 +260,11 @@ struct ResNetModel : ModelBase {
           prof.end(st);
           WS_LAUNCH(fe);
           have_y1 = true;
+          y1_idx = blk.has_sc ? cur : ic;
         } else {
           WS_LAUNCH(conv(blk.c3, out, P, t1, Co, Ho, Wo, 1, 0, ACT_RELU, res, ldr, lo));
         }
-        cur = (cur + 1) & 3;            // result in t1
+        cur = ia;                       // result in t1
       } else {
         WS_LAUNCH(conv(blk.c1, x, Cx, t1, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
         WS_LAUNCH(conv(blk.c2, t1, P, out, Co, Ho, Wo, 1, 1, ACT_RELU, res, ldr, lo));
