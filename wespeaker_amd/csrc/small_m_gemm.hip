@@ -77,9 +77,12 @@ __global__ __launch_bounds__(64 * NW) void small_m_gemm_f32_kernel(const ConvGem
 }
 }  // namespace
 
-// a plain fp32 linear layer with few rows and a long K, nothing fused but bias / activation / BN affine
+// a plain linear layer on fp32 rows with few of them and a long K, nothing fused but bias / activation / BN affine.
+// Every back-end takes it: the binary16 back-ends ran these two 0.3-GFLOP layers as split-K GEMMs on converted operands
+// (29 us each); the exact-fp32 form is both faster (13.6 us) and closer to the reference, and the fp32 weights are resident
+// anyway.
 bool small_m_gemm_f32_applies(const ConvGemmParams& p) {
-  return p.prec == 0 && p.A && p.D && !p.A16 && !p.A2 && !p.pre_scale && !p.D16 && !p.D2 && !p.D2_16 && p.kh == 1 &&
+  return p.W && p.A && p.D && !p.A16 && !p.A2 && !p.pre_scale && !p.D16 && !p.D2 && !p.D2_16 && p.kh == 1 &&
          p.kw == 1 && p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin &&
          p.m_begin == 0 && p.M >= 1 && p.M <= 2048 && p.N >= 1 && p.K >= 512 && p.K % (4 * 16 * SM_CH) == 0 &&
          p.ldw >= p.K &&
