@@ -230,6 +230,16 @@ struct EcapaModel : ModelBase {
         }));
         continue;
       }
+      if (T >= 64 && allf16 && se_fc_scale_residual_f16_supported(T, C, 128)) {      // the same on binary16 rows
+        p3.colsum = colsum;
+        WS_LAUNCH(gemm(p3, st));
+        WS_LAUNCH(other(1.5 * mc, st, [&] {
+          return launch_se_fc_scale_residual_f16(colsum, B, T, C, arena.at(se_w1[L]), arena.at(se_b1[L]),
+                                                 arena.at(se_w2t[L]), arena.at(se_b2[L]), 128, se_s, L0,
+                                                 L == 0 ? out1_16 : cat16, ldx, x_off, y3_16, C, cat16, 3 * C, L * C, st);
+        }));
+        continue;
+      }
       if (T >= 64) {
         // SE time-mean from the GEMM epilogue's per-tile column sums: y3 is not re-read
         p3.colsum = colsum;

@@ -362,6 +362,83 @@ hipError_t launch_se_scale_residual_f16(const uint16_t* x16, int ldx, int x_off,
   return hipGetLastError();
 }
 
+// The SE block of the all-binary16 back-end in ONE launch (round 6), the twin of se_fc_scale_residual_kernel: a
+// workgroup per utterance requests its first rows of x / y (binary16, 16-B = 8 channels per thread), runs the two FCs
+// on the column sums the conv3 epilogue left (se_fc_body: the stand-alone kernel's code), and streams
+// out = half(x + y * s) with s in registers.  Replaces se_fc_from_colsum (15 us of L2 round trips on 256 workgroups) +
+// se_scale_residual_f16 (25 us) + a launch boundary, three times per forward of a 1.3-ms step.
+__global__ __launch_bounds__(1024) void se_fc_scale_residual_f16_kernel(
+    const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, int bott, float* __restrict__ s_out,
+    const int* __restrict__ lens, const uint16_t* __restrict__ x, int ldx, int x_off, const uint16_t* __restrict__ y,
+    int ldy, uint16_t* __restrict__ out, int ldo, int o_off) {
+  typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) float mean[1024];
+  __shared__ __attribute__((aligned(16))) float hidden[256];
+  __shared__ __attribute__((aligned(16))) float s_lds[1024];
+  constexpr int U = 8, PRE = 4;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cols8 = C >> 3;                  // 64 / 128 (C = 512 / 1024): divides the 1024 threads
+  const int c = (tid % cols8) * 8, r0 = tid / cols8, rp = 1024 / cols8;
+  const long long m0 = (long long)b * T;
+  const uint16_t* xp = x + m0 * ldx + x_off + c;
+  const uint16_t* yp = y + m0 * ldy + c;
+  f16x8e xv[U], yv[U];
+  auto request = [&](int u) {
+    const int r = r0 + u * rp;
+    if (r < T) {
+      xv[u] = *reinterpret_cast<const f16x8e*>(xp + (long long)r * ldx);
+      yv[u] = *reinterpret_cast<const f16x8e*>(yp + (long long)r * ldy);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) request(u);
+  se_fc_body<1024, true>(colsum, b, T, C, w1, b1, w2, b2, bott, s_out, lens, mean, hidden, s_lds);
+#pragma unroll
+  for (int u = PRE; u < U; ++u) request(u);
+  __syncthreads();
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(&s_lds[c]);
+  const f32x4 s1 = *reinterpret_cast<const f32x4*>(&s_lds[c + 4]);
+  uint16_t* op = out + m0 * ldo + o_off + c;
+  for (int rb = r0; rb < T; rb += U * rp) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u * rp;
+      if (r < T) {
+        f16x8e o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                  // (the expression of se_scale_residual_f16_kernel: same bits)
+          o[q] = (_Float16)((float)xv[u][q] + (float)yv[u][q] * s0[q]);
+          o[4 + q] = (_Float16)((float)xv[u][4 + q] + (float)yv[u][4 + q] * s1[q]);
+        }
+        *reinterpret_cast<f16x8e*>(op + (long long)r * ldo) = o;
+        const int rn = r + U * rp;
+        if (rn < T) {
+          xv[u] = *reinterpret_cast<const f16x8e*>(xp + (long long)rn * ldx);
+          yv[u] = *reinterpret_cast<const f16x8e*>(yp + (long long)rn * ldy);
+        }
+      }
+    }
+  }
+}
+
+bool se_fc_scale_residual_f16_supported(int T, int C, int bottleneck) {
+  return C <= 1024 && (C & 255) == 0 && bottleneck <= 256 && (bottleneck & 31) == 0 && T >= 64 &&
+         1024 % (C >> 3) == 0;
+}
+
+hipError_t launch_se_fc_scale_residual_f16(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
+                                           const float* w2t, const float* b2, int bottleneck, float* s,
+                                           const int* lens, const uint16_t* x16, int ldx, int x_off,
+                                           const uint16_t* y16, int ldy, uint16_t* out16, int ldo, int o_off,
+                                           hipStream_t stream) {
+  if (!se_fc_scale_residual_f16_supported(T, C, bottleneck) || ((ldx | x_off | ldy | ldo | o_off) & 7))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(se_fc_scale_residual_f16_kernel, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2t, b2,
+                     bottleneck, s, lens, x16, ldx, x_off, y16, ldy, out16, ldo, o_off);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ASTP global-context statistics
 // grid = (B, C/256), block = 256: thread = 1 channel... channel-parallel, two passes over T
 // (mean, then centred sum of squares: same two-pass form torch.var uses, no E[x^2]-m^2 cancellation).

@@ -197,6 +197,13 @@ hipError_t launch_se_scale_residual(const float* x, int ldx, int x_off, const fl
                                     int C, hipStream_t stream, uint16_t* out16 = nullptr);
 // the SE FCs and the scale + residual pass in one launch (one workgroup per utterance; same bits as the two launches)
 bool se_fc_scale_residual_supported(int T, int C, int bottleneck);
+// ... and its all-binary16 twin (x / y / out as halfs; f16 back-end)
+bool se_fc_scale_residual_f16_supported(int T, int C, int bottleneck);
+hipError_t launch_se_fc_scale_residual_f16(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
+                                           const float* w2t, const float* b2, int bottleneck, float* s,
+                                           const int* lens, const uint16_t* x16, int ldx, int x_off,
+                                           const uint16_t* y16, int ldy, uint16_t* out16, int ldo, int o_off,
+                                           hipStream_t stream);
 hipError_t launch_se_fc_scale_residual(const float* colsum, int B, int T, int C, const float* w1, const float* b1,
                                        const float* w2t, const float* b2, int bottleneck, float* s,
                                        const int* lens, const float* x, int ldx, int x_off, const float* y, int ldy,
