@@ -2139,6 +2139,27 @@ def test_bottleneck_conv3_conv1_fusion_partial_pixel_blocks(name):
     model.check_range()
 
 
+def test_campplus_direct_conv_and_tile_kernels_same_rows():
+    """conv3x3_direct_f32_kernel against the implicit-GEMM tile kernels on CAM++'s FCM head (campplus.py:245-330; maps
+    of 40 / 20 / 10 mel rows, strides (1,1) and (2,1)).  The direct kernel takes a layer from 131 072 pixels on: a
+    batch of 96 utterances runs every FCM layer on it (8 x 16-pixel patches: the 20- and 10-row maps leave the last
+    patch row partly empty, 198 / 161 frames the last patch column), batches of 4 run the same layers on the tile
+    kernels.  The same k order per pixel: the embeddings agree bit for bit; spot rows against the oracle.
+    (Round 6 measured a second patch shape, 4 x 32, for the 20- / 10-row maps: 10 - 19 % fewer patches, the same
+    launch times -- 418 vs 410 us -- because the halo DMA, not the MFMA count, sets the patch time; not kept.)"""
+    from oracle import campplus as ocam
+    sd = synth.synth_state_dict("CAMPPlus", 80, 192, seed=11)
+    model = _native("CAMPPlus", sd, 192, max_batch=96, max_frames=200)
+    for T in (198, 161):
+        f = np.random.RandomState(T).randn(96, T, 80).astype(np.float32)
+        big = model(torch.from_numpy(f)).cpu().numpy()
+        small = np.concatenate([model(torch.from_numpy(f[i:i + 4])).cpu().numpy() for i in (0, 44, 92)])
+        assert np.array_equal(big[[0, 1, 2, 3, 44, 45, 46, 47, 92, 93, 94, 95]], small), T
+        ref = ocam.campplus_forward(sd, f[[0, 95]]).numpy()
+        assert _cos_err(big[[0, 95]], ref).max() < COS_TOL and _rel_err(big[[0, 95]], ref).max() < REL_TOL, T
+    model.check_range()
+
+
 def test_res2_chain_four_wavefront_kernel_sizes():
     """res2_chain4_kernel (csrc/res2_chain4.hip; ecapa_tdnn.py:58-78): the fp32 chain of ECAPA-512 takes it when the
     batch fills the chip (> 64 utterances) and 129 <= T <= 208 -- one instantiation per number of 16-row tiles (9 .. 13).

@@ -679,6 +679,136 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
     for (int d = 0; d < DEF_STEPS; ++d) deferred_step(d, prev, true);
   }
+  // ---- Row units (round 6): the rows behind the whole rounds of tiles, INSIDE this launch.  A separate launch for
+  // the last 1 536 of ECAPA's 50 688 rows cost 16 - 25 us per N = K = 512 layer and 105 us on the 1536-wide one (a
+  // launch ramp, a cold first K-tile and an epilogue for 7 / 46 us of matrix work: DESIGN.md 4.2.4 / 4.2.6); here the
+  // workgroups that have finished their tiles take 64 x 64 units of those rows -- unit u = (64-row strip, 64-column
+  // block), 192 of them for N = 512 -- through the same LDS ring: wavefronts 0-3 own one 32 x 32 block each (the
+  // same k order per accumulator as the tiles: the same bits), all eight copy the 16-KB K-tiles (64 rows of A, 64
+  // of W) two ahead, and the block's epilogue is the tiles' (epi_step).  Column sums: the two wavefronts of a
+  // 64-row strip add their halves through LDS in a fixed order.
+  constexpr bool UNITS = WM == 4 && TN == 2 && WNP == 2 && !RES && !CONV;
+  if constexpr (UNITS) {
+    if (p.n_units > 0) {
+      // the operand stream has ended: its pieces landed, everybody is done with the stages and the scratch
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      constexpr int U_STAGE = 16 * 1024;                      // 64 rows of A + 64 rows of W, 128 B each
+      constexpr int U_SCR = 3 * U_STAGE;                      // the transpose scratch of the four block owners
+      constexpr int U_XCH = U_SCR + 4 * S_SCR_BYTES;          // column-sum exchange: [wn][cs | cq][part][8 lanes] x 16 B
+      static_assert(U_XCH + 2 * 2 * 2 * 8 * 16 <= VEC_OFF, "the unit layout ends in front of the channel vectors");
+      const int utn = p.N >> 6;
+      const bool active = wave < 4;                           // (wave-uniform) block owners
+      const int wm2 = (wave >> 1) & 1, wn2 = wave & 1;
+      const bool isw = wave >= 4;                             // wavefronts 0-3 copy the A rows, 4-7 the W rows
+      const char* const ubase = isw ? reinterpret_cast<const char*>(p.W) : reinterpret_cast<const char*>(p.A);
+      int ua[4], uw[4];
+      {
+        const int key = (li >> 1) & 7;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int pc = ((2 * g) | lh) ^ key;
+          ua[g] = (wm2 * 32 + li) * 128 + pc * 16;
+          uw[g] = 8192 + (wn2 * 32 + li) * 128 + pc * 16;
+        }
+      }
+      for (int u = remap; u < p.n_units; u += nwg) {
+        const int us = u / utn;
+        const int um0 = p.tail_begin + 64 * us, un0 = (u - us * utn) * 64;
+        unsigned uvoff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = ((wave & 3) * 2 + i) * 8 + r8;
+          const int c = c8 ^ ((row >> 1) & 7);
+          const unsigned long long lin = (unsigned long long)((isw ? un0 : um0) + row);
+          uvoff[i] = (unsigned)((lin * (isw ? p.ldw : p.lda) + (isw ? 0 : p.a_off)) * 4ull + c * 16);
+        }
+        auto udma = [&](int kt, int stage) {
+          const char* kb = ubase + (size_t)(unsigned)(kt * (S_BK * 4));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) s_dma_16B(kb + uvoff[i], ldsb + stage * U_STAGE + (wave * 2 + i) * 1024);
+        };
+        {                                                     // the channel vectors of this wavefront's 32 columns
+          int col = un0 + wn2 * 32 + (lane & 31);
+          col = col < p.N ? col : p.N - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+          const float* zero = p.zeros;
+          __builtin_amdgcn_global_load_lds(p.bias ? p.bias + col : zero, (__attribute__((address_space(3))) void*)vec_w, 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(p.post_scale ? p.post_scale + col : zero,
+                                           (__attribute__((address_space(3))) void*)(vec_w + 256), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(p.post_scale ? p.post_shift + col : zero,
+                                           (__attribute__((address_space(3))) void*)(vec_w + 512), 4, 0, 0);
+#endif
+        }
+        udma(0, 0);
+        udma(1, 1);                                           // (nk >= 4)
+        s_wait_lds_vm_barrier<2>();                           // K-tile 0 (and everything older) landed
+        f32x16 uacc = {};
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+          const int pst = st == 0 ? 2 : st - 1;
+          udma(kt + 2 < nk ? kt + 2 : nk - 1, pst);           // (past the end: the last K-tile again, uniform counts)
+          if (active) {
+            const char* sb = ldsb + st * U_STAGE;
+            f32x4 xa[4], xw[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                     // all eight reads first (LDS answers in order: the
+              xa[g] = *reinterpret_cast<const f32x4*>(sb + ua[g]);   // MFMAs of group g wait for 2 g + 2 of them)
+              xw[g] = *reinterpret_cast<const f32x4*>(sb + uw[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                uacc = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[g][e], xa[g][e], uacc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          s_wait_lds_vm_barrier<2>();                         // K-tile kt + 1 landed, everybody left stage st
+          st = st == 2 ? 0 : st + 1;
+        }
+        TileOut ut = {};
+        ut.vec = reinterpret_cast<const float*>(vec_w);
+        ut.nblk = un0 + wn2 * 32;
+        ut.ncol = ut.nblk + c8 * 4;
+        ut.dvoff = (unsigned)(((unsigned long long)(um0 + r8) * p.ldd + p.d_off + ut.ncol) * 4ull);
+        ut.d2voff = p.D2 ? (unsigned)(((unsigned long long)(um0 + r8) * p.ldd2 + p.d2_off + ut.ncol - p.d2_col0) * 4ull) : 0u;
+        ut.rb = COLSUM ? (um0 / HW + 1) * HW - um0 : 64;
+        ut.t64 = um0 >> 6;
+        if (active) {
+          scr = reinterpret_cast<float*>(ldsb + U_SCR + wave * S_SCR_BYTES);
+#pragma unroll
+          for (int step = 0; step < 15; ++step) epi_step(step, wm2, 0, ut, uacc, true);
+          colsum_step(0, ut);
+          colsum_step(1, ut);
+          colsum_step(2, ut);
+        }
+        if (COLSUM) {
+          f32x4* const xch = reinterpret_cast<f32x4*>(ldsb + U_XCH) + wn2 * 32;      // [cs | cq][part][c8]
+          if (active && wm2 == 1 && r8 == 0) {
+            xch[c8] = cs[0][0];
+            xch[8 + c8] = cs[0][1];
+            if (COLSUM == 2) {
+              xch[16 + c8] = cq[0][0];
+              xch[24 + c8] = cq[0][1];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (active && wm2 == 0 && r8 == 0) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              *reinterpret_cast<f32x4*>(p.colsum + ((size_t)ut.t64 * 2 + w) * p.N + ut.ncol) = cs[0][w] + xch[8 * w + c8];
+              if (COLSUM == 2)
+                *reinterpret_cast<f32x4*>(p.colsumsq + ((size_t)ut.t64 * 2 + w) * p.N + ut.ncol) =
+                    cq[0][w] + xch[16 + 8 * w + c8];
+            }
+          }
+          cs[0][0] = cs[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          cq[0][0] = cq[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // (the next unit's first barrier orders these exchange reads in front of its writers)
+        }
+      }
+    }
+  }
   // drain the DMA pieces that ran past the end of the stream before the LDS goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -703,6 +833,8 @@ hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) 
 // env WS_STREAM: 0 off; 1 = 128x128 tile, four wavefronts; 2 = 128x128 tile, eight wavefronts; 3 = 256x128 tile,
 // eight wavefronts; 4 (default) = 2 or 3, whichever the cost model below prefers for the problem
 int g_ws_stream = -1;
+// 0: the rows behind the whole rounds go to the tile kernels as before round 6 (A/B probe)
+int g_ws_stream_units = 1;
 
 #ifdef WS_TRACE
 unsigned long long* stream_trace_buffer_address() {
@@ -714,7 +846,7 @@ unsigned long long* stream_trace_buffer_address() {
 
 namespace {
 // Cycles per K-tile of one tile (measured, steady state) and the per-tile overhead of the first / last K-tile.
-struct StreamPlan { int mode, bm, rows; long long cycles; };
+struct StreamPlan { int mode, bm, rows; long long cycles; int main_rows; };
 // mode 5 (round 5): the 256 x 64 tile of the 64-channel layers, eight wavefronts of 64 x 32 (per wavefront the work of
 // mode 2: 32 MFMAs per K-tile)
 constexpr int bn_of(int mode) { return mode == 5 ? 64 : 128; }
@@ -723,13 +855,16 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
   const long long per_kt = mode == 3 ? 8500 : 4400, per_tile = mode == 3 ? 5500 : 2500;
   const long long tiles_n = p.N / S_BN, tiles_m = (p.M - p.m_begin) / bm, nk = p.K / S_BK;
   const long long total = tiles_m * tiles_n, rounds = total / cus;
-  StreamPlan pl = {mode, bm, 0, 0};
+  StreamPlan pl = {mode, bm, 0, 0, 0};
   if (rounds < 2) return pl;
   const long long tile_time = nk * per_kt + per_tile;
   long long main_tiles_m = rounds * cus / tiles_n;
   // The tiles beyond the whole rounds: one more (partial) round here costs a whole tile time; as 64x64 tiles on the
   // tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the kernel boundary they cost
   // ceil(rem64 / 512) rounds -- take the cheaper.  Rows beyond the last whole tile row always go there.
+  // Round 6: the plain 256x128 form takes whole 64-row strips of those rows itself, as 64 x 64 units behind its
+  // tiles (~1400 cycles per K-tile and round of `cus` units); only a last partial strip is left to the tile kernel.
+  const bool units = g_ws_stream_units != 0 && mode == 3 && p.kh == 1 && !p.residual;
   const long long rem = total - main_tiles_m * tiles_n;
   const long long rest_rows = (p.M - p.m_begin) - tiles_m * bm;
   auto tile_kernel = [&](long long rows) {
@@ -737,16 +872,22 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
     const long long t64 = (rows + 63) / 64 * ((p.N + 63) / 64);
     return (t64 + 2 * cus - 1) / (2 * cus) * nk * 2600 + 12000;
   };
+  auto beyond = [&](long long rows) {
+    if (!units) return tile_kernel(rows);
+    const long long strips = rows / 64, n_units = strips * (p.N / 64);
+    return (n_units + cus - 1) / cus * (nk * 1400 + 4000) + tile_kernel(rows - strips * 64);
+  };
   long long cyc = (main_tiles_m * tiles_n / cus) * tile_time;
-  const long long here = tile_time + tile_kernel(rest_rows);
-  const long long there = tile_kernel((tiles_m - main_tiles_m) * bm + rest_rows);
+  const long long here = tile_time + beyond(rest_rows);
+  const long long there = beyond((tiles_m - main_tiles_m) * bm + rest_rows);
   if (rem > 0 && here <= there) {
     main_tiles_m = tiles_m;
     cyc += here;
   } else {
     cyc += there;
   }
-  pl.rows = (int)(main_tiles_m * bm);
+  pl.main_rows = (int)(main_tiles_m * bm);
+  pl.rows = pl.main_rows + (units ? (int)(((p.M - p.m_begin) - pl.main_rows) / 64 * 64) : 0);
   pl.cycles = cyc;
   return pl;
 }
@@ -817,14 +958,19 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
   ConvGemmParams p = p0;
   const StreamPlan pl = plan(p0, cus);
   if (pl.rows != rows) return hipErrorInvalidValue;      // (rows must come from gemm_f32_stream_rows)
-  p.tail_begin = p.m_begin + rows;
+  p.tail_begin = p.m_begin + pl.main_rows;               // the first row of the 64 x 64 units
+  p.n_units = (rows - pl.main_rows) / 64 * (p.N / 64);
   const int mode = pl.mode, bm = pl.bm;
-  p.n_big = rows / bm * (p.N / bn_of(mode));
+  p.n_big = pl.main_rows / bm * (p.N / bn_of(mode));
   const int grid = p.n_big < cus ? p.n_big : cus;
   if (dispatch_log_enabled()) {
     char k[96];
-    snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx%d tile, %d waves%s> tiles=%d", bm, bn_of(mode), mode == 1 ? 4 : 8,
-             p.kh == 3 ? ", conv" : "", p.n_big);
+    if (p.n_units)
+      snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx%d tile, %d waves> tiles=%d + %d 64x64 units", bm, bn_of(mode),
+               mode == 1 ? 4 : 8, p.n_big, p.n_units);
+    else
+      snprintf(k, sizeof(k), "gemm_f32_stream_kernel<%dx%d tile, %d waves%s> tiles=%d", bm, bn_of(mode), mode == 1 ? 4 : 8,
+               p.kh == 3 ? ", conv" : "", p.n_big);
     dispatch_log_note(p, k);
   }
   const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);

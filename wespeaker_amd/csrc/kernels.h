@@ -108,6 +108,8 @@ struct ConvGemmParams {
   int n_big, tail_begin;                      // set by the dispatcher (conv_gemm_dual_kernel): workgroups
                                               // [0, n_big) run 128x128 tiles over rows [m_begin, tail_begin),
                                               // the others 64x64 tiles over rows [tail_begin, M)
+  int n_units;                                // set by launch_gemm_f32_stream: 64x64 row units over the rows
+                                              // [tail_begin, tail_begin + 64 * n_units / (N / 64)) behind its tiles
 };
 hipError_t launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 
