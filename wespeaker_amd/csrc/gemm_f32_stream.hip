@@ -169,6 +169,17 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   }
   if (remap >= n_tiles) return;
   const int my_nt = (n_tiles - remap + nwg - 1) / nwg;
+  // MASK (round 6): a ragged batch of 1-D maps (ConvGemmParams::row_len; ECAPA's layers: Hout = 1, Wout = T >= 64) --
+  // rows at or beyond their utterance's own frame count are stored as zeros, like the tile kernels do.  The batch's
+  // lengths (<= 1024 of them) are copied into the last 4 KB of LDS once, before the operand stream starts; an
+  // epilogue reads the two lengths its 64-row half can touch.
+  constexpr bool MASK = !RES && !CONV;
+  int* const lens_s = reinterpret_cast<int*>(ldsb + VEC_OFF + NW * VEC_WAVE_BYTES);
+  const int nimg = MASK && p.row_len ? p.M / HW : 0;
+  if (MASK && p.row_len) {
+    for (int i = tid; i < nimg; i += 64 * NW) lens_s[i] = p.row_len[i];
+    __syncthreads();                         // (waits for the loads too: nothing of the stream is in flight yet)
+  }
   auto tile_of = [&](int seq, int& m0, int& n0) {
     const int work = seq * nwg + remap;
     const int tm = work / tiles_n;
@@ -342,6 +353,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     int nblk;              // n0 + wn*32*TN (wave-uniform)
     int rb;                // rows of the wavefront's 64-row half that belong to its first image
     int t64;               // (m0 + wm*64) / 64
+    int img0, ox0;         // MASK: the first image of the half and the frame its row 0 is
   };
   TileOut cur = {}, prev = {};
   bool pending = false;                      // DEFER: `prev`'s last block is waiting in ev[]
@@ -355,8 +367,10 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     t.dvoff = (unsigned)(((unsigned long long)(mh + r8) * p.ldd + p.d_off + t.ncol) * 4ull);
     t.d2voff = p.D2 ? (unsigned)(((unsigned long long)(mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4ull) : 0u;
     t.rvoff = RES ? (unsigned)(((unsigned long long)(mh + r8) * p.ldr + p.r_off + t.ncol) * 4ull) : 0u;
-    t.rb = COLSUM ? (mh / HW + 1) * HW - mh : 64;
+    t.rb = COLSUM || (MASK && p.row_len) ? (mh / HW + 1) * HW - mh : 64;
     t.t64 = mh >> 6;
+    t.img0 = mh / HW;
+    t.ox0 = mh - t.img0 * HW;
   };
   f32x4 cs[TN][2];                           // column sums of the stored values: [block column][image part]
   f32x4 cq[COLSUM == 2 ? TN : 1][2];         // ... and of their squares (the context std of the pooling layer)
@@ -365,6 +379,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
   for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
+  int len0 = 0, len1 = 0;                    // MASK: frame counts of the half's first / second image
   f32x4 rres[RES ? 2 * TN : 1][4];           // RES: the residual rows of all blocks of the tile ([im * TN + in][i])
   constexpr int NRES = RES ? 2 * TN * 4 : 0;
   auto res_load = [&](int j, const TileOut& t) {           // j = (im * TN + in) * 4 + i
@@ -396,6 +411,10 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       vb = *reinterpret_cast<const f32x4*>(&t.vec[n]);
       vs = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[64 + n]) : (f32x4){1.f, 1.f, 1.f, 1.f};
       vt = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[128 + n]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MASK && p.row_len) {
+        len0 = lens_s[t.img0];
+        len1 = lens_s[t.img0 + 1 < nimg ? t.img0 + 1 : nimg - 1];
+      }
     } else if (step >= 5 && step <= 8) {
       const int i = step - 5;
       f32x4 v = ev[i] + vb;
@@ -407,6 +426,11 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         v[e] = __int_as_float(__builtin_elementwise_max(__float_as_int(f), relu_bits));
       }
       ev[i] = v * vs + vt;
+      if (MASK && p.row_len) {               // (a 64-row half touches at most two utterances: Wout >= 64)
+        const int rr = im * 32 + 8 * i + r8;
+        const bool ok = rr < t.rb ? t.ox0 + rr < len0 : rr - t.rb < len1;
+        if (!ok) ev[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     } else if (step >= 9 && step <= 12) {
       const int i = step - 9;
       const int srow = im * 32 + 8 * i;
@@ -772,8 +796,10 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         ut.ncol = ut.nblk + c8 * 4;
         ut.dvoff = (unsigned)(((unsigned long long)(um0 + r8) * p.ldd + p.d_off + ut.ncol) * 4ull);
         ut.d2voff = p.D2 ? (unsigned)(((unsigned long long)(um0 + r8) * p.ldd2 + p.d2_off + ut.ncol - p.d2_col0) * 4ull) : 0u;
-        ut.rb = COLSUM ? (um0 / HW + 1) * HW - um0 : 64;
+        ut.rb = COLSUM || p.row_len ? (um0 / HW + 1) * HW - um0 : 64;
         ut.t64 = um0 >> 6;
+        ut.img0 = um0 / HW;
+        ut.ox0 = um0 - ut.img0 * HW;
         if (active) {
           scr = reinterpret_cast<float*>(ldsb + U_SCR + wave * S_SCR_BYTES);
 #pragma unroll
@@ -818,7 +844,7 @@ hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) 
   constexpr int NW = WM * WNP, BN = 32 * TN * WNP, NP = (8 * WM + BN / 8) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
   constexpr size_t lds_bytes = (size_t)3 * (64 * WM + BN) * S_BK * 4 + (alias ? 0 : (size_t)NW * S_SCR_BYTES) +
-                               (size_t)NW * 2 * 3 * 64 * 4;
+                               (size_t)NW * 2 * 3 * 64 * 4 + (!RES && !CONV ? 4096 : 0);   // (+ a ragged batch's lengths)
   static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV, WNP>;
@@ -928,9 +954,11 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   }
   if (g_ws_stream <= 0) return 0;
   const bool conv3 = gemm_f32_stream_is_conv3(p);
+  // a ragged batch: 1-D maps of >= 64 frames, at most 1024 utterances, no residual (the kernel's MASK)
+  const bool mask_ok = !p.row_len || (p.Hout == 1 && p.Wout >= 64 && p.M / p.Wout <= 1024 && !p.residual);
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
-                     !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial &&
+                     !p.bias_img && !p.residual16 && mask_ok && !p.seg_scale && !p.pool_partial &&
                      p.splitk <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU);
   if (!plain && !conv3) return 0;
   // the convolution form: the 256-row tiles, no column sums (rows behind the last whole tile go to the tile kernels
