@@ -2097,17 +2097,21 @@ def test_ragged_forward_rows_equal_the_batch1_oracle(name, E, lens, prec):
         model.embed_ragged(torch.from_numpy(pad), [0] + lens[1:])                   # shorter than the model minimum
 
 
-@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512"])
-def test_full_size_ragged_batch_on_the_persistent_kernel(name):
-    """A ragged batch big enough for the persistent fp32 GEMM (gemm_f32_stream.hip, MASK: rows at or beyond their
-    utterance's own frame count are stored as zeros in its epilogue, tiles and 64x64 row units alike; until round 6
-    every ragged batch ran on the tile kernels).  256 utterances of 70 .. 230 frames in 230-frame slots, NaN in the
-    padding: spot rows against the batch-1 oracle (the reference's whole-utterance mode, bin/extract.py:95) and
-    against the engine's own uniform batch-1 forward on that utterance alone (tile kernels: a batch of one never
-    reaches the persistent kernel)."""
-    sd = synth.synth_state_dict(name, 80, 192, seed=42)
+@pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 192), ("ECAPA_TDNN_c512", 192), ("ResNet34", 256),
+                                    ("ResNet221", 256)])
+def test_full_size_ragged_batch_on_the_persistent_kernel(name, E):
+    """A ragged batch big enough for the persistent fp32 GEMM (gemm_f32_stream.hip, MASK: output pixels at or beyond
+    their utterance's own width are stored as zeros in its epilogue -- tiles and 64x64 row units, the plain forms at
+    run time, the residual / 3x3 forms as masked twins; until round 6 every ragged batch ran on the tile kernels).
+    256 utterances of 70 .. 230 frames in 230-frame slots, NaN in the padding: spot rows against the batch-1 oracle
+    (the reference's whole-utterance mode, bin/extract.py:95) and against the engine's own uniform batch-1 forward on
+    that utterance alone (tile kernels: a batch of one never reaches the persistent kernel)."""
+    from oracle import resnet as oresnet
+    sd = synth.synth_state_dict(name, 80, E, seed=42)
     B, TMAX = 256, 230
-    model = _native(name, sd, 192, max_batch=B, max_frames=TMAX)
+    model = _native(name, sd, E, max_batch=B, max_frames=TMAX)
+    fwd = (lambda f: oecapa.ecapa_forward(sd, f).numpy()) if name.startswith("ECAPA") else \
+          (lambda f: oresnet.resnet_forward(sd, f, name).numpy())
     rng = np.random.RandomState(3)
     lens = rng.randint(70, TMAX + 1, size=B)
     lens[0], lens[1], lens[B - 1] = TMAX, 70, 199           # a full slot, the shortest, a strip-boundary case
@@ -2124,9 +2128,9 @@ def test_full_size_ragged_batch_on_the_persistent_kernel(name):
         out = model(torch.from_numpy(feats[i][None]))
         one = (out[-1] if isinstance(out, tuple) else out).cpu().numpy()
         assert _rel_err(got[i:i + 1], one).max() < 1e-5, (i, lens[i])
-    ref = _oracle_rows(lambda f: oecapa.ecapa_forward(sd, f).numpy(), [feats[i] for i in rows[:3]])
-    assert _cos_err(got[rows[:3]], ref).max() < COS_TOL and _rel_err(got[rows[:3]], ref).max() < REL_TOL
-    # the dispatcher really sent the masked layers to the persistent kernel
+    ref = _oracle_rows(fwd, [feats[i] for i in rows[:2]])
+    assert _cos_err(got[rows[:2]], ref).max() < COS_TOL and _rel_err(got[rows[:2]], ref).max() < REL_TOL
+    # the dispatcher really sent masked layers to the persistent kernel
     from wespeaker_amd.engine import dispatch_log, dispatch_report
     dispatch_log(True, clear=True)
     try:
@@ -2134,7 +2138,10 @@ def test_full_size_ragged_batch_on_the_persistent_kernel(name):
         lines = dispatch_report()
     finally:
         dispatch_log(False, clear=True)
-    assert any("+mask" in l and "gemm_f32_stream_kernel" in l for l in lines), lines[:8]
+    hits = [l for l in lines if "+mask" in l and "gemm_f32_stream_kernel" in l]
+    assert hits, lines[:8]
+    if name == "ResNet221":                                 # 3x3, residual and plain 1x1 forms
+        assert any("conv" in l for l in hits) and any("+res" in l for l in hits), hits
 
 
 @pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 100), ("ResNet18", 37), ("CAMPPlus", 200)])

@@ -108,7 +108,9 @@ __device__ __forceinline__ void s_wait_lds_vm_barrier() {
 // operation, which the vmcnt arithmetic of the barriers relies on.
 // WNP (round 5): wavefront columns, 4 / TN (a 128-column tile) unless given: <4, 1, .., 2> is eight wavefronts of
 // 64 x 32 over a 256 x 64 tile for the 64-channel layers (ResNet stage 2 / the 64-plane bottleneck layers).
-template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
+// MASKT (round 6): the RES / CONV forms of a ragged batch (ConvGemmParams::row_len) are instantiations of their own
+// (those forms have no registers to spare: the uniform ones stay what they were); the plain forms mask at run time.
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN, bool MASKT = false>   // COLSUM: 0 none, 1 column sums, 2 + sums of squares
 __global__ __launch_bounds__(64 * WM * WNP, WM * WNP / 4)
 void gemm_f32_stream_kernel(const ConvGemmParams p) {
   constexpr int WN = WNP;                    // wavefront columns
@@ -169,17 +171,33 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   }
   if (remap >= n_tiles) return;
   const int my_nt = (n_tiles - remap + nwg - 1) / nwg;
-  // MASK (round 6): a ragged batch of 1-D maps (ConvGemmParams::row_len; ECAPA's layers: Hout = 1, Wout = T >= 64) --
-  // rows at or beyond their utterance's own frame count are stored as zeros, like the tile kernels do.  The batch's
-  // lengths (<= 1024 of them) are copied into the last 4 KB of LDS once, before the operand stream starts; an
-  // epilogue reads the two lengths its 64-row half can touch.
-  constexpr bool MASK = !RES && !CONV;
+  // MASK (round 6): a ragged batch (ConvGemmParams::row_len) -- output pixels at or beyond their utterance's own width
+  // are stored as zeros, like the tile kernels do.  The batch's widths (<= 1024 of them) are copied into the last
+  // 4 KB of LDS once, before the operand stream starts; at the start of a tile a lane works out which of its eight
+  // rows (r8 + 8 i + 32 im of the wavefront's 64-row half) are real -- two integer divisions for the first row, the
+  // others by stepping (image size >= 8 pixels, width >= 8) -- and keeps one bit per row; the epilogue selects.
+  const bool masked = MASKT || (!RES && !CONV && p.row_len != nullptr);
   int* const lens_s = reinterpret_cast<int*>(ldsb + VEC_OFF + NW * VEC_WAVE_BYTES);
-  const int nimg = MASK && p.row_len ? p.M / HW : 0;
-  if (MASK && p.row_len) {
+  const int nimg = masked ? p.M / HW : 0;
+  if (masked) {
     for (int i = tid; i < nimg; i += 64 * NW) lens_s[i] = p.row_len[i];
     __syncthreads();                         // (waits for the loads too: nothing of the stream is in flight yet)
   }
+  auto row_mask = [&](int mh) {              // bit (4 im + i): row mh + 32 im + 8 i + r8 is inside its utterance
+    const int m = mh + r8;
+    int img = m / HW, rem = m - img * HW;
+    int ox = rem - (rem / p.Wout) * p.Wout;
+    unsigned mk = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mk |= (ox < lens_s[img < nimg ? img : nimg - 1] ? 1u : 0u) << j;
+      rem += 8;
+      ox += 8;
+      if (rem >= HW) { rem -= HW; ++img; ox = rem; }      // (rem < 8 <= Wout behind the wrap)
+      else if (ox >= p.Wout) ox -= p.Wout;
+    }
+    return mk;
+  };
   auto tile_of = [&](int seq, int& m0, int& n0) {
     const int work = seq * nwg + remap;
     const int tm = work / tiles_n;
@@ -353,7 +371,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     int nblk;              // n0 + wn*32*TN (wave-uniform)
     int rb;                // rows of the wavefront's 64-row half that belong to its first image
     int t64;               // (m0 + wm*64) / 64
-    int img0, ox0;         // MASK: the first image of the half and the frame its row 0 is
+    unsigned okmask;       // MASK: bit (4 im + i) = row 32 im + 8 i + r8 of the half lies inside its utterance
   };
   TileOut cur = {}, prev = {};
   bool pending = false;                      // DEFER: `prev`'s last block is waiting in ev[]
@@ -367,10 +385,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
     t.dvoff = (unsigned)(((unsigned long long)(mh + r8) * p.ldd + p.d_off + t.ncol) * 4ull);
     t.d2voff = p.D2 ? (unsigned)(((unsigned long long)(mh + r8) * p.ldd2 + p.d2_off + t.ncol - p.d2_col0) * 4ull) : 0u;
     t.rvoff = RES ? (unsigned)(((unsigned long long)(mh + r8) * p.ldr + p.r_off + t.ncol) * 4ull) : 0u;
-    t.rb = COLSUM || (MASK && p.row_len) ? (mh / HW + 1) * HW - mh : 64;
+    t.rb = COLSUM ? (mh / HW + 1) * HW - mh : 64;
     t.t64 = mh >> 6;
-    t.img0 = mh / HW;
-    t.ox0 = mh - t.img0 * HW;
+    t.okmask = masked ? row_mask(mh) : 0xffu;
   };
   f32x4 cs[TN][2];                           // column sums of the stored values: [block column][image part]
   f32x4 cq[COLSUM == 2 ? TN : 1][2];         // ... and of their squares (the context std of the pooling layer)
@@ -379,7 +396,6 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
   for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
-  int len0 = 0, len1 = 0;                    // MASK: frame counts of the half's first / second image
   f32x4 rres[RES ? 2 * TN : 1][4];           // RES: the residual rows of all blocks of the tile ([im * TN + in][i])
   constexpr int NRES = RES ? 2 * TN * 4 : 0;
   auto res_load = [&](int j, const TileOut& t) {           // j = (im * TN + in) * 4 + i
@@ -411,10 +427,6 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
       vb = *reinterpret_cast<const f32x4*>(&t.vec[n]);
       vs = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[64 + n]) : (f32x4){1.f, 1.f, 1.f, 1.f};
       vt = has_post ? *reinterpret_cast<const f32x4*>(&t.vec[128 + n]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MASK && p.row_len) {
-        len0 = lens_s[t.img0];
-        len1 = lens_s[t.img0 + 1 < nimg ? t.img0 + 1 : nimg - 1];
-      }
     } else if (step >= 5 && step <= 8) {
       const int i = step - 5;
       f32x4 v = ev[i] + vb;
@@ -426,17 +438,14 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         v[e] = __int_as_float(__builtin_elementwise_max(__float_as_int(f), relu_bits));
       }
       ev[i] = v * vs + vt;
-      if (MASK && p.row_len) {               // (a 64-row half touches at most two utterances: Wout >= 64)
-        const int rr = im * 32 + 8 * i + r8;
-        const bool ok = rr < t.rb ? t.ox0 + rr < len0 : rr - t.rb < len1;
-        if (!ok) ev[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+      if (masked && !((t.okmask >> (4 * im + i)) & 1u)) ev[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     } else if (step >= 9 && step <= 12) {
       const int i = step - 9;
       const int srow = im * 32 + 8 * i;
       const int so = (srow * p.ldd + in * 32) * 4, so2 = (srow * p.ldd2 + in * 32) * 4;
       // (the four-wavefront form too: hipcc sinks its rows' maths behind the previous row's stores inside one MFMA gap)
-      const bool voff_form = tail || NW == 4;
+      // (... and the masked RES / CONV twins: their select leaves a VALU write of ev[] next to a store; build.check_isa found it)
+      const bool voff_form = tail || NW == 4 || MASKT;
       if (voff_form) __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff + so, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b128(ev[i], d_rsrc, t.dvoff, so, 0);
       // (d2_col0 is a multiple of 32: a 32-column block goes to D2 as a whole -- a wave-uniform branch)
@@ -796,10 +805,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         ut.ncol = ut.nblk + c8 * 4;
         ut.dvoff = (unsigned)(((unsigned long long)(um0 + r8) * p.ldd + p.d_off + ut.ncol) * 4ull);
         ut.d2voff = p.D2 ? (unsigned)(((unsigned long long)(um0 + r8) * p.ldd2 + p.d2_off + ut.ncol - p.d2_col0) * 4ull) : 0u;
-        ut.rb = COLSUM || p.row_len ? (um0 / HW + 1) * HW - um0 : 64;
+        ut.rb = COLSUM ? (um0 / HW + 1) * HW - um0 : 64;
         ut.t64 = um0 >> 6;
-        ut.img0 = um0 / HW;
-        ut.ox0 = um0 - ut.img0 * HW;
+        ut.okmask = masked ? row_mask(um0) : 0xffu;
         if (active) {
           scr = reinterpret_cast<float*>(ldsb + U_SCR + wave * S_SCR_BYTES);
 #pragma unroll
@@ -839,15 +847,15 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN>
+template <int WM, int TN, int COLSUM, bool RES = false, bool CONV = false, int WNP = 4 / TN, bool MASKT = false>
 hipError_t launch_stream(const ConvGemmParams& p, int grid, hipStream_t stream) {
   constexpr int NW = WM * WNP, BN = 32 * TN * WNP, NP = (8 * WM + BN / 8) / NW;
   constexpr bool alias = NP * 1024 >= S_SCR_BYTES;
   constexpr size_t lds_bytes = (size_t)3 * (64 * WM + BN) * S_BK * 4 + (alias ? 0 : (size_t)NW * S_SCR_BYTES) +
-                               (size_t)NW * 2 * 3 * 64 * 4 + (!RES && !CONV ? 4096 : 0);   // (+ a ragged batch's lengths)
+                               (size_t)NW * 2 * 3 * 64 * 4 + (MASKT || (!RES && !CONV) ? 4096 : 0);   // (+ a ragged batch's widths)
   static_assert(lds_bytes <= 160 * 1024, "LDS budget");
   static size_t lds_granted[WS_MAX_DEVICES] = {};
-  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV, WNP>;
+  auto kern = gemm_f32_stream_kernel<WM, TN, COLSUM, RES, CONV, WNP, MASKT>;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, stream, p);
@@ -921,6 +929,7 @@ StreamPlan plan(const ConvGemmParams& p, int cus) {
   const int m = g_ws_stream;
   if (p.N % 128 != 0) return plan_mode(p, cus, 5);       // (N % 64 == 0: the 256x64 tile)
   if (p.kh == 3) return plan_mode(p, cus, 3);            // (the convolution form exists for the 256-row tiles only)
+  if (p.row_len && p.residual) return plan_mode(p, cus, 3);      // (ragged + residual: instantiated for that tile only)
   if (m >= 1 && m <= 3) return plan_mode(p, cus, m);
   const StreamPlan a = plan_mode(p, cus, 2), b = plan_mode(p, cus, 3);
   if (!b.rows) return a;
@@ -938,7 +947,8 @@ bool gemm_f32_stream_is_conv3(const ConvGemmParams& p) {
   return g_ws_stream_conv != 0 && p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 3 && p.kw == 3 &&
          p.stride_h == 1 && p.stride_w == 1 && p.pad_h == 1 && p.pad_w == 1 && p.dil_h == 1 && p.dil_w == 1 &&
          p.Hin == p.Hout && p.Win == p.Wout && p.Cin % S_BK == 0 && p.K == 9 * p.Cin && p.D && !p.D16 && !p.D2_16 &&
-         !p.bias_img && !p.residual16 && !p.row_len && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
+         !p.bias_img && !p.residual16 && !p.seg_scale && !p.pool_partial && p.splitk <= 1 &&
+         (!p.row_len || (p.Wout >= 8 && p.M / (p.Hout * p.Wout) <= 1024)) &&      // (ragged: the kernel's MASK)
          (p.act == ACT_NONE || p.act == ACT_RELU) && p.a_zero_off > 0 &&
          p.Cin <= 512 &&     // (the zero pad behind an activation buffer is 512 floats: resnet_model.hip reserve())
          (long long)p.M * p.lda * 4 + ((long long)p.Win + 2) * p.lda * 4 < (1LL << 32) &&
@@ -954,8 +964,8 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
   }
   if (g_ws_stream <= 0) return 0;
   const bool conv3 = gemm_f32_stream_is_conv3(p);
-  // a ragged batch: 1-D maps of >= 64 frames, at most 1024 utterances, no residual (the kernel's MASK)
-  const bool mask_ok = !p.row_len || (p.Hout == 1 && p.Wout >= 64 && p.M / p.Wout <= 1024 && !p.residual);
+  // a ragged batch (the kernel's MASK): at most 1024 utterances, maps of >= 8 pixels and >= 8 columns
+  const bool mask_ok = !p.row_len || (p.Hout * p.Wout >= 8 && p.Wout >= 8 && p.M / (p.Hout * p.Wout) <= 1024);
   const bool plain = p.prec == 0 && !p.A16 && !p.A2 && !p.pre_scale && p.kh == 1 && p.kw == 1 && p.stride_h == 1 &&
                      p.stride_w == 1 && p.pad_h == 0 && p.pad_w == 0 && p.K == p.Cin && p.D && !p.D16 && !p.D2_16 &&
                      !p.bias_img && !p.residual16 && mask_ok && !p.seg_scale && !p.pool_partial &&
@@ -1002,18 +1012,25 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
     dispatch_log_note(p, k);
   }
   const int cs = !p.colsum ? 0 : (p.colsumsq ? 2 : 1);
+  const bool mk = p.row_len != nullptr;          // a ragged batch: the RES / CONV forms have masked twins (MASKT)
   if (mode == 5) {
-    if (p.kh == 3)
+    if (p.kh == 3) {
+      if (mk) return p.residual ? launch_stream<4, 1, 0, true, true, 2, true>(p, grid, stream)
+                                : launch_stream<4, 1, 0, false, true, 2, true>(p, grid, stream);
       return p.residual ? launch_stream<4, 1, 0, true, true, 2>(p, grid, stream)
                         : launch_stream<4, 1, 0, false, true, 2>(p, grid, stream);
+    }
     return p.residual ? hipErrorInvalidValue : launch_stream<4, 1, 0, false, false, 2>(p, grid, stream);
   }
   if (p.kh == 3) {
     if (mode != 3) return hipErrorInvalidValue;
+    if (mk) return p.residual ? launch_stream<4, 2, 0, true, true, 2, true>(p, grid, stream)
+                              : launch_stream<4, 2, 0, false, true, 2, true>(p, grid, stream);
     return p.residual ? launch_stream<4, 2, 0, true, true>(p, grid, stream)
                       : launch_stream<4, 2, 0, false, true>(p, grid, stream);
   }
   if (p.residual) {
+    if (mk) return mode == 3 ? launch_stream<4, 2, 0, true, false, 2, true>(p, grid, stream) : hipErrorInvalidValue;
     if (mode == 2) return launch_stream<2, 1, 0, true>(p, grid, stream);
     if (mode == 3) return launch_stream<4, 2, 0, true>(p, grid, stream);
     return hipErrorInvalidValue;
