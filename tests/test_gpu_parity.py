@@ -2170,8 +2170,8 @@ def test_bottleneck_conv3_conv1_fusion_partial_pixel_blocks(name):
     """bneck_c3c1_kernel (csrc/bneck_fuse.hip; resnet.py:72-107): conv3 + residual + ReLU of a Bottleneck block and conv1 +
     ReLU of the next block in one launch (fp32, stages 1 - 2, incl. the stage 1 -> 2 transition).  A wavefront owns 32
     pixels; ONE utterance of an odd number of frames makes the pixel count 16 (mod 32) in both stages, so the last
-    block of pixels is half empty (dropped by the buffer bounds).  Against the oracle; and a ragged batch -- which
-    stays on the unfused kernels -- gives the same rows."""
+    block of pixels is half empty (dropped by the buffer bounds).  Against the oracle; and the ragged entry point with
+    the same lengths -- the kernel's masked twin -- gives the same rows."""
     from oracle import resnet as oresnet
     sd = synth.synth_resnet_state_dict(name, 80, 256, seed=42)
     model = _native(name, sd, 256, max_batch=4, max_frames=200)
@@ -2181,7 +2181,7 @@ def test_bottleneck_conv3_conv1_fusion_partial_pixel_blocks(name):
         got = model(torch.from_numpy(f))[-1].cpu().numpy()
         ref = oresnet.resnet_forward(sd, f, name).numpy()
         assert _cos_err(got, ref).max() < COS_TOL and _rel_err(got, ref).max() < REL_TOL, (B, T)
-        rag = model.embed_ragged(torch.from_numpy(f), [T] * B).cpu().numpy()      # per-utterance lengths: unfused path
+        rag = model.embed_ragged(torch.from_numpy(f), [T] * B).cpu().numpy()      # per-utterance lengths: the masked twin
         assert _rel_err(rag, got).max() < 1e-5, (B, T)
     model.check_range()
 

@@ -30,7 +30,10 @@ typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
 // P = 32: 256 threads, four workgroups per CU (33 KB of LDS each); P = 64: the two weight matrices fill 129 KB -- one
 // workgroup of 512 threads per CU
 // PN: planes of the NEXT block (= P inside a stage, 2 P at the stage 1 -> 2 transition)
-template <int P, int PN, int NT, int MINB>
+// MASKT: a ragged batch (BneckFuseParams::row_len) -- pixels at or beyond their utterance's own width are stored as
+// zeros in BOTH outputs (the next block's conv1 of a zero pixel would be relu(bias)); the batch's widths sit in LDS
+// behind the biases, a lane works out once per block of pixels whether ITS pixel is real (two integer divisions).
+template <int P, int PN, int NT, int MINB, bool MASKT = false>
 __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFuseParams p) {
   constexpr int NWV = NT / 64;
   constexpr int CX = 4 * P, OB = CX / 32, OB2 = PN / 32, KS3 = P / 2;
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFusePar
   float* const W1l = W3l + OB * KS3 * 64;                  // [OB2][OB][4][64][4]
   float* const b3l = W1l + OB2 * OB * 16 * 64;             // [CX]
   float* const b1l = b3l + CX;                             // [PN]
+  int* const lens_l = reinterpret_cast<int*>(b1l + PN);    // MASKT: [M / HW <= 1024]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   // ---- weights into LDS in consumption order
@@ -54,6 +58,9 @@ __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFusePar
   }
   for (int i = tid; i < CX; i += NT) b3l[i] = p.b3 ? p.b3[i] : 0.f;
   for (int i = tid; i < PN; i += NT) b1l[i] = p.b1 ? p.b1[i] : 0.f;
+  const int nimg = MASKT ? p.M / p.HW : 0;
+  if (MASKT)
+    for (int i = tid; i < nimg; i += NT) lens_l[i] = p.row_len[i];
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y2), 0, (unsigned)((long long)p.M * P * 4), 0x00020000);
@@ -86,6 +93,12 @@ __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFusePar
 #pragma unroll
       for (int r = 0; r < 16; ++r) y1a[o][r] = 0.f;
     const int nxt = blk + nwaves < nblk ? blk + nwaves : blk;       // (past the end: this block again, unused)
+    bool ok = true;
+    if (MASKT) {
+      const int m = blk * 32 + li;
+      const int img = m / p.HW, rem = m - img * p.HW;
+      ok = rem - (rem / p.W) * p.W < lens_l[img < nimg ? img : nimg - 1];
+    }
     // (the weight fragments are re-read from LDS for every block of pixels: hoisted out of this loop -- which hipcc
     // does when it can see that the addresses do not change -- they are 128 registers, and the kernel lives on
     // having sixteen wavefronts per CU in flight, not on saving 32 ds_read_b128 per 128 MFMAs)
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFusePar
         const f32x4 r = __builtin_bit_cast(f32x4, rs[g]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[g][e] = relu_f((acc[4 * g + e] + b[e]) + r[e]);
+        if (MASKT && !ok) o4[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       if (ob + 1 < OB) load_res(blk, ob + 1);
       else { load_y2(nxt); load_res(nxt, 0); }
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(NT, MINB) void bneck_c3c1_kernel(const BneckFusePar
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = relu_f(y1a[o][4 * g + e] + b[e]);
+        if (MASKT && !ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), y1r, (unsigned)li * (PN * 4) + lh * 16 + 32 * g + s, 0, 0);
       }
     }
@@ -155,14 +170,16 @@ bool bneck_fuse_supported(const BneckFuseParams& p) {
   return ((p.P == 32 && (p.PN == 32 || p.PN == 64)) || (p.P == 64 && p.PN == 64)) && p.M > 0 && p.ldw3 >= p.P && p.ldw1 >= 4 * p.P && (p.ldr & 3) == 0 &&
          p.ldr >= 4 * p.P && (long long)p.M * p.ldr * 4 < (1LL << 32) && (long long)p.M * 4 * p.P * 4 < (1LL << 32) &&
          ((reinterpret_cast<unsigned long long>(p.y2) | reinterpret_cast<unsigned long long>(p.res) |
-           reinterpret_cast<unsigned long long>(p.out) | reinterpret_cast<unsigned long long>(p.y1)) & 15) == 0;
+           reinterpret_cast<unsigned long long>(p.out) | reinterpret_cast<unsigned long long>(p.y1)) & 15) == 0 &&
+         // a ragged batch: whole images, at most 1024 of them (their widths go to LDS)
+         (!p.row_len || (p.HW > 0 && p.W > 0 && p.HW % p.W == 0 && p.M % p.HW == 0 && p.M / p.HW <= 1024));
 }
 
-template <int P, int PN, int NT, int MINB>
+template <int P, int PN, int NT, int MINB, bool MASKT = false>
 static hipError_t launch_bneck_fuse_p(const BneckFuseParams& p, hipStream_t stream) {
   constexpr int CX = 4 * P, OB = CX / 32, OB2 = PN / 32, KS3 = P / 2, NWV = NT / 64;
-  const size_t lds = (size_t)(OB * KS3 * 64 + OB2 * OB * 16 * 64 + CX + PN) * sizeof(float);
-  auto kern = bneck_c3c1_kernel<P, PN, NT, MINB>;
+  const size_t lds = (size_t)(OB * KS3 * 64 + OB2 * OB * 16 * 64 + CX + PN) * sizeof(float) + (MASKT ? 4096 : 0);
+  auto kern = bneck_c3c1_kernel<P, PN, NT, MINB, MASKT>;
   static size_t lds_granted[WS_MAX_DEVICES] = {};
   {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_granted);
@@ -179,9 +196,14 @@ hipError_t launch_bneck_fuse(const BneckFuseParams& p, hipStream_t stream) {
   if (!bneck_fuse_supported(p)) return hipErrorInvalidValue;
   if (dispatch_log_enabled()) {
     char key[160];
-    snprintf(key, sizeof(key), "rows=%d planes=%d next=%d -> bneck_c3c1_kernel (conv3 + residual + ReLU, next block's conv1 + ReLU)",
-             p.M, p.P, p.PN);
+    snprintf(key, sizeof(key), "rows=%d planes=%d next=%d%s -> bneck_c3c1_kernel (conv3 + residual + ReLU, next block's conv1 + ReLU)",
+             p.M, p.P, p.PN, p.row_len ? " +mask" : "");
     dispatch_log_note_text(key);
+  }
+  if (p.row_len) {
+    if (p.P == 64) return launch_bneck_fuse_p<64, 64, 512, 1, true>(p, stream);
+    return p.PN == 32 ? launch_bneck_fuse_p<32, 32, 256, 4, true>(p, stream)
+                      : launch_bneck_fuse_p<32, 64, 256, 3, true>(p, stream);
   }
   if (p.P == 64) return launch_bneck_fuse_p<64, 64, 512, 1>(p, stream);
   return p.PN == 32 ? launch_bneck_fuse_p<32, 32, 256, 4>(p, stream) : launch_bneck_fuse_p<32, 64, 256, 3>(p, stream);

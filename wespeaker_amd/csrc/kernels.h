@@ -144,6 +144,8 @@ struct BneckFuseParams {
   const float* W1; int ldw1; const float* b1; // the NEXT block's conv1 + bn1 folded: [PN][ldw1], [PN]
   float* y1;                                  // (M, PN): the next block's conv1 output
   int M, P, PN;                               // PN: the next block's planes (P, or 2 P at the stage 1 -> 2 transition)
+  const int* row_len; int HW, W;              // optional (ragged batch): [M / HW] widths, pixels per image, image width;
+                                              // pixels with ox >= row_len[img] are stored as zeros in out AND y1
 };
 bool bneck_fuse_supported(const BneckFuseParams& p);
 hipError_t launch_bneck_fuse(const BneckFuseParams& p, hipStream_t stream);

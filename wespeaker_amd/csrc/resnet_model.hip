@@ -239,19 +239,20 @@ struct ResNetModel : ModelBase {
         have_y1 = false;                // (else: the previous block's fused launch left this block's y1 in buf[ia])
         WS_LAUNCH(conv(blk.c2, t1, P, out, P, H, W, s, 1, ACT_RELU, nullptr, 0, lo));
         // conv3 (+ residual, ReLU) of this block and conv1 (+ ReLU) of the next one in ONE pass over the block output
-        // (bneck_fuse.hip): fp32, uniform batches, 32 / 64 planes, the next block with the same or twice the planes
+        // (bneck_fuse.hip): fp32, 32 / 64 planes, the next block with the same or twice the planes
         // (its conv1 has no stride: a block's stride sits in conv2).  The next block's y1 goes into the one buffer that
         // is dead by now: the spare one, or -- when this block has a shortcut convolution, whose output IS the spare
         // one -- the block's own input x (read by conv1 and the shortcut only)
         const Block* nb = bi + 1 < blocks.size() ? &blocks[bi + 1] : nullptr;
         BneckFuseParams fp = {};
-        if (gemm_precision == 0 && !ragged() && nb && (nb->planes == P || nb->planes == 2 * P) && nb->in_planes == Co &&
+        if (gemm_precision == 0 && nb && (nb->planes == P || nb->planes == 2 * P) && nb->in_planes == Co &&
             blk.c3.has_b && nb->c1.has_b && !blk.c3.has_post && !nb->c1.has_post) {
           fp.y2 = out; fp.W3 = arena.at(blk.c3.w); fp.ldw3 = blk.c3.ldw; fp.b3 = arena.at(blk.c3.b);
           fp.res = res; fp.ldr = ldr; fp.out = t1;
           fp.W1 = arena.at(nb->c1.w); fp.ldw1 = nb->c1.ldw; fp.b1 = arena.at(nb->c1.b);
           fp.y1 = blk.has_sc ? buf[cur] : t2;
           fp.M = B * Ho * Wo; fp.P = P; fp.PN = nb->planes;
+          fp.row_len = cur_lens[lo]; fp.HW = Ho * Wo; fp.W = Wo;      // (a ragged chunk: null otherwise)
         }
         if (fp.y2 && bneck_fuse_supported(fp)) {
           const double M_ = (double)fp.M;
