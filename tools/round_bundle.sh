@@ -31,6 +31,12 @@ done
 python bench.py --workload vox1o --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
 python bench.py --workload vox1o --model ResNet221 --steps 2 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
 python bench.py --workload stream10k --steps 3 --warmup 1 2> /dev/null | tail -1 >> "$OUT/${TAG}_bench_sets.jsonl"
+# a ragged batch (lengths within 12 % of each other) against the uniform batch of the same size, per family
+rm -f "$OUT/${TAG}_ragged.jsonl"
+for m in ECAPA_TDNN_GLOB_c512 ECAPA_TDNN_GLOB_c1024 ResNet34 ResNet221 CAMPPlus; do
+  b=256; case $m in ResNet34|CAMPPlus) b=512;; esac
+  timeout 600 python tools/bench_ragged.py --model $m --batch $b --steps 4 2> /dev/null | tail -1 >> "$OUT/${TAG}_ragged.jsonl"
+done
 # end to end from wave files in /dev/shm through the batch driver (one engine, two lanes, f16)
 timeout 600 python tools/bench_driver.py 2> /dev/null | tail -1 > "$OUT/${TAG}_driver.jsonl"; cut -c1-300 "$OUT/${TAG}_driver.jsonl"
 fi
