@@ -2144,6 +2144,40 @@ def test_full_size_ragged_batch_on_the_persistent_kernel(name, E):
         assert any("conv" in l for l in hits) and any("+res" in l for l in hits), hits
 
 
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512"])
+@pytest.mark.parametrize("B,T", [(256, 209), (128, 330), (128, 398), (64, 798)])
+def test_attentive_pooling_kernel_on_segments_of_long_utterances(name, B, T):
+    """astp_fused_kernel beyond 208 frames (round 6; pooling_layers.py:119-144): workgroup (u, seg) takes <= 208
+    frames of utterance u and leaves its online-softmax tuple per channel, astp_combine_kernel merges the tuples
+    (2 x 105, 2 x 165, 2 x 199, 4 x 200 frames here: all three row-block forms).  Uniform and ragged batches big
+    enough for the cost model to pick the kernel; spot rows against the batch-1 oracle, and the dispatch log must
+    name the kernel."""
+    sd = synth.synth_state_dict(name, 80, 192, seed=42)
+    model = _native(name, sd, 192, max_batch=B, max_frames=T)
+    f = np.random.RandomState(T).randn(B, T, 80).astype(np.float32)
+    from wespeaker_amd.engine import dispatch_log, dispatch_report
+    dispatch_log(True, clear=True)
+    try:
+        out = model(torch.from_numpy(f))
+        got = (out[-1] if isinstance(out, tuple) else out).cpu().numpy()
+        lines = dispatch_report()
+    finally:
+        dispatch_log(False, clear=True)
+    assert any("astp_fused_kernel" in l for l in lines), lines[:6]
+    rows = [0, B // 2, B - 1]
+    ref = oecapa.ecapa_forward(sd, f[rows]).numpy()
+    assert _cos_err(got[rows], ref).max() < COS_TOL and _rel_err(got[rows], ref).max() < REL_TOL, (B, T)
+    lens = np.random.RandomState(B).randint(T - 150, T + 1, size=B)
+    lens[0], lens[B - 1] = T, T - 150
+    pad = np.full((B, T, 80), np.nan, dtype=np.float32)
+    for i in range(B):
+        pad[i, :lens[i]] = f[i, :lens[i]]
+    rag = model.embed_ragged(torch.from_numpy(pad), [int(x) for x in lens]).cpu().numpy()
+    assert np.isfinite(rag).all()
+    ref = _oracle_rows(lambda x: oecapa.ecapa_forward(sd, x).numpy(), [f[i, :lens[i]] for i in rows])
+    assert _cos_err(rag[rows], ref).max() < COS_TOL and _rel_err(rag[rows], ref).max() < REL_TOL, (B, T)
+
+
 @pytest.mark.parametrize("name,E", [("ECAPA_TDNN_GLOB_c512", 100), ("ResNet18", 37), ("CAMPPlus", 200)])
 def test_small_m_gemm_edges(name, E):
     """small_m_gemm_f32_kernel (csrc/small_m_gemm.hip): the M = batch linear layers of the fp32 back-end in one launch

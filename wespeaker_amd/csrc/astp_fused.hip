@@ -95,6 +95,11 @@ struct AstpFusedParams {
   float* pooled;                    // [B][3072]
   const int* row_len;               // optional [B]
   int B, T;
+  // Segments (round 6, utterances longer than 208 frames): workgroup (u, seg) takes frames [seg * seg_rows, + seg_rows)
+  // of utterance u and leaves its online-softmax tuple (max, sum e, sum e x, sum e x^2) per channel in
+  // partial[(u * nseg + seg) * 1536 + c]; astp_combine_kernel merges an utterance's tuples.  nseg = 1: as before.
+  int nseg, seg_rows;
+  f32x4* partial;
 };
 
 template <bool RAGGED, int F_RB>
@@ -115,7 +120,6 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
   const int r16 = lane & 15, q4 = lane >> 4;
   const int r8 = lane >> 3, c8 = lane & 7;
   const int nk = F_NC / F_BK;                  // 48
-  const int T = p.T;
 
   // fragment byte offsets inside a stage (phase A) and inside H (phase B)
   int offA[2];
@@ -131,9 +135,13 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
   {
     // one utterance per workgroup (nothing carries over between utterances, so there is nothing to gain from a
     // persistent loop -- and the compiler hoists ~180 loop-invariant lane addresses out of one and spills them)
-    const int u = blockIdx.x;
-    const int len = p.row_len ? min(p.row_len[u], T) : T;
-    const float* hu = p.h + (long long)u * T * p.ldh;
+    const int nseg = p.nseg;
+    const int u = nseg > 1 ? blockIdx.x / nseg : blockIdx.x;
+    const int seg = blockIdx.x - u * nseg;
+    const int row0 = seg * p.seg_rows;           // (0 without segments)
+    const int T = min(p.seg_rows, p.T - row0);   // rows of this workgroup's part of the utterance's slot
+    const int len = max(0, min((p.row_len ? min(p.row_len[u], p.T) : p.T) - row0, T));
+    const float* hu = p.h + ((long long)u * p.T + row0) * p.ldh;
 
     // ---- DMA lane offsets of this wavefront's pieces (bytes from hu / w1, K offset added per K-tile)
     unsigned voff[F_NP];
@@ -389,18 +397,53 @@ __global__ __launch_bounds__(512, 2) void astp_fused_kernel(const AstpFusedParam
         s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         WS_ASTAMP(10 + 4 * (it + half));
         if (q4 == 0) {
-          const float inv = 1.f / s0;
-          const float mean = s1 * inv;
-          const float var = s2 * inv - mean * mean;
-          float* out = p.pooled + (long long)u * 2 * F_NC + c0 + r16;
-          out[0] = mean;
-          out[F_NC] = sqrtf(fmaxf(var, 1e-7f));
+          if (nseg > 1) {
+            p.partial[(long long)blockIdx.x * F_NC + c0 + r16] = (f32x4){mx, s0, s1, s2};
+          } else {
+            const float inv = 1.f / s0;
+            const float mean = s1 * inv;
+            const float var = s2 * inv - mean * mean;
+            float* out = p.pooled + (long long)u * 2 * F_NC + c0 + r16;
+            out[0] = mean;
+            out[F_NC] = sqrtf(fmaxf(var, 1e-7f));
+          }
         }
       }
     }
   }
 }
 
+// pooled[u] = [mean | std] from the nseg tuples of utterance u (the softmax's max differs per segment: rescale)
+__global__ void astp_combine_kernel(const f32x4* __restrict__ partial, int nseg, float* __restrict__ pooled) {
+  const int u = blockIdx.x;
+  for (int c = threadIdx.x; c < F_NC; c += blockDim.x) {
+    float M = -1e30f;
+    for (int s = 0; s < nseg; ++s) M = fmaxf(M, partial[((long long)u * nseg + s) * F_NC + c][0]);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+      const f32x4 t = partial[((long long)u * nseg + s) * F_NC + c];
+      const float w = __expf(t[0] - M);
+      s0 += t[1] * w;
+      s1 += t[2] * w;
+      s2 += t[3] * w;
+    }
+    const float inv = 1.f / s0, mean = s1 * inv, var = s2 * inv - mean * mean;
+    pooled[(long long)u * 2 * F_NC + c] = mean;
+    pooled[(long long)u * 2 * F_NC + F_NC + c] = sqrtf(fmaxf(var, 1e-7f));
+  }
+}
+
+// segments of an utterance of T frames: as few as fit 208 rows each, equal lengths (within nseg - 1 rows), and the
+// shortest one still covers the row blocks that its kernel form treats as whole (16 (RB - 3) rows)
+struct AstpSegs { int nseg, rows, rb; };
+AstpSegs astp_segments(int T) {
+  for (int nseg = (T + 207) / 208; nseg <= 16; ++nseg) {
+    const int rows = (T + nseg - 1) / nseg, last = T - (nseg - 1) * rows;
+    const int rb = rows <= 112 ? 7 : (rows <= 160 ? 10 : 13);
+    if (rows >= 64 && last >= 16 * (rb - 3) && last >= 1) return {nseg, rows, rb};
+  }
+  return {0, 0, 0};
+}
 }  // namespace
 
 bool astp_fused_supported(int T, int C, int bottleneck) {
@@ -408,7 +451,8 @@ bool astp_fused_supported(int T, int C, int bottleneck) {
   // 7, 10 or 13 row blocks of 16 frames; shorter utterances stay on the tile kernels, longer ones too (one workgroup
   // per utterance stops paying when an utterance needs several passes: with a constant rows budget the batch
   // then holds fewer utterances than there are CUs)
-  return !off && C == F_NC && bottleneck == F_NH && T >= 64 && T <= 208;
+  // (round 6: longer utterances as segments of <= 208 frames + a merge of their softmax tuples, up to 16 segments)
+  return !off && C == F_NC && bottleneck == F_NH && T >= 64 && astp_segments(T).nseg > 0;
 }
 
 // One workgroup per utterance costs a fixed ~25 us per row block and round of workgroups whatever the batch is; the
@@ -418,8 +462,10 @@ bool astp_fused_pays(int B, int T) {
   static const int force = [] { const char* e = getenv("WS_ASTP_FUSED"); return e && atoi(e) == 2 ? 1 : 0; }();
   if (force) return true;                        // (tests: the kernel on small batches)
   const int cus = current_device_cus();
-  const int rb = T <= 112 ? 7 : (T <= 160 ? 10 : 13);
-  const double fused = (double)((B + cus - 1) / cus) * (25.5 * rb);
+  const AstpSegs sg = astp_segments(T);
+  if (!sg.nseg) return false;
+  const int rb = sg.rb;
+  const double fused = (double)(((long long)B * sg.nseg + cus - 1) / cus) * (25.5 * rb) + (sg.nseg > 1 ? 8.0 : 0.0);
   const double tiles = 497.0 * ((double)B * T) / (256.0 * 198.0) + 20.0;
   return fused < tiles;
 }
@@ -434,24 +480,30 @@ hipError_t launch_astp_rb(const AstpFusedParams& p, hipStream_t stream) {
                            : ensure_dynamic_lds(reinterpret_cast<const void*>(astp_fused_kernel<false, RB>),
                                                 f_lds_bytes(RB), granted0);
   if (e != hipSuccess) return e;
-  if (p.row_len) hipLaunchKernelGGL((astp_fused_kernel<true, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
-  else hipLaunchKernelGGL((astp_fused_kernel<false, RB>), dim3(p.B), dim3(512), f_lds_bytes(RB), stream, p);
+  const dim3 grid((unsigned)(p.B * p.nseg));
+  if (p.row_len) hipLaunchKernelGGL((astp_fused_kernel<true, RB>), grid, dim3(512), f_lds_bytes(RB), stream, p);
+  else hipLaunchKernelGGL((astp_fused_kernel<false, RB>), grid, dim3(512), f_lds_bytes(RB), stream, p);
+  if (p.nseg > 1) hipLaunchKernelGGL(astp_combine_kernel, dim3(p.B), dim3(512), 0, stream, p.partial, p.nseg, p.pooled);
   return hipGetLastError();
 }
 }  // namespace
 
 hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float* w1, int ldw1, const float* bias,
                              const float* bias_img, const float* w2, int ldw2, float* pooled, const int* lens,
-                             hipStream_t stream) {
+                             hipStream_t stream, float* seg_scratch) {
   if (!astp_fused_supported(T, F_NC, F_NH) || (ldh & 3) || (ldw1 & 3) || (ldw2 & 3) || B <= 0)
     return hipErrorInvalidValue;
+  const AstpSegs sg = astp_segments(T);
+  // (segments: B * nseg * 1536 tuples of 16 B in seg_scratch, 16-byte aligned)
+  if (sg.nseg > 1 && (!seg_scratch || (reinterpret_cast<unsigned long long>(seg_scratch) & 15))) return hipErrorInvalidValue;
   // 32-bit byte offsets inside one utterance / the weight matrices
   if ((long long)T * ldh * 4 >= (1ll << 31) || (long long)F_NH * ldw1 * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   AstpFusedParams p;
   p.h = h; p.ldh = ldh; p.w1 = w1; p.ldw1 = ldw1; p.bias = bias; p.bias_img = bias_img;
   p.w2 = w2; p.ldw2 = ldw2; p.pooled = pooled; p.row_len = lens; p.B = B; p.T = T;
-  if (T <= 112) return launch_astp_rb<7>(p, stream);
-  if (T <= 160) return launch_astp_rb<10>(p, stream);
+  p.nseg = sg.nseg; p.seg_rows = sg.rows; p.partial = reinterpret_cast<f32x4*>(seg_scratch);
+  if (sg.rb == 7) return launch_astp_rb<7>(p, stream);
+  if (sg.rb == 10) return launch_astp_rb<10>(p, stream);
   return launch_astp_rb<13>(p, stream);
 }
 

@@ -312,7 +312,8 @@ struct EcapaModel : ModelBase {
         dispatch_log_note(note, "astp_fused_kernel (linear1 + tanh + linear2 + softmax pooling)");
       }
       hipError_t fe = launch_astp_fused(h, 1536, B, T, arena.at(pool1.w), pool1.ldw, glob ? nullptr : a1.bias,
-                                        glob ? bias_img : nullptr, arena.at(pool2.w), pool2.ldw, pooled, L0, st);
+                                        glob ? bias_img : nullptr, arena.at(pool2.w), pool2.ldw, pooled, L0, st,
+                                        e);       // (e: the logits buffer of the unfused path, free here: segment tuples)
       prof.end(st);
       WS_LAUNCH(fe);
     } else {

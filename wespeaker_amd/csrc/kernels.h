@@ -232,12 +232,12 @@ hipError_t launch_astp_context_bias(const float* h, int ldh, int B, int T, int C
                                     int ldw1, const float* b1, int bottleneck, float* stats,
                                     float* bias_img, hipStream_t stream);
 // ASTP linear1 -> tanh -> linear2 -> softmax over time -> weighted mean / std as one kernel, one workgroup per
-// utterance (astp_fused.hip; fp32, 64 <= T <= 208, C = 1536, bottleneck 128).  pooled[b] = [mean(C) | std(C)].
+// utterance -- or per segment of <= 208 frames of a longer one, + a merge -- (astp_fused.hip; fp32, T >= 64, C = 1536, bottleneck 128).  pooled[b] = [mean(C) | std(C)].
 bool astp_fused_supported(int T, int C, int bottleneck);
 bool astp_fused_pays(int B, int T);          // cost model: one workgroup per utterance vs the three tile launches
 hipError_t launch_astp_fused(const float* h, int ldh, int B, int T, const float* w1, int ldw1, const float* bias,
                              const float* bias_img, const float* w2, int ldw2, float* pooled, const int* lens,
-                             hipStream_t stream);
+                             hipStream_t stream, float* seg_scratch = nullptr);   // T > 208: B * ceil(T / 208 ..) * 1536 * 4 floats
 // Final combine of ConvGemmParams::pool_partial: per (b, c) merge the tile tuples of utterance b,
 // mean = S1/S0, std = sqrt(max(S2/S0 - mean^2, 1e-7)) -> pooled[b] = [mean(C) | std(C)]
 hipError_t launch_astp_pool_from_partials(const float* partials, int B, int T, int C, float* pooled,
