@@ -111,8 +111,8 @@ __device__ __forceinline__ void se_fc_body(const float* __restrict__ colsum, int
   const float inv_len = 1.f / (float)(lens ? lens[b] : T);
   const long long r0 = (long long)b * T, r1 = r0 + T - 1;
   const int t_first = (int)(r0 / 64), t_last = (int)(r1 / 64);
-  // the tile partials of an utterance (<= 8 for T <= 448; more fall back to the serial loop): all
-  // requested at once, in tile order -- a serial loop exposed one L2 round trip per tile
+  // the tile partials of an utterance (<= 8 for T <= 448, <= 16 for T <= 960; more fall back to the serial loop):
+  // all requested at once, in tile order -- a serial loop exposed one L2 round trip per tile
   for (int c = tid; c < C; c += NT) {
     float v = 0.f;
     if (t_last - t_first < 8) {
@@ -126,6 +126,17 @@ __device__ __forceinline__ void se_fc_body(const float* __restrict__ colsum, int
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) v += t_first + i <= t_last ? part[i] : 0.f;
+    } else if (t_last - t_first < 16) {
+      float part[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tm = t_first + i <= t_last ? t_first + i : t_last;
+        const int first_img = (int)(((long long)tm * 64) / T);
+        const int which = (first_img == b) ? 0 : 1;
+        part[i] = colsum[((long long)tm * 2 + which) * C + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v += t_first + i <= t_last ? part[i] : 0.f;
     } else {
       for (int tm = t_first; tm <= t_last; ++tm) {
         const int first_img = (int)(((long long)tm * 64) / T);
@@ -251,12 +262,15 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_kernel(
     const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, int bott, float* __restrict__ s_out,
     const int* __restrict__ lens, const float* __restrict__ x, int ldx, int x_off, const float* __restrict__ y,
-    int ldy, float* __restrict__ out, int ldo, int o_off, uint16_t* __restrict__ out16) {
+    int ldy, float* __restrict__ out, int ldo, int o_off, uint16_t* __restrict__ out16, int nsplit) {
   __shared__ __attribute__((aligned(16))) float mean[1024];
   __shared__ __attribute__((aligned(16))) float hidden[256];
   __shared__ __attribute__((aligned(16))) float s_lds[1024];
   constexpr int U = 8;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // nsplit (round 6): a batch of few, long utterances leaves most CUs without a workgroup -- nsplit workgroups per
+  // utterance then each compute s (the same bits) and stream their share [t0, t1) of its rows
+  const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit, tid = threadIdx.x;
+  const int chunk = (T + nsplit - 1) / nsplit, t0 = part * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
   const int cols4 = C >> 2;                  // 128 / 256 (C = 512 / 1024): divides the 1024 threads
   const int c = (tid % cols4) * 4, r0 = tid / cols4, rp = 1024 / cols4;
   const long long m0 = (long long)b * T;
@@ -265,8 +279,8 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_kernel(
   constexpr int PRE = 4;                     // slots requested in front of the FCs (more would spill there)
   f32x4 xv[U], yv[U];
   auto request = [&](int u) {
-    const int r = r0 + u * rp;
-    if (r < T) {
+    const int r = t0 + r0 + u * rp;
+    if (r < t1) {
       xv[u] = *reinterpret_cast<const f32x4*>(xp + (long long)r * ldx);
       yv[u] = *reinterpret_cast<const f32x4*>(yp + (long long)r * ldy);
     }
@@ -280,11 +294,11 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_kernel(
   const f32x4 sv = *reinterpret_cast<const f32x4*>(&s_lds[c]);
   float* op = out + m0 * ldo + o_off + c;
   uint16_t* op16 = OUT16 ? out16 + m0 * ldo + o_off + c : nullptr;
-  for (int rb = r0; rb < T; rb += U * rp) {
+  for (int rb = t0 + r0; rb < t1; rb += U * rp) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = rb + u * rp;
-      if (r < T) {
+      if (r < t1) {
         const f32x4 v = xv[u] + yv[u] * sv;
         *reinterpret_cast<f32x4*>(op + (long long)r * ldo) = v;
         if (OUT16) {                                 // binary16 copy for the f16 GEMM back-end
@@ -295,13 +309,22 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_kernel(
           *reinterpret_cast<f16x4e*>(op16 + (long long)r * ldo) = hv;
         }
         const int rn = r + U * rp;                   // this slot's next row
-        if (rn < T) {
+        if (rn < t1) {
           xv[u] = *reinterpret_cast<const f32x4*>(xp + (long long)rn * ldx);
           yv[u] = *reinterpret_cast<const f32x4*>(yp + (long long)rn * ldy);
         }
       }
     }
   }
+}
+
+// workgroups per utterance of the fused SE kernels: one when the batch covers the chip, else up to eight parts of
+// >= 64 rows each
+static int se_row_split(int B, int T) {
+  const int cus = current_device_cus();
+  int n = B >= cus ? 1 : cus / B;
+  if (n > T / 64) n = T / 64;
+  return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
 
 bool se_fc_scale_residual_supported(int T, int C, int bottleneck) {
@@ -315,12 +338,13 @@ hipError_t launch_se_fc_scale_residual(const float* colsum, int B, int T, int C,
                                        float* out, int ldo, int o_off, hipStream_t stream, uint16_t* out16) {
   if (!se_fc_scale_residual_supported(T, C, bottleneck) || ((ldx | x_off | ldy | ldo | o_off) & 3))
     return hipErrorInvalidValue;
+  const int nsplit = se_row_split(B, T);
   if (out16)
-    hipLaunchKernelGGL(se_fc_scale_residual_kernel<true>, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2,
-                       b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16);
+    hipLaunchKernelGGL(se_fc_scale_residual_kernel<true>, dim3(B * nsplit), dim3(1024), 0, stream, colsum, T, C, w1,
+                       b1, w2, b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16, nsplit);
   else
-    hipLaunchKernelGGL(se_fc_scale_residual_kernel<false>, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2,
-                       b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16);
+    hipLaunchKernelGGL(se_fc_scale_residual_kernel<false>, dim3(B * nsplit), dim3(1024), 0, stream, colsum, T, C, w1,
+                       b1, w2, b2, bottleneck, s, lens, x, ldx, x_off, y, ldy, out, ldo, o_off, out16, nsplit);
   return hipGetLastError();
 }
 
@@ -371,13 +395,14 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_f16_kernel(
     const float* __restrict__ colsum, int T, int C, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, int bott, float* __restrict__ s_out,
     const int* __restrict__ lens, const uint16_t* __restrict__ x, int ldx, int x_off, const uint16_t* __restrict__ y,
-    int ldy, uint16_t* __restrict__ out, int ldo, int o_off) {
+    int ldy, uint16_t* __restrict__ out, int ldo, int o_off, int nsplit) {
   typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) float mean[1024];
   __shared__ __attribute__((aligned(16))) float hidden[256];
   __shared__ __attribute__((aligned(16))) float s_lds[1024];
   constexpr int U = 8, PRE = 4;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit, tid = threadIdx.x;
+  const int chunk = (T + nsplit - 1) / nsplit, t0 = part * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
   const int cols8 = C >> 3;                  // 64 / 128 (C = 512 / 1024): divides the 1024 threads
   const int c = (tid % cols8) * 8, r0 = tid / cols8, rp = 1024 / cols8;
   const long long m0 = (long long)b * T;
@@ -385,8 +410,8 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_f16_kernel(
   const uint16_t* yp = y + m0 * ldy + c;
   f16x8e xv[U], yv[U];
   auto request = [&](int u) {
-    const int r = r0 + u * rp;
-    if (r < T) {
+    const int r = t0 + r0 + u * rp;
+    if (r < t1) {
       xv[u] = *reinterpret_cast<const f16x8e*>(xp + (long long)r * ldx);
       yv[u] = *reinterpret_cast<const f16x8e*>(yp + (long long)r * ldy);
     }
@@ -400,11 +425,11 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_f16_kernel(
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(&s_lds[c]);
   const f32x4 s1 = *reinterpret_cast<const f32x4*>(&s_lds[c + 4]);
   uint16_t* op = out + m0 * ldo + o_off + c;
-  for (int rb = r0; rb < T; rb += U * rp) {
+  for (int rb = t0 + r0; rb < t1; rb += U * rp) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = rb + u * rp;
-      if (r < T) {
+      if (r < t1) {
         f16x8e o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                  // (the expression of se_scale_residual_f16_kernel: same bits)
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(1024) void se_fc_scale_residual_f16_kernel(
         }
         *reinterpret_cast<f16x8e*>(op + (long long)r * ldo) = o;
         const int rn = r + U * rp;
-        if (rn < T) {
+        if (rn < t1) {
           xv[u] = *reinterpret_cast<const f16x8e*>(xp + (long long)rn * ldx);
           yv[u] = *reinterpret_cast<const f16x8e*>(yp + (long long)rn * ldy);
         }
@@ -434,8 +459,9 @@ hipError_t launch_se_fc_scale_residual_f16(const float* colsum, int B, int T, in
                                            hipStream_t stream) {
   if (!se_fc_scale_residual_f16_supported(T, C, bottleneck) || ((ldx | x_off | ldy | ldo | o_off) & 7))
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(se_fc_scale_residual_f16_kernel, dim3(B), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2t, b2,
-                     bottleneck, s, lens, x16, ldx, x_off, y16, ldy, out16, ldo, o_off);
+  const int nsplit = se_row_split(B, T);
+  hipLaunchKernelGGL(se_fc_scale_residual_f16_kernel, dim3(B * nsplit), dim3(1024), 0, stream, colsum, T, C, w1, b1, w2t,
+                     b2, bottleneck, s, lens, x16, ldx, x_off, y16, ldy, out16, ldo, o_off, nsplit);
   return hipGetLastError();
 }
 
