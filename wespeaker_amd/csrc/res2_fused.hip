@@ -462,6 +462,27 @@ bool res2_chain_supported(int W, int T, int dil) {
   return T >= 1 && dil >= 1 && chain_cap(W, chain_mtw(W, true)) - 2 * 7 * dil >= 32;
 }
 
+// w = 64, utterances longer than one window: the window size (MTW row tiles per wave row, 32 MTW rows) that needs the
+// fewest rounds of workgroups x the time of one (measured: 56.7 us at MTW = 4, 96 us at 7 -- linear in between).  A
+// 224-row window owns 196 / 182 / 168 frames at dilation 2 / 3 / 4: 64 utterances of 8 s are 320 workgroups, 1.25
+// rounds on 256 CUs, i.e. two; 256-row windows make it 256.  Every tiling gives the same bits
+// (test_res2_time_tiles_are_bit_identical_to_whole_utterance_windows).
+static int chain_pick_mtw64(int B, int T, int dil) {
+  const int cus = device_cus();
+  int best = 7;
+  double best_cost = 1e30;
+  const int cand[4] = {7, 8, 6, 5};
+  for (int i = 0; i < 4; ++i) {
+    const int mtw = cand[i], cap = chain_cap(64, mtw);
+    if (cap - 2 * 7 * dil < 32) continue;
+    int tiles, own;
+    chain_tiling_for(cap, T, dil, &tiles, &own);
+    const double cost = (double)(((long long)B * tiles + cus - 1) / cus) * (4.3 + 13.1 * mtw);
+    if (cost < best_cost * 0.97) { best_cost = cost; best = mtw; }      // (3 % better or stay: fewer code paths in use)
+  }
+  return best;
+}
+
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
@@ -469,10 +490,26 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (!res2_chain_supported(p.W, p.T, p.dil)) return hipErrorInvalidValue;
   const bool small = chain_use_small(p.W, p.B, p.T, p.dil);
   if (p.prec >= 1) {   // (the f16 mode reuses the split kernel: more precise, same launch count)
-    if (p.W == 64) return small ? launch_res2_f16_variant<64, 4>(p, stream) : launch_res2_f16_variant<64, 7>(p, stream);
+    if (p.W == 64) {
+      if (small) return launch_res2_f16_variant<64, 4>(p, stream);
+      switch (chain_pick_mtw64(p.B, p.T, p.dil)) {
+        case 5: return launch_res2_f16_variant<64, 5>(p, stream);
+        case 6: return launch_res2_f16_variant<64, 6>(p, stream);
+        case 8: return launch_res2_f16_variant<64, 8>(p, stream);
+        default: return launch_res2_f16_variant<64, 7>(p, stream);
+      }
+    }
     return small ? launch_res2_f16_variant<128, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
   }
   if (!small && chain4_takes(p)) return launch_res2_chain4(p, stream);
+  if (p.W == 64 && !small) {
+    switch (chain_pick_mtw64(p.B, p.T, p.dil)) {
+      case 5: return launch_res2_variant<64, 5>(p, stream);
+      case 6: return launch_res2_variant<64, 6>(p, stream);
+      case 8: return launch_res2_variant<64, 8>(p, stream);
+      default: return launch_res2_variant<64, 7>(p, stream);
+    }
+  }
   if (p.W == 64) return small ? launch_res2_variant<64, 4>(p, stream) : launch_res2_variant<64, 7>(p, stream);
   return small ? launch_res2_variant<128, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
 }
