@@ -179,7 +179,7 @@ hipError_t launch_tstp_f16(const uint16_t* x16, int ldx, int B, int F, int T, in
 // grid = B, block = 256.  C <= 256 channels, hidden <= 128, Cout <= 64, segs <= 32.
 // Segment sums over the T axis (lanes = channels, 256/C time groups), then the two small FCs
 // per segment.  mask[b][seg][Cout].
-__global__ __launch_bounds__(256) void cam_context_kernel(const float* __restrict__ h, int ldh, int T,
+__global__ __launch_bounds__(1024) void cam_context_kernel(const float* __restrict__ h, int ldh, int T,
                                                           int C, int seg_len, int segs,
                                                           const float* __restrict__ w1,
                                                           const float* __restrict__ b1, int hidden,
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
                                                           const int* __restrict__ lens) {
   extern __shared__ float sm[];
   float* segsum = sm;                       // [groups][segs][C]
-  const int groups = 256 / C;
+  const int NT = blockDim.x;                // 256, or 1024 for long utterances (more rows in flight per segment)
+  const int groups = NT / C;
   float* ctx = sm + groups * segs * C;      // [C]
   float* hid = ctx + C;                     // [hidden]
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
   }
   __syncthreads();
   // fold the time groups: segsum[0][s][c] <- sum_g
-  for (int i = tid; i < segs * C; i += 256) {
+  for (int i = tid; i < segs * C; i += NT) {
     float v = 0.f;
     for (int g = 0; g < groups; ++g) v += segsum[g * segs * C + i];
     segsum[i] = v;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void cam_context_kernel(const float* __restric
       ctx[tid] = tot / (float)T + segsum[s * C + tid] / (float)(t1 - t0);
     }
     __syncthreads();
-    for (int j = wave; j < hidden; j += 4) {          // hid = relu(W1 ctx + b1)
+    for (int j = wave; j < hidden; j += NT / 64) {    // hid = relu(W1 ctx + b1)
       const float* wr = w1 + (long long)j * C;
       float v = 0.f;
       for (int k = lane; k < C; k += 64) v += wr[k] * ctx[k];
@@ -309,10 +310,14 @@ hipError_t launch_cam_context(const float* h, int ldh, int B, int T, int C, int 
                               const float* b2, int Cout, float* mask, hipStream_t stream, const int* lens) {
   if (C > 256 || 256 % C != 0 || hidden > 128 || Cout > 64) return hipErrorInvalidValue;
   const int segs = (T + seg_len - 1) / seg_len;
-  const int groups = 256 / C;
+  // round 6: 1024 threads per utterance from 128 frames on (the kernel is a chain of strided row loads: 35 us per
+  // launch with 256 threads at T' = 199, 52 launches per forward of a CAM++ batch of 4-s utterances)
+  int nt = T >= 128 && 1024 % C == 0 ? 1024 : 256;
+  if (((size_t)(nt / C) * segs * C + C + hidden) * sizeof(float) > 60 * 1024) nt = 256;
+  const int groups = nt / C;
   const size_t lds = ((size_t)groups * segs * C + C + hidden) * sizeof(float);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cam_context_kernel, dim3(B), dim3(256), lds, stream, h, ldh, T, C, seg_len, segs,
+  hipLaunchKernelGGL(cam_context_kernel, dim3(B), dim3(nt), lds, stream, h, ldh, T, C, seg_len, segs,
                      w1, b1, hidden, w2, b2, Cout, mask, lens);
   return hipGetLastError();
 }
