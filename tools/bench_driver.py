@@ -27,7 +27,11 @@ def main():
     ap.add_argument("--repeats", type=int, default=7)
     ap.add_argument("--python_loader", action="store_true", help="the Python thread-pool decode path instead of "
                     "the native loader (ws_wav_load_rows)")
+    ap.add_argument("--long_n", type=int, default=0, help="instead of the two 2-s lists: this many files of 4 - 12 s "
+                    "(whole utterances of a VoxCeleb-like test set) -> utt/s and audio-seconds/s")
     args = ap.parse_args()
+    if args.long_n:
+        return long_list(args)
     root = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         rng = np.random.Generator(np.random.PCG64(1))
@@ -74,6 +78,52 @@ def main():
                     assert len(keys) == args.n and np.isfinite(emb).all()
                 rec["%s/%s" % (prec, tag)] = float(np.median(rates))
                 rec["%s/%s/passes" % (prec, tag)] = [round(r) for r in rates]
+        print(json.dumps(rec))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def long_list(args):
+    """Whole utterances of 4 - 12 s (every length different): sorted-length ragged batches, time-tiled Res2 chain,
+    the attentive pooling kernel on segments."""
+    root = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rng = np.random.Generator(np.random.PCG64(2))
+        base = synth.synth_wav(0, 192000)
+        lines, total_s = [], 0.0
+        for i in range(args.long_n):
+            n = int(rng.integers(64000, 192001))
+            p = os.path.join(root, "long_%05d.wav" % i)
+            synth.write_wav(p, np.roll(base, i * 37)[:n])
+            lines.append("utt%05d %s" % (i, p))
+            total_s += n / 16000.0
+        dev = torch.device("cuda:0")
+        E = EMBED_DIM.get(args.model[:5], 256)
+        fe = Frontend(16000, 80, device=dev)
+        from wespeaker_amd import SpeakerModelLanes
+        sd = synth.synth_state_dict(args.model, 80, E, seed=42)
+        mb = min(args.max_batch, 128)
+        model = NativeSpeakerModel(args.model, sd, feat_dim=80, embed_dim=E, device=dev, max_batch=mb, max_frames=1200)
+        lanes2 = SpeakerModelLanes(args.model, sd, lanes=2, feat_dim=80, embed_dim=E, device=dev, max_batch=mb,
+                                   max_frames=1200)
+        rec = {"model": args.model, "files": args.long_n, "seconds_of_audio": round(total_s, 1), "lengths": "4 - 12 s",
+               "max_batch": mb, "decode_threads": wx.decode_threads(args.workers), "host_cores": os.cpu_count()}
+        for prec in ("fp32", "fp32_2lanes", "f16"):
+            if not prec.endswith("lanes"):
+                model.set_precision(prec)
+            ex = wx.GpuExtractor(lanes2 if prec.endswith("lanes") else model, fe)
+            run = lambda ls: wx.extract_list("scp", ls, ex, batch_size=1, max_batch=mb, num_workers=args.workers)
+            run(lines[:256])
+            rates = []
+            for _ in range(args.repeats):
+                t0 = time.perf_counter()
+                keys, emb = run(lines)
+                wx.write_ark_scp(keys, emb, os.path.join(root, "out_%s.ark" % prec))
+                rates.append(1.0 / (time.perf_counter() - t0))
+                assert len(keys) == args.long_n and np.isfinite(emb).all()
+            r = float(np.median(rates))
+            rec["%s/utt_per_s" % prec] = round(r * args.long_n, 1)
+            rec["%s/audio_s_per_s" % prec] = round(r * total_s, 1)
         print(json.dumps(rec))
     finally:
         shutil.rmtree(root, ignore_errors=True)

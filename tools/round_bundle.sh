@@ -39,6 +39,8 @@ for m in ECAPA_TDNN_GLOB_c512 ECAPA_TDNN_GLOB_c1024 ResNet34 ResNet221 CAMPPlus;
 done
 # end to end from wave files in /dev/shm through the batch driver (one engine, two lanes, f16)
 timeout 600 python tools/bench_driver.py 2> /dev/null | tail -1 > "$OUT/${TAG}_driver.jsonl"; cut -c1-300 "$OUT/${TAG}_driver.jsonl"
+# ... and a list of 1 024 whole utterances of 4 - 12 s (what a VoxCeleb-like test set looks like)
+timeout 600 python tools/bench_driver.py --long_n 1024 2> /dev/null | tail -1 > "$OUT/${TAG}_driver_long.jsonl"; cut -c1-300 "$OUT/${TAG}_driver_long.jsonl"
 fi
 cd /tmp && export TMPDIR=/tmp
 # kernel tables: one headline-only run per back-end / family, so every table describes ONE workload
