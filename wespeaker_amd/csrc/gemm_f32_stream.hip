@@ -720,7 +720,8 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   // same k order per accumulator as the tiles: the same bits), all eight copy the 16-KB K-tiles (64 rows of A, 64
   // of W) two ahead, and the block's epilogue is the tiles' (epi_step).  Column sums: the two wavefronts of a
   // 64-row strip add their halves through LDS in a fixed order.
-  constexpr bool UNITS = WM == 4 && TN == 2 && WNP == 2 && !RES && !CONV;
+  // (both eight-wavefront plain forms: the 256x128 tile and the 128x128 tile of <2, 1, .., 4>)
+  constexpr bool UNITS = NW == 8 && ((WM == 4 && TN == 2 && WNP == 2) || (WM == 2 && TN == 1 && WNP == 4)) && !RES && !CONV;
   if constexpr (UNITS) {
     if (p.n_units > 0) {
       // the operand stream has ended: its pieces landed, everybody is done with the stages and the scratch
@@ -896,9 +897,9 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
   // The tiles beyond the whole rounds: one more (partial) round here costs a whole tile time; as 64x64 tiles on the
   // tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the kernel boundary they cost
   // ceil(rem64 / 512) rounds -- take the cheaper.  Rows beyond the last whole tile row always go there.
-  // Round 6: the plain 256x128 form takes whole 64-row strips of those rows itself, as 64 x 64 units behind its
+  // Round 6: the plain eight-wavefront forms (256x128 and 128x128 tiles) take whole 64-row strips of those rows themselves, as 64 x 64 units behind its
   // tiles (~1400 cycles per K-tile and round of `cus` units); only a last partial strip is left to the tile kernel.
-  const bool units = g_ws_stream_units != 0 && mode == 3 && p.kh == 1 && !p.residual;
+  const bool units = g_ws_stream_units != 0 && (mode == 3 || mode == 2) && p.kh == 1 && !p.residual;
   const long long rem = total - main_tiles_m * tiles_n;
   const long long rest_rows = (p.M - p.m_begin) - tiles_m * bm;
   auto tile_kernel = [&](long long rows) {
