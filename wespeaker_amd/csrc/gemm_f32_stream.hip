@@ -352,9 +352,12 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
   const bool has_post = p.post_scale != nullptr;
   // raw buffer descriptors of D / D2: one store instruction per row = lane offset (VGPR) + row offset (SGPR),
   // no 64-bit address arithmetic on the vector ALU
-  const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.D, 0, 0xffffffff, 0x00020000);
+  // (the descriptors END at row M: the row units' last, partial strip stores rows that do not exist -- dropped)
+  const __amdgpu_buffer_rsrc_t d_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.D, 0, (unsigned)((unsigned long long)p.M * p.ldd * 4ull), 0x00020000);
   const __amdgpu_buffer_rsrc_t d2_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.D2 ? p.D2 : p.D, 0, 0xffffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(p.D2 ? p.D2 : p.D, 0,
+                                        (unsigned)((unsigned long long)p.M * (p.D2 ? p.ldd2 : p.ldd) * 4ull), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       RES ? const_cast<float*>(p.residual) : p.D, 0, 0xffffffff, 0x00020000);
   // ReLU as ONE integer max per value: the int image of a float is >= 0 exactly for +0, positive values, +inf and
@@ -396,6 +399,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
 #pragma unroll
   for (int in = 0; in < (COLSUM == 2 ? TN : 1); ++in) cq[in][0] = cq[in][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 ev[4], vb, vs, vt;                   // rows r8 + 8 i of the block being finished; bias / scale / shift
+  bool unit_partial = false;                 // (wave-uniform) a row unit whose strip runs past row M: its okmask drops those rows
   f32x4 rres[RES ? 2 * TN : 1][4];           // RES: the residual rows of all blocks of the tile ([im * TN + in][i])
   constexpr int NRES = RES ? 2 * TN * 4 : 0;
   auto res_load = [&](int j, const TileOut& t) {           // j = (im * TN + in) * 4 + i
@@ -438,7 +442,7 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         v[e] = __int_as_float(__builtin_elementwise_max(__float_as_int(f), relu_bits));
       }
       ev[i] = v * vs + vt;
-      if (masked && !((t.okmask >> (4 * im + i)) & 1u)) ev[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if ((masked || unit_partial) && !((t.okmask >> (4 * im + i)) & 1u)) ev[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     } else if (step >= 9 && step <= 12) {
       const int i = step - 9;
       const int srow = im * 32 + 8 * i;
@@ -753,7 +757,9 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         for (int i = 0; i < 2; ++i) {
           const int row = ((wave & 3) * 2 + i) * 8 + r8;
           const int c = c8 ^ ((row >> 1) & 7);
-          const unsigned long long lin = (unsigned long long)((isw ? un0 : um0) + row);
+          // (a partial last strip: the rows past M read row M - 1 again, their results are masked and their stores dropped)
+          const int arow = um0 + row < p.M ? um0 + row : p.M - 1;
+          const unsigned long long lin = (unsigned long long)(isw ? un0 + row : arow);
           uvoff[i] = (unsigned)((lin * (isw ? p.ldw : p.lda) + (isw ? 0 : p.a_off)) * 4ull + c * 16);
         }
         auto udma = [&](int kt, int stage) {
@@ -809,6 +815,13 @@ void gemm_f32_stream_kernel(const ConvGemmParams p) {
         ut.rb = COLSUM ? (um0 / HW + 1) * HW - um0 : 64;
         ut.t64 = um0 >> 6;
         ut.okmask = masked ? row_mask(um0) : 0xffu;
+        unit_partial = um0 + 64 > p.M;
+        if (unit_partial) {
+          unsigned inr = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) inr |= (um0 + 8 * j + r8 < p.M ? 1u : 0u) << j;
+          ut.okmask &= inr;
+        }
         if (active) {
           scr = reinterpret_cast<float*>(ldsb + U_SCR + wave * S_SCR_BYTES);
 #pragma unroll
@@ -898,7 +911,7 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
   // tile kernel (512 block slots, ~2600 cycles per K-tile and round, measured) plus the kernel boundary they cost
   // ceil(rem64 / 512) rounds -- take the cheaper.  Rows beyond the last whole tile row always go there.
   // Round 6: the plain eight-wavefront forms (256x128 and 128x128 tiles) take whole 64-row strips of those rows themselves, as 64 x 64 units behind its
-  // tiles (~1400 cycles per K-tile and round of `cus` units); only a last partial strip is left to the tile kernel.
+  // tiles (~1400 cycles per K-tile and round of `cus` units); the last strip may be partial (rows past M are masked, their stores fall outside the output descriptor).
   const bool units = g_ws_stream_units != 0 && (mode == 3 || mode == 2) && p.kh == 1 && !p.residual;
   const long long rem = total - main_tiles_m * tiles_n;
   const long long rest_rows = (p.M - p.m_begin) - tiles_m * bm;
@@ -909,8 +922,8 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
   };
   auto beyond = [&](long long rows) {
     if (!units) return tile_kernel(rows);
-    const long long strips = rows / 64, n_units = strips * (p.N / 64);
-    return (n_units + cus - 1) / cus * (nk * 1400 + 4000) + tile_kernel(rows - strips * 64);
+    const long long strips = (rows + 63) / 64, n_units = strips * (p.N / 64);      // (a last partial strip too)
+    return (n_units + cus - 1) / cus * (nk * 1400 + 4000);
   };
   long long cyc = (main_tiles_m * tiles_n / cus) * tile_time;
   const long long here = tile_time + beyond(rest_rows);
@@ -922,7 +935,7 @@ StreamPlan plan_mode(const ConvGemmParams& p, int cus, int mode) {
     cyc += there;
   }
   pl.main_rows = (int)(main_tiles_m * bm);
-  pl.rows = pl.main_rows + (units ? (int)(((p.M - p.m_begin) - pl.main_rows) / 64 * 64) : 0);
+  pl.rows = units ? p.M - p.m_begin : pl.main_rows;      // (units: every remaining row, the last strip may be partial)
   pl.cycles = cyc;
   return pl;
 }
@@ -987,8 +1000,9 @@ int gemm_f32_stream_rows(const ConvGemmParams& p, int cus) {
                      (long long)p.M * p.ldr * 4 >= (1LL << 32)))
     return 0;
   // 32-bit byte offsets
-  if ((long long)p.M * p.lda * 4 >= (1LL << 32) || (long long)p.M * p.ldd * 4 >= (1LL << 32) ||
-      (long long)p.N * p.ldw * 4 >= (1LL << 32) || (p.D2 && (long long)p.M * p.ldd2 * 4 >= (1LL << 32)))
+  // (+ 64 rows: a row unit's partial last strip forms offsets of rows that do not exist; they must not wrap)
+  if ((long long)(p.M + 64) * p.lda * 4 >= (1LL << 32) || (long long)(p.M + 64) * p.ldd * 4 >= (1LL << 32) ||
+      (long long)p.N * p.ldw * 4 >= (1LL << 32) || (p.D2 && (long long)(p.M + 64) * p.ldd2 * 4 >= (1LL << 32)))
     return 0;
   return plan(p, cus).rows;
 }
@@ -998,7 +1012,7 @@ hipError_t launch_gemm_f32_stream(const ConvGemmParams& p0, int rows, int cus, h
   const StreamPlan pl = plan(p0, cus);
   if (pl.rows != rows) return hipErrorInvalidValue;      // (rows must come from gemm_f32_stream_rows)
   p.tail_begin = p.m_begin + pl.main_rows;               // the first row of the 64 x 64 units
-  p.n_units = (rows - pl.main_rows) / 64 * (p.N / 64);
+  p.n_units = (rows - pl.main_rows + 63) / 64 * (p.N / 64);
   const int mode = pl.mode, bm = pl.bm;
   p.n_big = pl.main_rows / bm * (p.N / bn_of(mode));
   const int grid = p.n_big < cus ? p.n_big : cus;
