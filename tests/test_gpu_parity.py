@@ -2144,14 +2144,15 @@ def test_full_size_ragged_batch_on_the_persistent_kernel(name, E):
         assert any("conv" in l for l in hits) and any("+res" in l for l in hits), hits
 
 
-@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512"])
+@pytest.mark.parametrize("name", ["ECAPA_TDNN_GLOB_c512", "ECAPA_TDNN_c512", "ECAPA_TDNN_GLOB_c1024"])
 @pytest.mark.parametrize("B,T", [(256, 209), (128, 330), (128, 398), (64, 798)])
 def test_attentive_pooling_kernel_on_segments_of_long_utterances(name, B, T):
     """astp_fused_kernel beyond 208 frames (round 6; pooling_layers.py:119-144): workgroup (u, seg) takes <= 208
     frames of utterance u and leaves its online-softmax tuple per channel, astp_combine_kernel merges the tuples
     (2 x 105, 2 x 165, 2 x 199, 4 x 200 frames here: all three row-block forms).  Uniform and ragged batches big
     enough for the cost model to pick the kernel; spot rows against the batch-1 oracle, and the dispatch log must
-    name the kernel."""
+    name the kernel.  The same shapes put the time-tiled Res2 chain on the windows chain_pick_mtw64 / chain_pick_mtw128
+    choose (160 .. 256 rows; ECAPA-1024: 160 or 208)."""
     sd = synth.synth_state_dict(name, 80, 192, seed=42)
     model = _native(name, sd, 192, max_batch=B, max_frames=T)
     f = np.random.RandomState(T).randn(B, T, 80).astype(np.float32)

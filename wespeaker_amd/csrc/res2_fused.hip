@@ -483,6 +483,23 @@ static int chain_pick_mtw64(int B, int T, int dil) {
   return best;
 }
 
+// ... and for w = 128 (ECAPA-1024; one row of wavefronts, 16 MTW rows): 208- or 160-row windows (347 / 268 us)
+static int chain_pick_mtw128(int B, int T, int dil) {
+  const int cus = device_cus();
+  int best = 13;
+  double best_cost = 1e30;
+  const int cand[2] = {13, 10};
+  for (int i = 0; i < 2; ++i) {
+    const int mtw = cand[i], cap = chain_cap(128, mtw);
+    if (cap - 2 * 7 * dil < 32) continue;
+    int tiles, own;
+    chain_tiling_for(cap, T, dil, &tiles, &own);
+    const double cost = (double)(((long long)B * tiles + cus - 1) / cus) * (4.7 + 26.3 * mtw);
+    if (cost < best_cost * 0.97) { best_cost = cost; best = mtw; }
+  }
+  return best;
+}
+
 hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
   if (p.B <= 0) return hipSuccess;
   if ((p.ldy1 | p.ldy2 | p.ldw) & 3) return hipErrorInvalidValue;
@@ -499,7 +516,9 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
         default: return launch_res2_f16_variant<64, 7>(p, stream);
       }
     }
-    return small ? launch_res2_f16_variant<128, 7>(p, stream) : launch_res2_f16_variant<128, 13>(p, stream);
+    if (small) return launch_res2_f16_variant<128, 7>(p, stream);
+    return chain_pick_mtw128(p.B, p.T, p.dil) == 10 ? launch_res2_f16_variant<128, 10>(p, stream)
+                                                    : launch_res2_f16_variant<128, 13>(p, stream);
   }
   if (!small && chain4_takes(p)) return launch_res2_chain4(p, stream);
   if (p.W == 64 && !small) {
@@ -511,7 +530,9 @@ hipError_t launch_res2_chain(const Res2ChainParams& p, hipStream_t stream) {
     }
   }
   if (p.W == 64) return small ? launch_res2_variant<64, 4>(p, stream) : launch_res2_variant<64, 7>(p, stream);
-  return small ? launch_res2_variant<128, 7>(p, stream) : launch_res2_variant<128, 13>(p, stream);
+  if (small) return launch_res2_variant<128, 7>(p, stream);
+  return chain_pick_mtw128(p.B, p.T, p.dil) == 10 ? launch_res2_variant<128, 10>(p, stream)
+                                                  : launch_res2_variant<128, 13>(p, stream);
 }
 
 }  // namespace wsamd
